@@ -1,0 +1,282 @@
+"""Synthetic random-motif molecules and the MolGraph.tensorize() input layout.
+
+Two things live here, both pure host code (numpy, no rdkit, no networkx):
+
+* ``random_molecule`` / ``random_batch`` -- the seed-deterministic "random-motif
+  graph" generator that BASELINE.json's configs name: a
+  random tree of motifs, each a bond or a 5-/6-ring, a child sharing exactly
+  one atom with its parent, valence capped at 4.
+* ``tensorize`` -- a restatement of the *layout* produced by the reference's
+  ``MolGraph.tensorize`` / ``tensorize_graph`` (reference ggpm/mol_graph.py:199-281,
+  ``create_pad_tensor`` ggpm/nnutils.py:105-110): 1-indexed nodes and messages,
+  pad row 0, ``agraph``/``bgraph`` zero padded to ``max_len + 1`` columns.  The
+  chemistry that normally fills those tensors (rdkit) is out of scope; the
+  layout is the contract the encoder consumes.
+
+``tests/golden/make_golden.py`` feeds the same molecule specs through the
+reference's own ``MolGraph.tensorize`` and the committed fixtures pin that this
+restatement yields identical arrays.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# Indices into the reference's COMMON_ATOMS table (ggpm/vocab.py:64-68) of the six
+# labels the generator draws from: C, N, O, S, F, Cl (all neutral).
+SYNTH_ATOM_IDS = (5, 21, 24, 30, 13, 8)
+ATOM_VOCAB_SIZE = 38      # len(COMMON_ATOMS)
+NUM_BOND_TYPES = 4        # len(MolGraph.BOND_LIST), ggpm/mol_graph.py:14-15
+MAX_POS = 20              # MolGraph.MAX_POS, ggpm/mol_graph.py:16
+
+
+@dataclass
+class MolSpec:
+    """One synthetic molecule: atom graph + motif tree (what MolGraph.__init__ derives)."""
+    atom_label: List[int]                                   # atom-vocab id per atom
+    bonds: Dict[Tuple[int, int], int]                       # (a<b) -> bond type
+    clusters: List[List[int]]                               # atoms of each motif, motif 0 = root
+    parent: List[int]                                       # motif tree parent, -1 for root
+    motif_label: List[Tuple[int, int]]                      # (motif id, attachment id) per motif
+    # filled by label_tree():
+    tree_edge_label: Dict[Tuple[int, int], int] = field(default_factory=dict)
+    bond_pos: Dict[Tuple[int, int], int] = field(default_factory=dict)   # directed (u,v) -> child order
+    order: List[Tuple[int, Optional[int], int]] = field(default_factory=list)
+
+    @property
+    def n_atoms(self) -> int:
+        return len(self.atom_label)
+
+    @property
+    def n_motifs(self) -> int:
+        return len(self.clusters)
+
+    def atom_adj(self) -> List[List[int]]:
+        adj: List[List[int]] = [[] for _ in range(self.n_atoms)]
+        for (a, b) in self.bonds:
+            adj[a].append(b)
+            adj[b].append(a)
+        return [sorted(x) for x in adj]
+
+    def tree_adj(self) -> List[List[int]]:
+        adj: List[List[int]] = [[] for _ in range(self.n_motifs)]
+        for c, p in enumerate(self.parent):
+            if p >= 0:
+                adj[c].append(p)
+                adj[p].append(c)
+        return [sorted(x) for x in adj]
+
+    def bond_type(self, a: int, b: int) -> int:
+        return self.bonds[(a, b) if a < b else (b, a)]
+
+
+def label_tree(spec: MolSpec) -> None:
+    """Edge labels, child-order positions and the decode order.
+
+    Follows reference ggpm/mol_graph.py:121-178 (``MolGraph.label_tree``): DFS from
+    motif 0 over children in ascending id; parent->child tree edge gets label 0,
+    child->parent gets ``idx + 1``; when the parent motif has more than two atoms,
+    bonds from the child's own atoms into the shared atom carry ``(bond, child order)``.
+    """
+    adj = spec.tree_adj()
+    spec.tree_edge_label.clear()
+    spec.bond_pos.clear()
+    spec.order = []
+    pa = {}
+    atom_adj = spec.atom_adj()
+
+    # iterative DFS that reproduces the recursive visiting order
+    def dfs(x: int, fa: int) -> None:
+        pa[x] = fa
+        children = [y for y in adj[x] if y != fa]
+        for idx, y in enumerate(children):
+            spec.tree_edge_label[(x, y)] = 0
+            spec.tree_edge_label[(y, x)] = idx + 1
+            spec.order.append((x, y, 1))
+            dfs(y, x)
+            spec.order.append((y, x, 0))
+
+    import sys
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, 10 * spec.n_motifs + 100))
+    try:
+        dfs(0, -1)
+    finally:
+        sys.setrecursionlimit(old)
+    spec.order.append((0, None, 0))
+
+    for i, cls in enumerate(spec.clusters):
+        p = pa[i]
+        if p < 0 or len(spec.clusters[p]) <= 2:
+            continue
+        pa_cls = set(spec.clusters[p])
+        inter_atoms = set(cls) & pa_cls
+        child_order = spec.tree_edge_label[(i, p)]
+        diff = set(cls) - pa_cls
+        for fa_atom in inter_atoms:
+            for ch_atom in atom_adj[fa_atom]:
+                if ch_atom in diff and (ch_atom, fa_atom) not in spec.bond_pos:
+                    spec.bond_pos[(ch_atom, fa_atom)] = child_order
+
+
+def random_molecule(rng: random.Random, motifs: Tuple[int, int] = (7, 11),
+                    n_motif_vocab: int = 500, attach_per_motif: int = 3,
+                    n_attach_vocab: Optional[int] = None) -> MolSpec:
+    """One random-motif molecule (SURVEY.md section 8d generator)."""
+    M = rng.randint(motifs[0], motifs[1])
+    atom_label: List[int] = []
+    bonds: Dict[Tuple[int, int], int] = {}
+    degree: List[int] = []
+    clusters: List[List[int]] = []
+    parent: List[int] = []
+
+    def new_atom() -> int:
+        atom_label.append(SYNTH_ATOM_IDS[rng.randrange(len(SYNTH_ATOM_IDS))])
+        degree.append(0)
+        return len(atom_label) - 1
+
+    def add_bond(a: int, b: int) -> None:
+        bonds[(a, b) if a < b else (b, a)] = rng.randrange(NUM_BOND_TYPES)
+        degree[a] += 1
+        degree[b] += 1
+
+    def motif_size() -> int:
+        u = rng.random()
+        return 2 if u < 0.25 else (5 if u < 0.5 else 6)
+
+    def build(shared: Optional[int]) -> List[int]:
+        size = motif_size()
+        atoms = [shared if shared is not None else new_atom()]
+        atoms += [new_atom() for _ in range(size - 1)]
+        for k in range(size - 1):
+            add_bond(atoms[k], atoms[k + 1])
+        if size > 2:
+            add_bond(atoms[-1], atoms[0])
+        return atoms
+
+    clusters.append(build(None))
+    parent.append(-1)
+    while len(clusters) < M:
+        cand = [(c, a) for c in range(len(clusters)) for a in clusters[c] if degree[a] <= 2]
+        if not cand:
+            break
+        # random parent first (random tree), then a free atom of it
+        parents = sorted({c for c, _ in cand})
+        p = parents[rng.randrange(len(parents))]
+        free = [a for c, a in cand if c == p]
+        a = free[rng.randrange(len(free))]
+        clusters.append(build(a))
+        parent.append(p)
+
+    if n_attach_vocab is None:
+        n_attach_vocab = n_motif_vocab * attach_per_motif
+    motif_label = []
+    for _ in clusters:
+        m = rng.randrange(n_motif_vocab)
+        if n_attach_vocab == n_motif_vocab * attach_per_motif:
+            a = m * attach_per_motif + rng.randrange(attach_per_motif)
+        else:
+            a = rng.randrange(n_attach_vocab)
+        motif_label.append((m, a))
+    spec = MolSpec(atom_label, bonds, clusters, parent, motif_label)
+    label_tree(spec)
+    return spec
+
+
+def random_batch(seed: int, batch_size: int, **kw) -> List[MolSpec]:
+    rng = random.Random(seed)
+    return [random_molecule(rng, **kw) for _ in range(batch_size)]
+
+
+def _pad(rows: List[List[int]]) -> np.ndarray:
+    """create_pad_tensor (reference ggpm/nnutils.py:105-110): width max_len + 1, zero padded."""
+    width = max(len(r) for r in rows) + 1
+    out = np.zeros((len(rows), width), dtype=np.int32)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return out
+
+
+def _tensorize_level(adjs: Sequence[List[List[int]]], node_label, edge_attr):
+    """Restatement of MolGraph.tensorize_graph (reference ggpm/mol_graph.py:238-281).
+
+    ``adjs[b]`` is the ascending adjacency of molecule b, ``node_label(b, v)`` the
+    fnode entry, ``edge_attr(b, u, v)`` the (attr0, attr1) pair of the directed edge.
+    """
+    fnode: List = [None]
+    fmess: List[Tuple[int, int, int, int]] = [(0, 0, 0, 0)]
+    agraph: List[List[int]] = [[]]
+    bgraph: List[List[int]] = [[]]
+    scope: List[Tuple[int, int]] = []
+    for b, adj in enumerate(adjs):
+        offset = len(fnode)
+        n = len(adj)
+        scope.append((offset, n))
+        for v in range(n):
+            fnode.append(node_label(b, v))
+            agraph.append([])
+        edge_id: Dict[Tuple[int, int], int] = {}
+        for u in range(n):
+            for v in adj[u]:
+                a0, a1 = edge_attr(b, u, v)
+                fmess.append((u + offset, v + offset, a0, a1))
+                eid = len(fmess) - 1
+                edge_id[(u, v)] = eid
+                agraph[v + offset].append(eid)
+                bgraph.append([])
+        # predecessors(u) of the reference DiGraph iterate in edge insertion order,
+        # which for an ascending adjacency is ascending w.
+        for u in range(n):
+            for v in adj[u]:
+                eid = edge_id[(u, v)]
+                for w in adj[u]:
+                    if w == v:
+                        continue
+                    bgraph[eid].append(edge_id[(w, u)])
+    fnode[0] = fnode[1]
+    return (np.asarray(fnode, dtype=np.int32), np.asarray(fmess, dtype=np.int32),
+            _pad(agraph), _pad(bgraph), scope)
+
+
+def tensorize(batch: Sequence[MolSpec]):
+    """(tree_tensors, graph_tensors) in the reference's A0 layout (numpy int32 + host scope).
+
+    tree  = (fnode[Nt+1,2], fmess[Et+1,4], agraph, bgraph, cgraph, scope)   (mol_graph.py:233)
+    graph = (fnode[Na+1],   fmess[Ea+1,4], agraph, bgraph, scope)           (mol_graph.py:281)
+    """
+    tree_adjs = [m.tree_adj() for m in batch]
+    atom_adjs = [m.atom_adj() for m in batch]
+
+    tfnode, tfmess, tagraph, tbgraph, tscope = _tensorize_level(
+        tree_adjs,
+        lambda b, v: batch[b].motif_label[v],
+        lambda b, u, v: (batch[b].tree_edge_label[(u, v)], 0))
+    gfnode, gfmess, gagraph, gbgraph, gscope = _tensorize_level(
+        atom_adjs,
+        lambda b, v: batch[b].atom_label[v],
+        lambda b, u, v: (batch[b].bond_type(u, v), batch[b].bond_pos.get((u, v), 0)))
+
+    max_cls = max(len(c) for m in batch for c in m.clusters)
+    cgraph = np.zeros((tfnode.shape[0], max_cls), dtype=np.int32)
+    for b, m in enumerate(batch):
+        toff, aoff = tscope[b][0], gscope[b][0]
+        for i, cls in enumerate(m.clusters):
+            cgraph[toff + i, :len(cls)] = [a + aoff for a in cls]
+
+    tree = (tfnode, tfmess, tagraph, tbgraph, cgraph, tscope)
+    graph = (gfnode, gfmess, gagraph, gbgraph, gscope)
+    return tree, graph
+
+
+def batch_stats(tree, graph) -> dict:
+    """Sizes (excluding the pad rows) and mean real predecessors per message."""
+    out = {}
+    for name, t in (("tree", tree), ("atom", graph)):
+        bg = t[3]
+        E = bg.shape[0] - 1
+        out[name] = dict(N=t[0].shape[0] - 1, E=E, K=bg.shape[1], A=t[2].shape[1],
+                         dbar=float((bg[1:] != 0).sum()) / max(E, 1))
+    return out

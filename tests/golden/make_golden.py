@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py
+
+What it does
+------------
+* imports the reference's hot-path modules (ggpm/rnn.py, encoder.py, mol_graph.py,
+  property_vae.py) from /root/reference.  ``rdkit`` is not installed here and is never
+  called on this path, so empty stand-in modules are registered for the import
+  statements only (SURVEY.md section 8c recipe);
+* builds synthetic molecules with ``ggpm_amd.synth`` and pushes them through the
+  reference's OWN ``MolGraph.tensorize`` (only ``MolGraph.__init__``, the rdkit part,
+  is replaced by a constructor that fills the attributes from the synthetic spec);
+* loads seeded parameters into the reference's ``HierMPNEncoder`` and records, per case:
+  the A0 input tensors, the four encoder outputs, message states after depth 1 and D,
+  KL from the reference's ``HierPropertyVAE.rsample`` and parameter gradients of
+  ``beta*KL + sum_k <c_k, out_k>`` (c_k seeded).
+
+Fixtures are DATA (inputs / expected outputs); no reference source text is stored.
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+
+
+def import_reference():
+    for name in ["rdkit", "rdkit.Chem", "rdkit.Chem.AllChem", "rdkit.Chem.rdchem", "rdkit.DataStructs",
+                 "rdkit.RDLogger", "rdkit.Chem.Descriptors", "rdkit.Chem.rdmolops"]:
+        m = MagicMock()
+        m.__path__ = []
+        sys.modules[name] = m
+    pkg = types.ModuleType("ggpm")
+    pkg.__path__ = [os.path.join(REF, "ggpm")]
+    sys.modules["ggpm"] = pkg
+    import ggpm.rnn, ggpm.encoder, ggpm.mol_graph, ggpm.vocab, ggpm.property_vae  # noqa
+    return sys.modules["ggpm"]
+
+
+import torch  # noqa: E402
+import networkx as nx  # noqa: E402
+
+from ggpm_amd import synth  # noqa: E402
+from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict  # noqa: E402
+
+CASES = [
+    # name, rnn, H, latent, depthT, depthG, B, motifs, n_motif, n_attach, seed, full_grads
+    ("tiny_gru_s0", "GRU", 16, 8, 3, 3, 2, (2, 4), 11, 33, 0, True),
+    ("tiny_gru_s1", "GRU", 16, 8, 3, 4, 3, (1, 5), 11, 33, 1, True),
+    ("tiny_lstm_s0", "LSTM", 16, 8, 3, 3, 2, (2, 4), 11, 33, 0, True),
+    ("tiny_lstm_s2", "LSTM", 24, 8, 2, 5, 3, (1, 5), 11, 33, 2, True),
+    ("cfg_gru_s0", "GRU", 300, 32, 20, 20, 4, (7, 11), 50, 150, 0, False),
+    ("cfg_gru_s1", "GRU", 300, 32, 20, 20, 4, (7, 11), 50, 150, 1, False),
+    ("cfg_lstm_s0", "LSTM", 300, 32, 20, 20, 4, (7, 11), 50, 150, 0, False),
+    ("cfg_lstm_s2", "LSTM", 250, 24, 20, 20, 5, (7, 11), 50, 150, 2, False),
+]
+BETA = 0.1
+N_PROBE = 64
+
+
+class FakePairVocab:
+    """dict-backed stand-in for PairVocab (only __getitem__/size are used on this path)."""
+
+    def __init__(self, n_motif, n_attach):
+        self.n = (n_motif, n_attach)
+
+    def __getitem__(self, label):
+        return int(label[0][1:]), int(label[1][1:])
+
+    def size(self):
+        return self.n
+
+
+def patched_init(self, spec, mol=None):
+    """Replacement for MolGraph.__init__ (the rdkit part): fill attributes from a MolSpec."""
+    from ggpm.vocab import COMMON_ATOMS
+    self.smiles = "synthetic"
+    g = nx.DiGraph()
+    for a, lab in enumerate(spec.atom_label):
+        g.add_node(a, label=COMMON_ATOMS[lab])
+    adj = spec.atom_adj()
+    for u in range(spec.n_atoms):
+        for v in adj[u]:
+            bt = spec.bond_type(u, v)
+            pos = spec.bond_pos.get((u, v))
+            g.add_edge(u, v, label=(bt, pos) if pos is not None else bt)
+    self.mol_graph = g
+    t = nx.DiGraph()
+    for i, cls in enumerate(spec.clusters):
+        m, a = spec.motif_label[i]
+        t.add_node(i, label=("m%d" % m, "a%d" % a), smiles="m%d" % m, ismiles="a%d" % a,
+                   inter_label=[], cluster=list(cls), assm_cands=[])
+    tadj = spec.tree_adj()
+    for u in range(spec.n_motifs):
+        for v in tadj[u]:
+            t.add_edge(u, v, label=spec.tree_edge_label[(u, v)])
+    self.mol_tree = t
+    self.clusters = [list(c) for c in spec.clusters]
+    self.order = list(spec.order)
+
+
+def probe_indices(name, numel, seed):
+    rs = np.random.RandomState((hash_name(name) + seed) % (2 ** 31))
+    return rs.randint(0, numel, size=min(N_PROBE, numel))
+
+
+def hash_name(name):
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % (2 ** 31)
+    return h
+
+
+def loss_coeffs(shapes, seed):
+    rs = np.random.RandomState(seed + 1000)
+    return [rs.standard_normal(s).astype(np.float32) for s in shapes]
+
+
+def main():
+    ggpm = import_reference()
+    from ggpm.mol_graph import MolGraph
+    from ggpm.encoder import HierMPNEncoder
+    from ggpm.vocab import common_atom_vocab
+    from ggpm.property_vae import HierPropertyVAE
+    from ggpm.nnutils import make_cuda
+    MolGraph.__init__ = patched_init
+
+    for (name, rnn, H, latent, dT, dG, B, motifs, n_motif, n_attach, seed, full) in CASES:
+        torch.manual_seed(seed)
+        specs = synth.random_batch(seed, B, motifs=motifs, n_motif_vocab=n_motif, n_attach_vocab=n_attach)
+        vocab = FakePairVocab(n_motif, n_attach)
+        batch = [[s, 0.0, 0.0] for s in specs]
+        _, _, (tree_t, graph_t), orders, _, _ = MolGraph.tensorize(batch, vocab, common_atom_vocab)
+        tree_np = [np.asarray(x.numpy()) for x in tree_t[:-1]] + [tree_t[-1]]
+        graph_np = [np.asarray(x.numpy()) for x in graph_t[:-1]] + [graph_t[-1]]
+
+        # our own layout restatement must agree with the reference's tensorize
+        mine_tree, mine_graph = synth.tensorize(specs)
+        for a, b in zip(tree_np[:-1], mine_tree[:-1]):
+            assert a.shape == b.shape and (a == b).all(), "tree layout mismatch in " + name
+        for a, b in zip(graph_np[:-1], mine_graph[:-1]):
+            assert a.shape == b.shape and (a == b).all(), "graph layout mismatch in " + name
+        assert [tuple(x) for x in tree_np[-1]] == [tuple(x) for x in mine_tree[-1]]
+        assert [tuple(x) for x in graph_np[-1]] == [tuple(x) for x in mine_graph[-1]]
+
+        shapes = encoder_param_shapes(rnn, H, n_motif, n_attach)
+        sd = seeded_state_dict(shapes, seed)
+        head = seeded_state_dict(vae_head_shapes(H, latent), seed + 7)
+
+        out = {}
+        for dtype, tag in ((torch.float32, ""), (torch.float64, "_f64")):
+            torch.set_default_dtype(dtype)   # the reference allocates its states with the default dtype
+            enc = HierMPNEncoder(vocab, common_atom_vocab, rnn, H, H, dT, dG, 0.0)
+            missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            enc = enc.to(dtype)
+            for attr in ("E_a", "E_b", "E_apos", "E_pos"):
+                setattr(enc, attr, getattr(enc, attr).to(dtype))
+            R_mean = torch.nn.Linear(H, latent).to(dtype)
+            R_var = torch.nn.Linear(H, latent).to(dtype)
+            with torch.no_grad():
+                R_mean.weight.copy_(torch.from_numpy(head["R_mean.weight"])); R_mean.bias.copy_(torch.from_numpy(head["R_mean.bias"]))
+                R_var.weight.copy_(torch.from_numpy(head["R_var.weight"])); R_var.bias.copy_(torch.from_numpy(head["R_var.bias"]))
+            tt, gt = make_cuda((tree_np, graph_np))
+
+            captured = {}
+            hk = [enc.graph_encoder.rnn.register_forward_hook(lambda m, i, o: captured.__setitem__("atom", o)),
+                  enc.inter_encoder.rnn.register_forward_hook(lambda m, i, o: captured.__setitem__("inter", o)),
+                  enc.tree_encoder.rnn.register_forward_hook(lambda m, i, o: captured.__setitem__("tree", o))]
+            hroot, hnode, hinter, hatom = enc(tt, gt)
+            for h in hk:
+                h.remove()
+            outs = [hroot, hnode, hinter, hatom]
+            z, kl = HierPropertyVAE.rsample(None, hroot, R_mean, R_var, perturb=False)
+            coeffs = loss_coeffs([tuple(o.shape) for o in outs], seed)
+            loss = BETA * kl
+            for c, o in zip(coeffs, outs):
+                loss = loss + (torch.from_numpy(c).to(dtype) * o).sum()
+            loss.backward()
+
+            for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
+                out[k + tag] = o.detach().numpy()
+            for lvl in ("atom", "inter", "tree"):
+                o = captured[lvl]
+                o = o[0] if isinstance(o, tuple) else o
+                out[lvl + "_hD" + tag] = o.detach().numpy()
+            # state after ONE depth on the atom level (depth attribute drives the loop)
+            with torch.no_grad():
+                emb = enc.embed_graph(gt)
+                saved = enc.graph_encoder.rnn.depth
+                enc.graph_encoder.rnn.depth = 1
+                h1 = enc.graph_encoder.rnn(emb[1], emb[3])
+                enc.graph_encoder.rnn.depth = saved
+                h1 = h1[0] if isinstance(h1, tuple) else h1
+            out["atom_h1" + tag] = h1.numpy()
+            out["kl" + tag] = kl.detach().numpy()
+            out["z" + tag] = z.detach().numpy()
+            out["loss" + tag] = loss.detach().numpy()
+
+            named = list(enc.named_parameters()) + [("R_mean.weight", R_mean.weight), ("R_mean.bias", R_mean.bias),
+                                                    ("R_var.weight", R_var.weight), ("R_var.bias", R_var.bias)]
+            for pname, prm in named:
+                g = prm.grad.detach().numpy() if prm.grad is not None else np.zeros(tuple(prm.shape))
+                if full:
+                    out["grad/" + pname + tag] = g
+                else:
+                    idx = probe_indices(pname, g.size, seed)
+                    out["gprobe/" + pname + tag] = g.reshape(-1)[idx]
+                    out["gstat/" + pname + tag] = np.array([g.sum(dtype=np.float64), np.sqrt((g.astype(np.float64) ** 2).sum()),
+                                                            np.abs(g).max()])
+
+        torch.set_default_dtype(torch.float32)
+        for i, k in enumerate(("fnode", "fmess", "agraph", "bgraph", "cgraph")):
+            out["tree_" + k] = tree_np[i].astype(np.int32)
+        out["tree_scope"] = np.asarray(tree_np[-1], dtype=np.int32)
+        for i, k in enumerate(("fnode", "fmess", "agraph", "bgraph")):
+            out["graph_" + k] = graph_np[i].astype(np.int32)
+        out["graph_scope"] = np.asarray(graph_np[-1], dtype=np.int32)
+        out["meta"] = np.array([H, latent, dT, dG, B, n_motif, n_attach, seed, motifs[0], motifs[1], int(full)], dtype=np.int64)
+        out["rnn"] = np.array(rnn)
+        out["beta"] = np.array(BETA)
+        # keep fixtures small: the float64 pass is stored rounded to fp32 ("best possible fp32 answer"),
+        # and for the config-shaped cases the bulky per-message states are kept for the fp32 pass only
+        for k in list(out.keys()):
+            if k.endswith("_f64"):
+                if not full and (k.startswith("atom_h") or k.startswith("inter_h") or k.startswith("tree_h")):
+                    del out[k]
+                elif k not in ("kl_f64", "loss_f64"):
+                    out[k] = out[k].astype(np.float32)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-14s E_atom=%d E_tree=%d  kl=%.6f loss=%.6f  -> %s (%.1f KB)" % (
+            name, graph_np[1].shape[0] - 1, tree_np[1].shape[0] - 1, float(out["kl"]), float(out["loss"]),
+            os.path.basename(path), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
