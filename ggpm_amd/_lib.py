@@ -1,0 +1,76 @@
+"""ctypes binding of libggpm_hip.so (include/ggpm_hip.h).  Fails loudly: there is no CPU fallback.
+
+The library is built in-tree by ``python -m ggpm_amd.build`` (``__graft_entry__.build()``).  Loading it does
+not need a GPU (hipcc cross-compiles; the CPU tests check that every declared symbol is exported), calling
+a compute entry point does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, POINTER
+
+from . import build as _build
+
+_LIB = None
+
+# name -> (restype, [argtypes]); mirrors include/ggpm_hip.h one to one
+P = c_void_p
+I = c_int
+SIGNATURES = {
+    "ggpm_version": (I, []),
+    "ggpm_error_string": (c_char_p, [I]),
+    "ggpm_padded_hidden": (I, [I]),
+    "ggpm_padded_to_csr": (I, [P, I, I, P, P, P]),
+    "ggpm_csr_transpose": (I, [P, P, I, I, P, P, P, P]),
+    "ggpm_extract_column": (I, [P, I, I, I, P, P]),
+    "ggpm_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "ggpm_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, I, P, I, I, I, P, c_size_t, P]),
+    "ggpm_colsum": (I, [P, I, I, I, P, P, P]),
+    "ggpm_act_backward": (I, [P, P, I, I, I, I, I, P, P]),
+    "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, P]),
+    "ggpm_gather_rows": (I, [P, I, P, I, I, P, I, I, P]),
+    "ggpm_onehot": (I, [P, I, I, P, I, I, P]),
+    "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
+    "ggpm_gru_pack_floats": (c_size_t, [I]),
+    "ggpm_gru_forward": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, I, P]),
+    "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),
+    "ggpm_gru_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                              P, I, P, I, P, P, I, P, c_size_t, P]),
+    "ggpm_lstm_pack_floats": (c_size_t, [I]),
+    "ggpm_lstm_forward": (I, [I, I, I, P, P, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "ggpm_lstm_backward_workspace_bytes": (c_size_t, [I, I, I]),
+    "ggpm_lstm_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P,
+                               P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_timing_enable": (I, [I]),
+    "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if the .so is absent) and type every entry point."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("ggpm_amd: %s is missing; run `python -m ggpm_amd.build` (no CPU fallback exists)" % path)
+        _build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header / library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().ggpm_error_string(code).decode()
+        raise RuntimeError("ggpm_amd: %s failed: %s (code %d)" % (what, msg, code))

@@ -1,0 +1,38 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA f32, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ggpm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GGPM_WAVE 64
+
+#define GGPM_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return GGPM_ERR_LAUNCH; \
+    } while (0)
+
+static inline int ggpm_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ggpm_round_up(int a, int b) { return ggpm_ceil_div(a, b) * b; }
+
+__device__ __forceinline__ float ggpm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float4 ggpm_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void ggpm_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
+    return make_float4(ggpm_sigmoid(a.x), ggpm_sigmoid(a.y), ggpm_sigmoid(a.z), ggpm_sigmoid(a.w));
+}
+__device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Optional per-launch timing (bench.py roofline): implemented in capi.hip.
+void ggpm_timing_begin(int which, hipStream_t s, double flops);
+void ggpm_timing_end(int which, hipStream_t s);

@@ -1,0 +1,122 @@
+// Row gathers and segmented sums over CSR lists (HBM / L2 bound; fp32 rows of H floats).
+// One wave owns one destination row and walks its (short) list; lanes stride the feature dimension
+// with 16-byte accesses when the strides allow it, so every load/store is a coalesced row segment.
+#include "common.h"
+
+namespace {
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) segment_sum_k(const float* __restrict__ src, int ld_src,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, int rows, int width,
+                                                     float* __restrict__ out, int ld_out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    float* dst = out + (size_t)r * ld_out;
+    if (VEC) {
+        for (int c = lane * 4; c < width; c += 256) {
+            float4 acc = accumulate ? ggpm_ld4(dst + c) : ggpm_zero4();
+            for (int j = lo; j < hi; ++j) acc = acc + ggpm_ld4(src + (size_t)col[j] * ld_src + c);
+            ggpm_st4(dst + c, acc);
+        }
+    } else {
+        for (int c = lane; c < width; c += 64) {
+            float acc = accumulate ? dst[c] : 0.f;
+            for (int j = lo; j < hi; ++j) acc += src[(size_t)col[j] * ld_src + c];
+            dst[c] = acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ table, int ld_table,
+                                                     const int32_t* __restrict__ idx, int rows, int width,
+                                                     float* __restrict__ out, int ld_out, int col_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int id = idx[r];
+    float* dst = out + (size_t)r * ld_out + col_off;
+    if (id < 0) {
+        for (int c = lane; c < width; c += 64) dst[c] = 0.f;
+    } else {
+        const float* s = table + (size_t)id * ld_table;
+        for (int c = lane; c < width; c += 64) dst[c] = s[c];
+    }
+}
+
+__global__ void onehot_k(const int32_t* __restrict__ idx, int rows, int classes, float* __restrict__ out,
+                         int ld_out, int col_off) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= classes) return;
+    out[(size_t)r * ld_out + col_off + c] = (idx[r] == c) ? 1.f : 0.f;
+}
+
+__global__ void embed_graph_k(const int64_t* __restrict__ fnode, int N1, const int64_t* __restrict__ fmess,
+                              int E1, int atom_size, int bond_types, int max_pos, float* __restrict__ hnode,
+                              int ld_n, float* __restrict__ hmess, int ld_m) {
+    const int r = blockIdx.x;
+    const int c = threadIdx.x;
+    if (r < N1) {
+        if (c < ld_n) hnode[(size_t)r * ld_n + c] = (c < atom_size && fnode[r] == c) ? 1.f : 0.f;
+    } else {
+        const int e = r - N1;
+        if (e < E1 && c < ld_m) {
+            const int64_t* f = fmess + (size_t)e * 4;
+            const int64_t a = fnode[f[0]];
+            float v = 0.f;
+            if (c < atom_size) v = (a == c) ? 1.f : 0.f;
+            else if (c < atom_size + bond_types) v = (f[2] == c - atom_size) ? 1.f : 0.f;
+            else if (c < atom_size + bond_types + max_pos) v = (f[3] == c - atom_size - bond_types) ? 1.f : 0.f;
+            hmess[(size_t)e * ld_m + c] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const int32_t* col,
+                                int rows, int width, float* out, int ld_out, int accumulate,
+                                ggpm_stream_t stream) {
+    if (!src || !rowptr || !col || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (width % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) &&
+                     (((uintptr_t)src & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int grid = ggpm_ceil_div(rows, 4);
+    if (vec) segment_sum_k<true><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate);
+    else segment_sum_k<false><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
+                                float* out, int ld_out, int col_off, ggpm_stream_t stream) {
+    if (!table || !idx || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
+    gather_rows_k<<<ggpm_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(table, ld_table, idx, rows, width, out,
+                                                                          ld_out, col_off);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off,
+                           ggpm_stream_t stream) {
+    if (!idx || !out || rows <= 0 || classes <= 0) return GGPM_ERR_ARG;
+    dim3 grid(ggpm_ceil_div(classes, 64), rows);
+    onehot_k<<<grid, 64, 0, (hipStream_t)stream>>>(idx, rows, classes, out, ld_out, col_off);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1, int atom_size,
+                                int bond_types, int max_pos, float* hnode, int ld_n, float* hmess, int ld_m,
+                                ggpm_stream_t stream) {
+    if (!fnode || !fmess || !hnode || !hmess || N1 <= 0 || E1 <= 0) return GGPM_ERR_ARG;
+    if (ld_n > 256 || ld_m > 256 || ld_n < atom_size || ld_m < atom_size + bond_types + max_pos)
+        return GGPM_ERR_UNSUPPORTED;
+    embed_graph_k<<<N1 + E1, 256, 0, (hipStream_t)stream>>>(fnode, N1, fmess, E1, atom_size, bond_types, max_pos,
+                                                           hnode, ld_n, hmess, ld_m);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

@@ -1,0 +1,142 @@
+// Graph layout kernels: MolGraph.tensorize()'s zero-padded int64 neighbour tables -> int32 CSR,
+// and the CSR transposes that make every backward scatter a deterministic gather.
+// Integer/byte work, HBM/latency bound; sizes are a few thousand rows per batch.
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 1024;
+
+__global__ void count_nonzero_rows(const int64_t* __restrict__ padded, int rows, int width,
+                                   int32_t* __restrict__ counts) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t* p = padded + (size_t)r * width;
+    int c = 0;
+    for (int k = 0; k < width; ++k) c += (p[k] != 0);
+    counts[r] = c;
+}
+
+// Exclusive scan of counts[0..n) into out[0..n], out[n] = total. One block; in-place allowed.
+__global__ void __launch_bounds__(SCAN_THREADS) exclusive_scan_1block(const int32_t* counts, int n,
+                                                                      int32_t* out) {
+    __shared__ int32_t partial[SCAN_THREADS];
+    const int t = threadIdx.x;
+    const int ipt = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(t * ipt, n), hi = min(lo + ipt, n);
+    int32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    partial[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        int32_t v = (t >= off) ? partial[t - off] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    int32_t run = partial[t] - sum;   // exclusive prefix of this thread's segment
+    for (int i = lo; i < hi; ++i) {
+        int32_t c = counts[i];
+        out[i] = run;
+        run += c;
+    }
+    if (t == SCAN_THREADS - 1) out[n] = partial[t];
+}
+
+__global__ void fill_csr_from_padded(const int64_t* __restrict__ padded, int rows, int width,
+                                     const int32_t* __restrict__ rowptr, int32_t* __restrict__ col) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t* p = padded + (size_t)r * width;
+    int o = rowptr[r];
+    for (int k = 0; k < width; ++k) {
+        int64_t v = p[k];
+        if (v != 0) col[o++] = (int32_t)v;
+    }
+}
+
+__global__ void zero_i32(int32_t* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+__global__ void count_columns(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int rows,
+                              int ncols, int32_t* __restrict__ counts) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+        int c = col[j];
+        if (c >= 0 && c < ncols) atomicAdd(&counts[c], 1);   // integer atomics: the COUNT is order independent
+    }
+}
+
+__global__ void fill_transpose(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int rows,
+                               int ncols, const int32_t* __restrict__ rowptrT, int32_t* __restrict__ cursor,
+                               int32_t* __restrict__ colT) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+        int c = col[j];
+        if (c >= 0 && c < ncols) {
+            int pos = atomicAdd(&cursor[c], 1);
+            colT[rowptrT[c] + pos] = r;
+        }
+    }
+}
+
+// Slot order above depends on atomic arrival; sorting each (short) list ascending makes the
+// transpose -- and therefore every floating-point sum that walks it -- bitwise reproducible.
+__global__ void sort_lists(const int32_t* __restrict__ rowptrT, int32_t* __restrict__ colT, int ncols) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    int lo = rowptrT[c], hi = rowptrT[c + 1];
+    for (int i = lo + 1; i < hi; ++i) {
+        int32_t v = colT[i];
+        int j = i - 1;
+        while (j >= lo && colT[j] > v) { colT[j + 1] = colT[j]; --j; }
+        colT[j + 1] = v;
+    }
+}
+
+__global__ void extract_column_k(const int64_t* __restrict__ mat, int rows, int width, int column,
+                                 int32_t* __restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = (int32_t)mat[(size_t)r * width + column];
+}
+
+}  // namespace
+
+extern "C" int ggpm_padded_to_csr(const int64_t* padded, int rows, int width, int32_t* rowptr, int32_t* col,
+                                  ggpm_stream_t stream) {
+    if (!padded || !rowptr || !col || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = 256, B = ggpm_ceil_div(rows, T);
+    count_nonzero_rows<<<B, T, 0, s>>>(padded, rows, width, rowptr);
+    exclusive_scan_1block<<<1, SCAN_THREADS, 0, s>>>(rowptr, rows, rowptr);
+    fill_csr_from_padded<<<B, T, 0, s>>>(padded, rows, width, rowptr, col);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int rows, int ncols,
+                                  int32_t* rowptrT, int32_t* colT, int32_t* cursor, ggpm_stream_t stream) {
+    if (!rowptr || !col || !rowptrT || !colT || !cursor || rows <= 0 || ncols <= 0) return GGPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = 256;
+    zero_i32<<<ggpm_ceil_div(ncols + 1, T), T, 0, s>>>(rowptrT, ncols + 1);
+    zero_i32<<<ggpm_ceil_div(ncols, T), T, 0, s>>>(cursor, ncols);
+    count_columns<<<ggpm_ceil_div(rows, T), T, 0, s>>>(rowptr, col, rows, ncols, rowptrT);
+    exclusive_scan_1block<<<1, SCAN_THREADS, 0, s>>>(rowptrT, ncols, rowptrT);
+    fill_transpose<<<ggpm_ceil_div(rows, T), T, 0, s>>>(rowptr, col, rows, ncols, rowptrT, cursor, colT);
+    sort_lists<<<ggpm_ceil_div(ncols, T), T, 0, s>>>(rowptrT, colT, ncols);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_extract_column(const int64_t* mat, int rows, int width, int column, int32_t* out,
+                                   ggpm_stream_t stream) {
+    if (!mat || !out || rows <= 0 || column < 0 || column >= width) return GGPM_ERR_ARG;
+    extract_column_k<<<ggpm_ceil_div(rows, 256), 256, 0, (hipStream_t)stream>>>(mat, rows, width, column, out);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

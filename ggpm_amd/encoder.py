@@ -1,0 +1,177 @@
+"""MPNEncoder / HierMPNEncoder -- drop-in for reference ggpm/encoder.py:8-157.
+
+Same constructor signatures, parameter names and shapes (state_dict compatible), same
+``forward(tree_tensors, graph_tensors) -> (hroot, hnode, hinter, hatom)`` on the ``MolGraph.tensorize()``
+input layout after ``make_cuda``.  Underneath, every level runs as hand-written HIP kernels on gfx950.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import functional as F_
+from .nnutils import to_cuda
+from .rnn import GRU, LSTM
+
+NUM_BOND_TYPES = 4   # len(MolGraph.BOND_LIST), reference ggpm/mol_graph.py:14-15
+MAX_POS = 20         # MolGraph.MAX_POS,        reference ggpm/mol_graph.py:16
+
+
+class LevelGraph:
+    """Device-side CSR view of one level's (fmess, agraph, bgraph[, cgraph]) tensors."""
+
+    def __init__(self, fmess: torch.Tensor, agraph: torch.Tensor, bgraph: torch.Tensor,
+                 cgraph: Optional[torch.Tensor] = None, n_lower: int = 0):
+        self.E1, self.N1 = fmess.shape[0], agraph.shape[0]
+        self.pred = F_.csr_from_padded(bgraph, ncols=self.E1)          # message -> predecessor messages
+        self.agr = F_.csr_from_padded(agraph, ncols=self.E1)           # node -> incoming messages
+        self.src = F_.extract_column(fmess, 0)                         # message -> source node
+        self.src_csr = F_.csr_from_index(self.src, ncols=self.N1)
+        self.attr0 = F_.extract_column(fmess, 2)                       # tree levels: position label
+        self.cgr = F_.csr_from_padded(cgraph, ncols=n_lower) if cgraph is not None else None
+
+
+class PreparedBatch:
+    """CSR structures of one tensorized batch; build once, reuse across forward calls of the same batch."""
+
+    def __init__(self, tree_tensors, graph_tensors):
+        tfnode, tfmess, tagraph, tbgraph, tcgraph, tscope = tree_tensors
+        gfnode, gfmess, gagraph, gbgraph, gscope = graph_tensors
+        self.graph = LevelGraph(gfmess, gagraph, gbgraph)
+        self.tree = LevelGraph(tfmess, tagraph, tbgraph, tcgraph, n_lower=gfnode.shape[0])
+        self.motif_id = F_.extract_column(tfnode, 0)
+        self.attach_id = F_.extract_column(tfnode, 1)
+        self.roots = torch.tensor([st for st, _ in tscope], dtype=torch.int32, device=tfnode.device)
+
+
+class MPNEncoder(nn.Module):
+    """reference ggpm/encoder.py:8-38"""
+
+    def __init__(self, rnn_type, input_size, node_fdim, hidden_size, depth, dropout):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.node_fdim = node_fdim
+        self.depth = depth
+        self.W_o = nn.Sequential(nn.Linear(node_fdim + hidden_size, hidden_size), nn.ReLU(), nn.Dropout(dropout))
+        if rnn_type == 'GRU':
+            self.rnn = GRU(input_size, hidden_size, depth)
+        elif rnn_type == 'LSTM':
+            self.rnn = LSTM(input_size, hidden_size, depth)
+        else:
+            raise ValueError('unsupported rnn cell type ' + rnn_type)
+
+    def forward_padded(self, fnode, fmess, agr: F_.CSR, pred: F_.CSR):
+        """-> (node_hiddens [N1,Hp], h [E1,Hp], nei [N1,Hp]) with zero pad columns."""
+        H = self.hidden_size
+        h = self.rnn.forward_padded(fmess, pred)
+        h = self.rnn.get_hidden_state(h)
+        nei = F_.segment_sum(h, agr, H)
+        node = F_.linear([fnode, nei], [self.node_fdim, H], self.W_o[0].weight, self.W_o[0].bias,
+                         act=F_.ACT_RELU, zero_row0=True)
+        node = self.W_o[2](node)        # Dropout (identity when p = 0 / eval)
+        return node, h, nei
+
+    def forward(self, fnode, fmess, agraph, bgraph):
+        agr = agraph if isinstance(agraph, F_.CSR) else F_.csr_from_padded(agraph, ncols=fmess.shape[0])
+        pred = bgraph if isinstance(bgraph, F_.CSR) else F_.csr_from_padded(bgraph, ncols=fmess.shape[0])
+        node, h, _ = self.forward_padded(fnode, fmess, agr, pred)
+        H = self.hidden_size
+        return node[:, :H], h[:, :H]
+
+
+class HierMPNEncoder(nn.Module):
+    """reference ggpm/encoder.py:41-157"""
+
+    def __init__(self, vocab, avocab, rnn_type, embed_size, hidden_size, depthT, depthG, dropout):
+        super().__init__()
+        self.vocab = vocab
+        self.hidden_size = hidden_size
+        self.embed_size = embed_size
+        self.dropout = dropout
+        self.atom_size = atom_size = avocab.size()
+        self.bond_size = bond_size = NUM_BOND_TYPES + MAX_POS
+
+        self.E_c = nn.Sequential(nn.Embedding(vocab.size()[0], embed_size), nn.Dropout(dropout))
+        self.E_i = nn.Sequential(nn.Embedding(vocab.size()[1], embed_size), nn.Dropout(dropout))
+        self.W_c = nn.Sequential(nn.Linear(embed_size + hidden_size, hidden_size), nn.ReLU(), nn.Dropout(dropout))
+        self.W_i = nn.Sequential(nn.Linear(embed_size * 2, hidden_size), nn.ReLU(), nn.Dropout(dropout))
+
+        # constant one-hot tables: plain attributes (not in state_dict), kept for the decoder's tie_embedding
+        self.E_a = to_cuda(torch.eye(atom_size))
+        self.E_b = to_cuda(torch.eye(NUM_BOND_TYPES))
+        self.E_apos = to_cuda(torch.eye(MAX_POS))
+        self.E_pos = to_cuda(torch.eye(MAX_POS))
+
+        self.W_root = nn.Sequential(nn.Linear(hidden_size * 2, hidden_size), nn.Tanh())
+        self.tree_encoder = MPNEncoder(rnn_type, hidden_size + MAX_POS, hidden_size, hidden_size, depthT, dropout)
+        self.inter_encoder = MPNEncoder(rnn_type, hidden_size + MAX_POS, hidden_size, hidden_size, depthT, dropout)
+        self.graph_encoder = MPNEncoder(rnn_type, atom_size + bond_size, atom_size, hidden_size, depthG, dropout)
+
+    def tie_embedding(self, other):
+        self.E_c, self.E_i = other.E_c, other.E_i
+        self.E_a, self.E_b = other.E_a, other.E_b
+
+    # ------------------------------------------------------------------ embeddings (padded tensors)
+    def _tree_mess(self, hnode, lvl: LevelGraph):
+        H = self.hidden_size
+        ld = (H + MAX_POS + 3) // 4 * 4
+        return F_.tree_message_input(hnode, lvl.src, lvl.src_csr, lvl.attr0, H, MAX_POS, ld)
+
+    def embed_graph_padded(self, graph_tensors):
+        fnode, fmess = graph_tensors[0], graph_tensors[1]
+        return F_.embed_graph(fnode, fmess, self.atom_size, NUM_BOND_TYPES, MAX_POS)
+
+    def embed_inter_padded(self, prep: PreparedBatch, hatom):
+        H, He = self.hidden_size, self.embed_size
+        emb = self.E_i[0].weight
+        ids = prep.attach_id
+        finput = F_.gather_rows(emb, ids, F_.csr_from_index(ids, ncols=emb.shape[0]), He, F_.padded_hidden(He))
+        finput = self.E_i[1](finput)
+        pooled = F_.segment_sum(hatom, prep.tree.cgr, H)
+        hnode = F_.linear([finput, pooled], [He, H], self.W_i[0].weight, self.W_i[0].bias, act=F_.ACT_RELU)
+        hnode = self.W_i[2](hnode)
+        return hnode, self._tree_mess(hnode, prep.tree)
+
+    def embed_tree_padded(self, prep: PreparedBatch, hinter):
+        H, He = self.hidden_size, self.embed_size
+        emb = self.E_c[0].weight
+        ids = prep.motif_id
+        finput = F_.gather_rows(emb, ids, F_.csr_from_index(ids, ncols=emb.shape[0]), He, F_.padded_hidden(He))
+        finput = self.E_c[1](finput)
+        hnode = F_.linear([finput, hinter], [He, H], self.W_c[0].weight, self.W_c[0].bias, act=F_.ACT_RELU)
+        hnode = self.W_c[2](hnode)
+        return hnode, self._tree_mess(hnode, prep.tree)
+
+    def embed_root_padded(self, prep: PreparedBatch, hnode_in, nei):
+        """tanh(W_root [hnode_in[root], sum hmess[agraph[root]]]) -- reference ggpm/encoder.py:128-138."""
+        H = self.hidden_size
+        roots = prep.roots
+        rcsr = F_.csr_from_index(roots, ncols=hnode_in.shape[0])
+        f = F_.gather_rows(hnode_in, roots, rcsr, H, F_.padded_hidden(H))
+        n = F_.gather_rows(nei, roots, rcsr, H, F_.padded_hidden(H))
+        return F_.linear([f, n], [H, H], self.W_root[0].weight, self.W_root[0].bias, act=F_.ACT_TANH)
+
+    # ------------------------------------------------------------------ forward
+    def forward_padded(self, tree_tensors, graph_tensors, prep: Optional[PreparedBatch] = None):
+        if prep is None:
+            prep = PreparedBatch(tree_tensors, graph_tensors)
+        hnode_a, hmess_a = self.embed_graph_padded(graph_tensors)
+        hatom, _, _ = self.graph_encoder.forward_padded(hnode_a, hmess_a, prep.graph.agr, prep.graph.pred)
+
+        hnode_i, hmess_i = self.embed_inter_padded(prep, hatom)
+        hinter, _, _ = self.inter_encoder.forward_padded(hnode_i, hmess_i, prep.tree.agr, prep.tree.pred)
+
+        hnode_t, hmess_t = self.embed_tree_padded(prep, hinter)
+        hnode, _, nei = self.tree_encoder.forward_padded(hnode_t, hmess_t, prep.tree.agr, prep.tree.pred)
+
+        hroot = self.embed_root_padded(prep, hnode_t, nei)
+        return hroot, hnode, hinter, hatom
+
+    def forward(self, tree_tensors, graph_tensors, prep: Optional[PreparedBatch] = None):
+        H = self.hidden_size
+        outs = self.forward_padded(tree_tensors, graph_tensors, prep)
+        return tuple(o[:, :H] for o in outs)

@@ -1,0 +1,421 @@
+"""torch.autograd wrappers over the C ABI (include/ggpm_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the stream and the autograd tape;
+every number on the hot path is produced by a hand-written HIP kernel from libggpm_hip.so.  There is no CPU
+or eager fallback: on a tensor that is not on a ROCm device these functions raise.
+
+Conventions: feature matrices are 2-D fp32 tensors whose row stride may exceed the logical width; pad
+columns are zero.  Index tensors are int32 (CSR) unless stated.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ggpm_amd: tensors must live on the MI355X (got a %s tensor); there is no CPU path"
+                               % t.device.type)
+
+
+def padded_hidden(H: int) -> int:
+    return (H + 15) // 16 * 16
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------- graph layout
+class CSR:
+    """Device CSR (int32 rowptr[rows+1], col[cap]) plus its lazily built transpose."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, rows: int, ncols: int):
+        self.rowptr, self.col, self.rows, self.ncols = rowptr, col, rows, ncols
+        self._T: Optional["CSR"] = None
+
+    @property
+    def T(self) -> "CSR":
+        if self._T is None:
+            lib = _lib.load()
+            dev = self.col.device
+            rowptrT = torch.empty(self.ncols + 1, dtype=torch.int32, device=dev)
+            colT = torch.empty(max(self.col.numel(), 1), dtype=torch.int32, device=dev)
+            cursor = torch.empty(self.ncols, dtype=torch.int32, device=dev)
+            _lib.check(lib.ggpm_csr_transpose(_p(self.rowptr), _p(self.col), self.rows, self.ncols, _p(rowptrT),
+                                              _p(colT), _p(cursor), _stream()), "csr_transpose")
+            self._T = CSR(rowptrT, colT, self.ncols, self.rows)
+            self._T._T = self
+        return self._T
+
+
+def csr_from_padded(padded: torch.Tensor, ncols: int) -> CSR:
+    """agraph/bgraph/cgraph (int64 [rows, width], 0 = no entry) -> CSR over the real entries."""
+    _need_gpu(padded)
+    assert padded.dtype == torch.int64 and padded.dim() == 2
+    padded = padded.contiguous()
+    rows, width = padded.shape
+    rowptr = torch.empty(rows + 1, dtype=torch.int32, device=padded.device)
+    col = torch.empty(max(rows * width, 1), dtype=torch.int32, device=padded.device)
+    _lib.check(_lib.load().ggpm_padded_to_csr(_p(padded), rows, width, _p(rowptr), _p(col), _stream()),
+               "padded_to_csr")
+    return CSR(rowptr, col, rows, ncols)
+
+
+def csr_from_index(idx: torch.Tensor, ncols: int) -> CSR:
+    """One entry per row (col = idx[row]); its transpose lists, per id, the rows that use it."""
+    rows = idx.numel()
+    rowptr = torch.arange(rows + 1, dtype=torch.int32, device=idx.device)
+    return CSR(rowptr, idx, rows, ncols)
+
+
+def extract_column(mat: torch.Tensor, column: int) -> torch.Tensor:
+    _need_gpu(mat)
+    assert mat.dtype == torch.int64
+    if mat.dim() == 1:
+        mat = mat.unsqueeze(1)
+    mat = mat.contiguous()
+    out = torch.empty(mat.shape[0], dtype=torch.int32, device=mat.device)
+    _lib.check(_lib.load().ggpm_extract_column(_p(mat), mat.shape[0], mat.shape[1], column, _p(out), _stream()),
+               "extract_column")
+    return out
+
+
+# ----------------------------------------------------------------------------- raw launches
+def gemm(ta: int, tb: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
+         C: torch.Tensor, ldc: int, n_pad: int, bias: Optional[torch.Tensor] = None, accumulate: bool = False,
+         act: int = ACT_NONE, zero_row0: bool = False, splitk: bool = False) -> None:
+    lib = _lib.load()
+    ws, wsb = None, 0
+    if splitk:
+        wsb = int(lib.ggpm_gemm_workspace_bytes(M, N, K))
+        if wsb:
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=C.device)
+    _lib.check(lib.ggpm_gemm(ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, n_pad, _p(bias),
+                             int(accumulate), act, int(zero_row0), _p(ws), wsb, _stream()), "gemm")
+
+
+def colsum(A: torch.Tensor, M: int, N: int) -> torch.Tensor:
+    out = torch.empty(N, dtype=torch.float32, device=A.device)
+    ws = torch.empty(64 * N, dtype=torch.float32, device=A.device)
+    _lib.check(_lib.load().ggpm_colsum(_p(A), _ld(A), M, N, _p(out), _p(ws), _stream()), "colsum")
+    return out
+
+
+def _segment_sum_raw(src: torch.Tensor, csr: CSR, width: int, out: torch.Tensor) -> None:
+    _lib.check(_lib.load().ggpm_segment_sum(_p(src), _ld(src), _p(csr.rowptr), _p(csr.col), csr.rows, width,
+                                            _p(out), _ld(out), 0, _stream()), "segment_sum")
+
+
+# ----------------------------------------------------------------------------- autograd functions
+class _Linear(torch.autograd.Function):
+    """y[:, :N] = act( sum_i x_i[:, :K_i] W[:, off_i:off_i+K_i]^T + b ), pad columns of y zero."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, act, zero_row0, ld_out, Ks, *xs):
+        _need_gpu(weight, *xs)
+        N = weight.shape[0]
+        M = xs[0].shape[0]
+        assert sum(Ks) == weight.shape[1] and weight.stride(1) == 1
+        y = torch.empty(M, ld_out, dtype=torch.float32, device=weight.device)
+        off = 0
+        last = len(xs) - 1
+        for i, (x, K) in enumerate(zip(xs, Ks)):
+            wv = weight[:, off:]
+            gemm(0, 1, M, N, K, x, _ld(x), wv, weight.stride(0), y, ld_out, ld_out,
+                 bias=bias if i == 0 else None, accumulate=i > 0, act=act if i == last else ACT_NONE,
+                 zero_row0=zero_row0 and i == last)
+            off += K
+        ctx.save_for_backward(weight, y, *xs)
+        ctx.meta = (act, zero_row0, Ks, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, y, *xs = ctx.saved_tensors
+        act, zero_row0, Ks, has_bias = ctx.meta
+        N = weight.shape[0]
+        M = y.shape[0]
+        dy = dy.contiguous() if dy.stride(1) != 1 else dy
+        lib = _lib.load()
+        if act != ACT_NONE or zero_row0:
+            dpre = torch.empty_like(y)
+            assert _ld(dy) == _ld(y)
+            _lib.check(lib.ggpm_act_backward(_p(dy), _p(y), M, N, _ld(y), act, int(zero_row0), _p(dpre), _stream()),
+                       "act_backward")
+        else:
+            dpre = dy
+        dW = torch.empty_like(weight) if ctx.needs_input_grad[0] else None
+        db = colsum(dpre, M, N) if (has_bias and ctx.needs_input_grad[1]) else None
+        dxs: List[Optional[torch.Tensor]] = []
+        off = 0
+        for i, (x, K) in enumerate(zip(xs, Ks)):
+            if dW is not None:
+                gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW[:, off:], dW.stride(0), K, splitk=True)
+            if ctx.needs_input_grad[6 + i]:
+                dx = torch.empty_like(x)
+                gemm(0, 0, M, K, N, dpre, _ld(dpre), weight[:, off:], weight.stride(0), dx, _ld(dx), x.shape[1])
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+            off += K
+        return (dW, db, None, None, None, None, *dxs)
+
+
+def linear(xs: Sequence[torch.Tensor], Ks: Sequence[int], weight: torch.Tensor, bias: Optional[torch.Tensor],
+           act: int = ACT_NONE, zero_row0: bool = False, ld_out: Optional[int] = None) -> torch.Tensor:
+    N = weight.shape[0]
+    if ld_out is None:
+        ld_out = padded_hidden(N)
+    return _Linear.apply(weight, bias, act, zero_row0, ld_out, tuple(Ks), *xs)
+
+
+class _SegmentSum(torch.autograd.Function):
+    """out[r] = sum_{j in csr row r} src[col[j]]  (index_select_ND(...).sum(1) over real entries)."""
+
+    @staticmethod
+    def forward(ctx, src, csr, width):
+        _need_gpu(src)
+        out = torch.empty(csr.rows, _ld(src), dtype=torch.float32, device=src.device)
+        if _ld(src) > width:
+            out[:, width:].zero_()
+        _segment_sum_raw(src, csr, width, out)
+        ctx.csr, ctx.width, ctx.src_rows = csr, width, src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous() if dout.stride(1) != 1 else dout
+        csrT = ctx.csr.T
+        assert csrT.rows == ctx.src_rows
+        dsrc = torch.empty(ctx.src_rows, _ld(dout), dtype=torch.float32, device=dout.device)
+        if _ld(dout) > ctx.width:
+            dsrc[:, ctx.width:].zero_()
+        _segment_sum_raw(dout, csrT, ctx.width, dsrc)
+        return dsrc, None, None
+
+
+def segment_sum(src: torch.Tensor, csr: CSR, width: int) -> torch.Tensor:
+    return _SegmentSum.apply(src, csr, width)
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[r, :width] = table[idx[r], :width] (nn.Embedding / index_select); backward through idx^T."""
+
+    @staticmethod
+    def forward(ctx, table, idx, idx_csr, width, ld_out):
+        _need_gpu(table, idx)
+        rows = idx.numel()
+        out = torch.empty(rows, ld_out, dtype=torch.float32, device=table.device)
+        if ld_out > width:
+            out[:, width:].zero_()
+        _lib.check(_lib.load().ggpm_gather_rows(_p(table), _ld(table), _p(idx), rows, width, _p(out), ld_out, 0,
+                                                _stream()), "gather_rows")
+        ctx.idx_csr, ctx.width, ctx.tshape, ctx.tld = idx_csr, width, table.shape, _ld(table)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous() if dout.stride(1) != 1 else dout
+        csrT = ctx.idx_csr.T
+        dtable = torch.empty(ctx.tshape, dtype=torch.float32, device=dout.device)
+        if ctx.tshape[1] > ctx.width:
+            dtable[:, ctx.width:].zero_()
+        _segment_sum_raw(dout, csrT, ctx.width, dtable)
+        return dtable, None, None, None, None
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, idx_csr: CSR, width: int, ld_out: int) -> torch.Tensor:
+    return _GatherRows.apply(table, idx, idx_csr, width, ld_out)
+
+
+class _TreeMessInput(torch.autograd.Function):
+    """hmess = [hnode[src] | onehot(pos)]  (embed_inter/embed_tree, ggpm/encoder.py:103-106,114-116)."""
+
+    @staticmethod
+    def forward(ctx, hnode, src, src_csr, pos, H, n_pos, ld_out):
+        _need_gpu(hnode, src, pos)
+        lib = _lib.load()
+        rows = src.numel()
+        out = torch.empty(rows, ld_out, dtype=torch.float32, device=hnode.device)
+        if ld_out > H + n_pos:
+            out[:, H + n_pos:].zero_()
+        _lib.check(lib.ggpm_gather_rows(_p(hnode), _ld(hnode), _p(src), rows, H, _p(out), ld_out, 0, _stream()),
+                   "gather_rows")
+        _lib.check(lib.ggpm_onehot(_p(pos), rows, n_pos, _p(out), ld_out, H, _stream()), "onehot")
+        ctx.src_csr, ctx.H, ctx.nshape = src_csr, H, hnode.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous() if dout.stride(1) != 1 else dout
+        csrT = ctx.src_csr.T
+        dh = torch.empty(ctx.nshape, dtype=torch.float32, device=dout.device)
+        if ctx.nshape[1] > ctx.H:
+            dh[:, ctx.H:].zero_()
+        _segment_sum_raw(dout, csrT, ctx.H, dh)
+        return dh, None, None, None, None, None, None
+
+
+def tree_message_input(hnode, src, src_csr, pos, H, n_pos, ld_out):
+    return _TreeMessInput.apply(hnode, src, src_csr, pos, H, n_pos, ld_out)
+
+
+def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_types: int, max_pos: int
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One-hot atom-level inputs (constants: no gradient), ggpm/encoder.py:119-126."""
+    _need_gpu(fnode, fmess)
+    N1, E1 = fnode.shape[0], fmess.shape[0]
+    ld_n = (atom_size + 3) // 4 * 4
+    ld_m = (atom_size + bond_types + max_pos + 3) // 4 * 4
+    hnode = torch.empty(N1, ld_n, dtype=torch.float32, device=fnode.device)
+    hmess = torch.empty(E1, ld_m, dtype=torch.float32, device=fnode.device)
+    _lib.check(_lib.load().ggpm_embed_graph(_p(fnode.contiguous()), N1, _p(fmess.contiguous()), E1, atom_size,
+                                            bond_types, max_pos, _p(hnode), ld_n, _p(hmess), ld_m, _stream()),
+               "embed_graph")
+    return hnode, hmess
+
+
+class _GruMessages(torch.autograd.Function):
+    """GRU.forward over CSR predecessors (ggpm/rnn.py:41-50): returns h_D [E1, Hp]."""
+
+    @staticmethod
+    def forward(ctx, Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred, depth, H):
+        _need_gpu(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h)
+        lib = _lib.load()
+        E1, Hp = Xz.shape[0], padded_hidden(H)
+        assert _ld(Xz) == Hp and _ld(Xr) == Hp and _ld(Xh) == Hp
+        dev = Xz.device
+        save = any(ctx.needs_input_grad)
+        f32 = dict(dtype=torch.float32, device=dev)
+        wpack = torch.empty(int(lib.ggpm_gru_pack_floats(H)), **f32)
+        if save:
+            Hs = torch.empty(depth + 1, E1, Hp, **f32)
+            Qs = torch.empty(depth, E1, Hp, **f32)
+            St = torch.empty(4, depth, E1, Hp, **f32)
+            Ss, Gs, Zs, Ms = St[0], St[1], St[2], St[3]
+        else:
+            Hs = torch.empty(2, E1, Hp, **f32)
+            Qs = torch.empty(2, E1, Hp, **f32)
+            Ss = Gs = Zs = Ms = None
+        _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(Xz), _p(Xr), _p(Xh), _p(Wz_h), Wz_h.stride(0), _p(Ur),
+                                        Ur.stride(0), _p(bu), _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col),
+                                        _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(wpack), int(save),
+                                        _stream()), "gru_forward")
+        out = Hs[depth] if save else Hs[depth & 1]
+        if save:
+            ctx.save_for_backward(Xr, Wz_h, Ur, Wh_h)
+            ctx.stash = (Hs, Qs, Ss, Gs, Zs, Ms)
+            ctx.pred, ctx.depth, ctx.H = pred, depth, H
+        return out
+
+    @staticmethod
+    def backward(ctx, dHD):
+        Xr, Wz_h, Ur, Wh_h = ctx.saved_tensors
+        Hs, Qs, Ss, Gs, Zs, Ms = ctx.stash
+        lib = _lib.load()
+        H, depth, pred = ctx.H, ctx.depth, ctx.pred
+        E1, Hp = Xr.shape[0], padded_hidden(H)
+        succ = pred.T
+        dHD = dHD.contiguous()
+        assert dHD.shape == (E1, Hp)
+        f32 = dict(dtype=torch.float32, device=Xr.device)
+        dX = torch.empty(3, E1, Hp, **f32)
+        dWz = torch.empty(H, H, **f32)
+        dUr = torch.empty(H, H, **f32)
+        dWh = torch.empty(H, H, **f32)
+        dbu = torch.empty(H, **f32)
+        wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), Wz_h.stride(0), _p(Ur), Ur.stride(0),
+                                         _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
+                                         _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(dHD),
+                                         _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz), H, _p(dUr), H, _p(dbu), _p(dWh), H,
+                                         _p(work), work.numel() * 4, _stream()), "gru_backward")
+        ctx.stash = None
+        return dX[0], dX[1], dX[2], dWz, dUr, dbu, dWh, None, None, None
+
+
+def gru_messages(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred: CSR, depth: int, H: int) -> torch.Tensor:
+    return _GruMessages.apply(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred, depth, H)
+
+
+class _LstmMessages(torch.autograd.Function):
+    """LSTM.forward over CSR predecessors (ggpm/rnn.py:96-108): returns (h_D, c_D), each [E1, Hp]."""
+
+    @staticmethod
+    def forward(ctx, Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred, depth, H):
+        _need_gpu(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h)
+        lib = _lib.load()
+        E1, Hp = Xi.shape[0], padded_hidden(H)
+        assert _ld(Xi) == Hp and _ld(Xo) == Hp and _ld(Xu) == Hp and _ld(Xf) == Hp
+        save = any(ctx.needs_input_grad)
+        f32 = dict(dtype=torch.float32, device=Xi.device)
+        wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H)), **f32)
+        if save:
+            Hs = torch.empty(depth + 1, E1, Hp, **f32)
+            Cs = torch.empty(depth + 1, E1, Hp, **f32)
+            Qs = torch.empty(depth, E1, Hp, **f32)
+            St = torch.empty(4, depth, E1, Hp, **f32)
+            Ss, Is, Os, Us = St[0], St[1], St[2], St[3]
+        else:
+            Hs = torch.empty(2, E1, Hp, **f32)
+            Cs = torch.empty(2, E1, Hp, **f32)
+            Qs = torch.empty(2, E1, Hp, **f32)
+            Ss = Is = Os = Us = None
+        _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(Xi), _p(Xo), _p(Xu), _p(Xf), _p(Wi_h), Wi_h.stride(0),
+                                         _p(Wo_h), Wo_h.stride(0), _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0),
+                                         _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os),
+                                         _p(Us), _p(wpack), int(save), _stream()), "lstm_forward")
+        k = depth if save else depth & 1
+        if save:
+            ctx.save_for_backward(Xf, Wi_h, Wo_h, Wu_h, Wf_h)
+            ctx.stash = (Hs, Cs, Qs, Ss, Is, Os, Us)
+            ctx.pred, ctx.depth, ctx.H = pred, depth, H
+        c_out = Cs[k]
+        ctx.mark_non_differentiable(c_out)
+        return Hs[k], c_out
+
+    @staticmethod
+    def backward(ctx, dHD, _dC):
+        Xf, Wi_h, Wo_h, Wu_h, Wf_h = ctx.saved_tensors
+        Hs, Cs, Qs, Ss, Is, Os, Us = ctx.stash
+        lib = _lib.load()
+        H, depth, pred = ctx.H, ctx.depth, ctx.pred
+        E1, Hp = Xf.shape[0], padded_hidden(H)
+        succ = pred.T
+        dHD = dHD.contiguous()
+        f32 = dict(dtype=torch.float32, device=Xf.device)
+        dX = torch.empty(4, E1, Hp, **f32)
+        dW = torch.empty(4, H, H, **f32)
+        wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wi_h), Wi_h.stride(0), _p(Wo_h), Wo_h.stride(0),
+                                          _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0), _p(pred.rowptr),
+                                          _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
+                                          _p(Is), _p(Os), _p(Us), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dX[3]),
+                                          _p(dW[0]), H, _p(dW[1]), H, _p(dW[2]), H, _p(dW[3]), H, _p(work),
+                                          work.numel() * 4, _stream()), "lstm_backward")
+        ctx.stash = None
+        return dX[0], dX[1], dX[2], dX[3], dW[0], dW[1], dW[2], dW[3], None, None, None
+
+
+def lstm_messages(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred: CSR, depth: int, H: int):
+    return _LstmMessages.apply(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred, depth, H)

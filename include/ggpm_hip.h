@@ -1,0 +1,175 @@
+/*
+ * ggpm_hip.h -- C ABI of the MI355X (gfx950) hierarchical message-passing library.
+ *
+ * The reference (quocdat32461997/ggpm) is pure Python/PyTorch and has NO native
+ * interface for this path; the seam is Python class substitution.
+ * Each entry point below therefore cites the reference *Python* lines whose
+ * arithmetic it replaces.  All paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (the host side uses the
+ *     PyTorch caching allocator); the library allocates nothing and keeps no state;
+ *   - fp32 row-major matrices with an explicit leading dimension (in floats);
+ *     index arrays are int32 (CSR) or the int64 padded tensors MolGraph.tensorize
+ *     delivers (ggpm/mol_graph.py:199-281, ggpm/nnutils.py:210-214);
+ *   - "E1"/"N1" row counts INCLUDE the pad row 0 of the reference layout;
+ *   - feature matrices use a padded row stride Hp = ggpm_padded_hidden(H)
+ *     (multiple of 16); pad columns are zero on input and kept zero on output;
+ *   - work is enqueued on `stream` (a hipStream_t) and never synchronised;
+ *   - return value 0 = ok, otherwise a GGPM_ERR_* code (ggpm_error_string()).
+ *     Nothing aborts; the Python wrappers raise RuntimeError.
+ *   - re-entrant: no globals, safe from autograd's worker threads.
+ */
+#ifndef GGPM_HIP_H
+#define GGPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ggpm_stream_t; /* hipStream_t */
+
+enum {
+    GGPM_OK = 0,
+    GGPM_ERR_ARG = 1,         /* bad size / null pointer / misaligned leading dimension */
+    GGPM_ERR_LAUNCH = 2,      /* hipGetLastError() != hipSuccess after a launch */
+    GGPM_ERR_UNSUPPORTED = 3, /* shape outside what the kernels were built for */
+    GGPM_ERR_WORKSPACE = 4    /* workspace too small */
+};
+
+enum { GGPM_ACT_NONE = 0, GGPM_ACT_RELU = 1, GGPM_ACT_TANH = 2, GGPM_ACT_SIGMOID = 3 };
+
+int ggpm_version(void);
+const char* ggpm_error_string(int code);
+/* Padded feature stride used by the message kernels: H rounded up to a multiple of 16. */
+int ggpm_padded_hidden(int H);
+
+/* ------------------------------------------------------------------ graph layout
+ * A0 (ggpm/mol_graph.py:238-281, create_pad_tensor ggpm/nnutils.py:105-110): agraph/bgraph/cgraph
+ * arrive as zero-padded int64 [rows, width]; entry 0 means "no neighbour" (row 0 is the pad row, so
+ * index 0 always gathers zeros in the reference).  These build the equivalent CSR over the real
+ * entries, which is what makes the padded gather of index_select_ND (ggpm/nnutils.py:65-70) unnecessary.
+ */
+/* rowptr[rows+1], col[>= rows*width]; entries keep their in-row order. */
+int ggpm_padded_to_csr(const int64_t* padded, int rows, int width, int32_t* rowptr, int32_t* col,
+                       ggpm_stream_t stream);
+/* Transpose of a CSR whose column ids lie in [0, ncols): rowptrT[ncols+1], colT[>= nnz capacity]
+ * hold, for every column id, the ascending list of rows that reference it (deterministic order);
+ * `cursor` is int32 scratch of ncols entries. Used for the atomics-free backward gathers. */
+int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int rows, int ncols,
+                       int32_t* rowptrT, int32_t* colT, int32_t* cursor, ggpm_stream_t stream);
+/* out[r] = (int32) mat[r*width + column]   (e.g. fmess[:,0], fnode[:,1]) */
+int ggpm_extract_column(const int64_t* mat, int rows, int width, int column, int32_t* out,
+                        ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ dense algebra (fp32 MFMA)
+ * C[m,n] = act( sum_k A'(m,k) B'(k,n) + bias[n] + (accumulate ? C[m,n] : 0) ),
+ *   A'(m,k) = trans_a ? A[k*lda+m] : A[m*lda+k],   B'(k,n) = trans_b ? B[n*ldb+k] : B[k*ldb+n].
+ * Columns N..n_pad-1 of C are zero-filled (n_pad <= ldc; pass n_pad = N for none); zero_row0 forces
+ * row 0 of C to zero (the reference's "first node/message is padding" masks, ggpm/encoder.py:36-38).
+ * Replaces nn.Linear on this path (ggpm/rnn.py:13-16,69-72, ggpm/encoder.py:15-19,62-82) and autograd's
+ * mm/addmm for its gradients.  `splitk_ws` (may be NULL) enables a deterministic split-K reduction for
+ * tall contractions (weight gradients over depth*E rows); it needs ggpm_gemm_workspace_bytes() bytes.
+ */
+size_t ggpm_gemm_workspace_bytes(int M, int N, int K);
+int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+              int ldb, float* C, int ldc, int n_pad, const float* bias, int accumulate, int act,
+              int zero_row0, float* splitk_ws, size_t splitk_ws_bytes, ggpm_stream_t stream);
+/* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 64*N floats. */
+int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream);
+/* dpre = dy * act'(y) given the activation OUTPUT y; optional row-0 zeroing. In-place allowed. */
+int ggpm_act_backward(const float* dy, const float* y, int rows, int cols, int ld, int act,
+                      int zero_row0, float* dpre, ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ gathers / segmented sums
+ * out[r, 0:width] = sum_{j in rowptr[r]..rowptr[r+1]} src[col[j], 0:width]
+ * = index_select_ND(h, 0, agraph).sum(1) of ggpm/encoder.py:31-32,99,135-136 (and, through the
+ * transposed CSR, every scatter-add autograd would run for their backward).  accumulate!=0 adds to out. */
+int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const int32_t* col, int rows,
+                     int width, float* out, int ld_out, int accumulate, ggpm_stream_t stream);
+/* out[r, col_off : col_off+width] = table[idx[r], 0:width]; rows with idx<0 give zeros.
+ * = nn.Embedding / index_select of ggpm/encoder.py:98,103,111,114 */
+int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
+                     float* out, int ld_out, int col_off, ggpm_stream_t stream);
+/* out[r, col_off + idx[r]] = 1, the other `classes` columns of that block 0: the one-hot tables
+ * E_a/E_b/E_apos/E_pos of ggpm/encoder.py:74-77,121-125,104-105. */
+int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off,
+                ggpm_stream_t stream);
+/* embed_graph (ggpm/encoder.py:119-126) in one launch: hnode[N1, ld_n] = onehot(fnode), hmess[E1, ld_m] =
+ * [onehot(fnode[src]) | onehot(bond) | onehot(pos)] from the int64 A0 tensors. */
+int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1, int atom_size,
+                     int bond_types, int max_pos, float* hnode, int ld_n, float* hmess, int ld_m,
+                     ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ GRU message function
+ * GRU.forward (ggpm/rnn.py:41-50) with GRU.GRU (ggpm/rnn.py:25-39) restated over CSR predecessors with
+ * the depth-invariant input halves hoisted:  Xz = x W_z[:, :I]^T + b_z, Xr = x W_r^T, Xh = x W_h[:, :I]^T + b_h
+ * are computed once by ggpm_gemm; per depth
+ *     s_e = sum_p h_p,  g_e = sum_p sigmoid(Xr_e + q_p) * h_p,   q_p = U_r h_p + b_u,
+ *     z = sigmoid(Xz + Wz_h s), m = tanh(Xh + Wh_h g), h' = (1-z) s + z m, row 0 := 0.
+ * One fused kernel per depth: CSR gather -> LDS tiles -> MFMA gate GEMMs -> gate math -> MFMA q' GEMM.
+ * Stash layout ([t] = depth slot): Hs[depth+1][E1][Hp] (Hs[0]=0, Hs[depth] = result), Qs/Ss/Gs/Zs/Ms
+ * [depth][E1][Hp].  With save_for_backward = 0 only Hs[2][E1][Hp] and Qs[2][E1][Hp] are needed and the
+ * result is Hs[depth & 1].   wpack: ggpm_gru_pack_floats(H) floats of scratch.
+ */
+size_t ggpm_gru_pack_floats(int H);
+int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
+                     const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
+                     const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
+                     float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* wpack,
+                     int save_for_backward, ggpm_stream_t stream);
+/* Backward of the above (replaces autograd's replay of ggpm/rnn.py:41-50): given dHD = dL/dh_D it
+ * overwrites dXz/dXr/dXh [E1][Hp] and the weight gradients (written as [H,H] blocks with the given
+ * leading dimension so they can land inside the full W_z/W_h gradient tensors), dbu[H].
+ * succ_* is the CSR transpose of pred_* (ggpm_csr_transpose).  work: ggpm_gru_backward_workspace_bytes(). */
+size_t ggpm_gru_backward_workspace_bytes(int E1, int H, int depth);
+int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+                      const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                      const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* succ_rowptr,
+                      const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss,
+                      const float* Gs, const float* Zs, const float* Ms, const float* dHD, float* dXz,
+                      float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
+                      float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
+                      ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ LSTM message function
+ * LSTM.forward (ggpm/rnn.py:96-108) with LSTM.LSTM (ggpm/rnn.py:85-94), same restatement:
+ *     Xi/Xo/Xu/Xf = x W_*[:, :I]^T + b_*  (hoisted),   qf_p = Wf_h h_p,
+ *     s = sum_p h_p,  fc = sum_p sigmoid(Xf_e + qf_p) * c_p,
+ *     i = sigmoid(Xi + Wi_h s), o = sigmoid(Xo + Wo_h s), u = tanh(Xu + Wu_h s),
+ *     c' = i u + fc,  h' = o tanh(c'),  rows 0 := 0.
+ * Stash: Hs, Cs [depth+1][E1][Hp]; Qs (qf), Ss, Is, Os, Us [depth][E1][Hp].
+ */
+size_t ggpm_lstm_pack_floats(int H);
+int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, const float* Xo, const float* Xu,
+                      const float* Xf, const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
+                      const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
+                      const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
+                      float* Qs, float* Ss, float* Is, float* Os, float* Us, float* wpack,
+                      int save_for_backward, ggpm_stream_t stream);
+size_t ggpm_lstm_backward_workspace_bytes(int E1, int H, int depth);
+int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
+                       const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
+                       int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col,
+                       const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
+                       const float* Cs, const float* Qs, const float* Ss, const float* Is,
+                       const float* Os, const float* Us, const float* dHD, float* dXi, float* dXo,
+                       float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                       float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
+                       size_t work_bytes, ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ instrumentation
+ * When a timing sink is installed, every fused depth-step launch is bracketed by HIP events on its own
+ * stream; ggpm_timing_collect() synchronises those events and returns launches / total milliseconds
+ * for kernel class `which` (0 gru fwd, 1 gru bwd, 2 lstm fwd, 3 lstm bwd). Used by bench.py for
+ * roofline.achieved; off by default (no events, no overhead). */
+int ggpm_timing_enable(int on);
+int ggpm_timing_collect(int which, int* launches, double* total_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGPM_HIP_H */

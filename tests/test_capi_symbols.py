@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/ggpm_hip.h declares."""
+import os
+import re
+
+from ggpm_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ggpm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggpm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(_lib.SIGNATURES.keys())
+
+
+def test_library_builds_and_exports_every_symbol():
+    build.build(verbose=False)
+    lib = _lib.load()
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
+    # host-only entry points can be called without a GPU
+    assert lib.ggpm_version() >= 100
+    assert lib.ggpm_padded_hidden(300) == 304 and lib.ggpm_padded_hidden(16) == 16
+    assert lib.ggpm_error_string(1).decode().startswith("invalid")
+    assert lib.ggpm_gru_pack_floats(300) == 3 * 304 * 304 + 304
+    assert lib.ggpm_gemm_workspace_bytes(300, 300, 100) == 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the wrappers raise instead of silently computing elsewhere."""
+    import pytest
+    import torch
+    from ggpm_amd import functional as F_
+    with pytest.raises(RuntimeError):
+        F_.csr_from_padded(torch.zeros(3, 2, dtype=torch.int64), ncols=3)
+    with pytest.raises(RuntimeError):
+        F_.linear([torch.zeros(2, 4)], [4], torch.zeros(3, 4), None)

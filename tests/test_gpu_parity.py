@@ -1,0 +1,207 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from golden_utils import Golden, case_names, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json: outputs / losses within 1e-4 fp32 relative
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------ primitives
+def test_native_library_is_loaded():
+    from ggpm_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    assert lib.ggpm_version() >= 100
+
+
+@pytest.mark.parametrize("rows,width", [(1, 1), (7, 3), (300, 5), (5000, 13)])
+def test_padded_to_csr_and_transpose(rows, width):
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(rows + width)
+    ncols = rows + 3
+    padded = np.zeros((rows, width), dtype=np.int64)
+    for r in range(1, rows):
+        k = rs.randint(0, width)           # trailing column always zero, like create_pad_tensor
+        padded[r, :k] = rs.randint(1, ncols, size=k)
+    csr = F_.csr_from_padded(torch.from_numpy(padded).to(_dev()), ncols=ncols)
+    rowptr = csr.rowptr.cpu().numpy()
+    col = csr.col.cpu().numpy()
+    exp_rows = [list(padded[r][padded[r] != 0]) for r in range(rows)]
+    assert rowptr[0] == 0 and rowptr[-1] == sum(len(x) for x in exp_rows)
+    for r in range(rows):
+        assert list(col[rowptr[r]:rowptr[r + 1]]) == exp_rows[r]
+    T = csr.T
+    rp, cl = T.rowptr.cpu().numpy(), T.col.cpu().numpy()
+    exp_T = [[] for _ in range(ncols)]
+    for r in range(rows):
+        for c in exp_rows[r]:
+            exp_T[c].append(r)
+    for c in range(ncols):
+        assert list(cl[rp[c]:rp[c + 1]]) == sorted(exp_T[c])
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 33, 70, 62), (0, 1, 513, 300, 320), (0, 0, 257, 62, 300),
+                                         (1, 0, 300, 320, 5000), (1, 0, 16, 16, 40), (0, 1, 1, 1, 1),
+                                         (1, 1, 65, 66, 67), (0, 1, 2751, 300, 62)])
+def test_gemm_against_fp64(ta, tb, M, N, K):
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    lda = (M if ta else K) + 4
+    ldb = (K if tb else N) + 4
+    A = rs.standard_normal((K if ta else M, lda)).astype(np.float32)
+    B = rs.standard_normal((N if tb else K, ldb)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    ldc = (N + 15) // 16 * 16 + 16
+    C = torch.full((M, ldc), 7.0, device=_dev())
+    a, b = torch.from_numpy(A).to(_dev()), torch.from_numpy(B).to(_dev())
+    F_.gemm(ta, tb, M, N, K, a, lda, b, ldb, C, ldc, ldc - 8, bias=torch.from_numpy(bias).to(_dev()), splitk=True)
+    Am = (A[:, :M].T if ta else A[:, :K]).astype(np.float64)
+    Bm = (B[:, :K].T if tb else B[:, :N]).astype(np.float64)
+    ref = Am @ Bm + bias
+    got = C.cpu().numpy()
+    assert rel_err(got[:, :N], ref) < 2e-6
+    assert (got[:, N:ldc - 8] == 0).all() and (got[:, ldc - 8:] == 7.0).all()
+    # accumulate + relu + row-0 mask
+    F_.gemm(ta, tb, M, N, K, a, lda, b, ldb, C, ldc, N, accumulate=True, act=F_.ACT_RELU, zero_row0=True)
+    ref2 = np.maximum(ref + got[:, :N], 0.0)
+    ref2[0] = 0
+    assert rel_err(C.cpu().numpy()[:, :N], ref2) < 2e-6
+
+
+def test_segment_sum_and_gather():
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(0)
+    rows, nsrc, W, ld = 200, 300, 300, 304
+    src = np.zeros((nsrc, ld), dtype=np.float32)
+    src[:, :W] = rs.standard_normal((nsrc, W))
+    padded = np.zeros((rows, 6), dtype=np.int64)
+    for r in range(1, rows):
+        k = rs.randint(0, 6)
+        padded[r, :k] = rs.randint(1, nsrc, size=k)
+    s = torch.from_numpy(src).to(_dev()).requires_grad_(True)
+    csr = F_.csr_from_padded(torch.from_numpy(padded).to(_dev()), ncols=nsrc)
+    out = F_.segment_sum(s, csr, W)
+    ref = src[padded].sum(axis=1)
+    ref[0] = 0
+    assert rel_err(out.detach().cpu().numpy(), ref) < 1e-6
+    g = rs.standard_normal((rows, ld)).astype(np.float32)
+    g[:, W:] = 0
+    out.backward(torch.from_numpy(g).to(_dev()))
+    dref = np.zeros_like(src)
+    for r in range(rows):
+        for c in padded[r]:
+            if c != 0:
+                dref[c] += g[r]
+    assert rel_err(s.grad.cpu().numpy(), dref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ message functions
+def _random_level(rs, E, I, K=4):
+    bgraph = np.zeros((E + 1, K + 1), dtype=np.int64)
+    for e in range(1, E + 1):
+        k = rs.randint(0, K + 1)
+        bgraph[e, :k] = rs.choice(np.arange(1, E + 1), size=k, replace=False) if E >= k else 0
+    x = rs.standard_normal((E + 1, I)).astype(np.float32)
+    return x, bgraph
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+@pytest.mark.parametrize("E,I,H,depth", [(5, 7, 16, 1), (40, 13, 24, 3), (333, 62, 300, 6), (200, 270, 250, 4),
+                                         (17, 20, 600, 2), (1000, 62, 64, 2)])
+def test_message_function_matches_oracle(rnn, E, I, H, depth):
+    """rnn.GRU / rnn.LSTM forward + backward vs the padded-order oracle on random predecessor tables."""
+    from ggpm_amd import rnn as R
+    from ggpm_amd.params import rnn_param_shapes, seeded_state_dict
+    from oracle import ref_encoder as ref
+    rs = np.random.RandomState(E + I + H + depth)
+    x, bgraph = _random_level(rs, E, I)
+    sd = seeded_state_dict(rnn_param_shapes(rnn, I, H), seed=E + H)
+    mod = (R.GRU if rnn == "GRU" else R.LSTM)(I, H, depth).to(_dev())
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    xg = torch.from_numpy(x).to(_dev()).requires_grad_(True)
+    out = mod(xg, torch.from_numpy(bgraph).to(_dev()))
+    h = out if rnn == "GRU" else out[0]
+    w = torch.from_numpy(rs.standard_normal((E + 1, H)).astype(np.float32))
+    (h * w.to(_dev())).sum().backward()
+
+    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items()}
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    href = ref.rnn_forward(p, "", rnn, xr, torch.from_numpy(bgraph), depth)
+    (href * w.double()).sum().backward()
+
+    assert rel_err(h.detach().cpu().numpy(), href.detach().numpy()) < TOL
+    assert (h.detach().cpu().numpy()[0] == 0).all()
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+    for k, v in mod.named_parameters():
+        assert rel_err(v.grad.cpu().numpy(), p[k].grad.numpy()) < TOL, k
+
+
+# ------------------------------------------------------------------------------------------ full encoder vs golden
+class _Vocab:
+    def __init__(self, n):
+        self.n = n
+
+    def size(self):
+        return self.n
+
+
+def _build_encoder(g):
+    from ggpm_amd.property_vae import HierEncoderVAE
+
+    class Args:
+        pass
+    a = Args()
+    a.vocab, a.atom_vocab = _Vocab((g.n_motif, g.n_attach)), _Vocab(38)
+    a.rnn_type, a.embed_size, a.hidden_size = g.rnn, g.H, g.H
+    a.depthT, a.depthG, a.dropout, a.latent_size = g.depthT, g.depthG, 0.0, g.latent
+    model = HierEncoderVAE(a).to(_dev())
+    sd = {}
+    for k, v in g.params().items():
+        sd[k if k.startswith("R_") else "encoder." + k] = v
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_encoder_matches_reference_golden(name):
+    """HierMPNEncoder outputs, KL and parameter gradients vs vectors produced by the reference itself."""
+    g = Golden(name)
+    model = _build_encoder(g)
+    z, kl, outs = model(g.numpy_tensors(), perturb_z=False)
+    coeffs = g.loss_coeffs([tuple(o.shape) for o in outs])
+    loss = g.beta * kl
+    for c, o in zip(coeffs, outs):
+        loss = loss + (torch.from_numpy(c).to(_dev()) * o).sum()
+    loss.backward()
+    for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
+        e = rel_err(o.detach().cpu().numpy(), g.z[k])
+        assert e < TOL, "%s %s rel err %.3e" % (name, k, e)
+    assert abs(float(kl.detach()) - float(g.z["kl"])) <= TOL * max(1.0, abs(float(g.z["kl"])))
+    assert rel_err(z.detach().cpu().numpy(), g.z["z"]) < TOL
+    assert abs(float(loss.detach()) - float(g.z["loss"])) <= TOL * max(1.0, abs(float(g.z["loss"])))
+    for k, v in model.named_parameters():
+        key = k[len("encoder."):] if k.startswith("encoder.") else k
+        grad = v.grad if v.grad is not None else torch.zeros_like(v)
+        g.check_grad(key, grad.cpu().numpy(), rel=TOL)
+
+
+@pytest.mark.parametrize("name", ["tiny_gru_s0", "cfg_gru_s0", "cfg_lstm_s0"])
+def test_encoder_is_bitwise_reproducible(name):
+    """No atomics on the float path: two runs give identical bits (outputs and gradients)."""
+    g = Golden(name)
+    model = _build_encoder(g)
+    res = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        z, kl, outs = model(g.numpy_tensors(), perturb_z=False)
+        (kl + sum(o.sum() for o in outs)).backward()
+        res.append([o.detach().clone() for o in outs] + [p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
