@@ -70,7 +70,7 @@ def test_gemm_against_fp64(ta, tb, M, N, K):
     assert (got[:, N:ldc - 8] == 0).all() and (got[:, ldc - 8:] == 7.0).all()
     # accumulate + relu + row-0 mask
     F_.gemm(ta, tb, M, N, K, a, lda, b, ldb, C, ldc, N, accumulate=True, act=F_.ACT_RELU, zero_row0=True)
-    ref2 = np.maximum(ref + got[:, :N], 0.0)
+    ref2 = np.maximum((ref - bias) + got[:, :N], 0.0)
     ref2[0] = 0
     assert rel_err(C.cpu().numpy()[:, :N], ref2) < 2e-6
 
@@ -81,6 +81,7 @@ def test_segment_sum_and_gather():
     rows, nsrc, W, ld = 200, 300, 300, 304
     src = np.zeros((nsrc, ld), dtype=np.float32)
     src[:, :W] = rs.standard_normal((nsrc, W))
+    src[0] = 0            # row 0 is the pad row of the reference layout (always zero there)
     padded = np.zeros((rows, 6), dtype=np.int64)
     for r in range(1, rows):
         k = rs.randint(0, 6)
