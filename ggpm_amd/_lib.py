@@ -56,6 +56,11 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the ONE HIP runtime in the process (the
+    # stream and every device pointer we are handed come from it).  Importing torch first makes our
+    # library's libamdhip64.so.7 dependency resolve to the copy torch already loaded; the other order
+    # leaves two runtimes in one process and every launch fails.
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         if not build_if_missing:

@@ -14,6 +14,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (hipGetLastError() != hipSuccess) return GGPM_ERR_LAUNCH; \
     } while (0)
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (PyTorch
+// leaves benign errors behind, e.g. from capability probes); clear it on entry so that the check after our
+// launches reports OUR launches only.
+#define GGPM_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
 static inline int ggpm_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int ggpm_round_up(int a, int b) { return ggpm_ceil_div(a, b) * b; }
 

@@ -80,6 +80,7 @@ __global__ void embed_graph_k(const int64_t* __restrict__ fnode, int N1, const i
 extern "C" int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const int32_t* col,
                                 int rows, int width, float* out, int ld_out, int accumulate,
                                 ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!src || !rowptr || !col || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (width % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) &&
@@ -93,6 +94,7 @@ extern "C" int ggpm_segment_sum(const float* src, int ld_src, const int32_t* row
 
 extern "C" int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
                                 float* out, int ld_out, int col_off, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!table || !idx || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
     gather_rows_k<<<ggpm_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(table, ld_table, idx, rows, width, out,
                                                                           ld_out, col_off);
@@ -102,6 +104,7 @@ extern "C" int ggpm_gather_rows(const float* table, int ld_table, const int32_t*
 
 extern "C" int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off,
                            ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!idx || !out || rows <= 0 || classes <= 0) return GGPM_ERR_ARG;
     dim3 grid(ggpm_ceil_div(classes, 64), rows);
     onehot_k<<<grid, 64, 0, (hipStream_t)stream>>>(idx, rows, classes, out, ld_out, col_off);
@@ -112,6 +115,7 @@ extern "C" int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out
 extern "C" int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1, int atom_size,
                                 int bond_types, int max_pos, float* hnode, int ld_n, float* hmess, int ld_m,
                                 ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!fnode || !fmess || !hnode || !hmess || N1 <= 0 || E1 <= 0) return GGPM_ERR_ARG;
     if (ld_n > 256 || ld_m > 256 || ld_n < atom_size || ld_m < atom_size + bond_types + max_pos)
         return GGPM_ERR_UNSUPPORTED;

@@ -202,6 +202,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
                          const float* B, int ldb, float* C, int ldc, int n_pad, const float* bias,
                          int accumulate, int act, int zero_row0, float* splitk_ws, size_t splitk_ws_bytes,
                          ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || n_pad < N || n_pad > ldc) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g;
@@ -233,6 +234,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
 }
 
 extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!A || !out || !ws || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 g1(ggpm_ceil_div(N, 256), CS_ROWS);
@@ -244,6 +246,7 @@ extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, fl
 
 extern "C" int ggpm_act_backward(const float* dy, const float* y, int rows, int cols, int ld, int act,
                                  int zero_row0, float* dpre, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!dy || !y || !dpre || rows <= 0 || cols <= 0) return GGPM_ERR_ARG;
     dim3 grid(ggpm_ceil_div(cols, 256), rows);
     act_backward_k<<<grid, 256, 0, (hipStream_t)stream>>>(dy, y, rows, cols, ld, act, zero_row0, dpre);

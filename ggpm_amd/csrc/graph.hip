@@ -108,6 +108,7 @@ __global__ void extract_column_k(const int64_t* __restrict__ mat, int rows, int 
 
 extern "C" int ggpm_padded_to_csr(const int64_t* padded, int rows, int width, int32_t* rowptr, int32_t* col,
                                   ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!padded || !rowptr || !col || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int T = 256, B = ggpm_ceil_div(rows, T);
@@ -120,6 +121,7 @@ extern "C" int ggpm_padded_to_csr(const int64_t* padded, int rows, int width, in
 
 extern "C" int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int rows, int ncols,
                                   int32_t* rowptrT, int32_t* colT, int32_t* cursor, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!rowptr || !col || !rowptrT || !colT || !cursor || rows <= 0 || ncols <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int T = 256;
@@ -135,6 +137,7 @@ extern "C" int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int
 
 extern "C" int ggpm_extract_column(const int64_t* mat, int rows, int width, int column, int32_t* out,
                                    ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (!mat || !out || rows <= 0 || column < 0 || column >= width) return GGPM_ERR_ARG;
     extract_column_k<<<ggpm_ceil_div(rows, 256), 256, 0, (hipStream_t)stream>>>(mat, rows, width, column, out);
     GGPM_CHECK_LAUNCH();

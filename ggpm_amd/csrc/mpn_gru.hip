@@ -363,6 +363,7 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
                                 const float* Wh_h, int ld_wh, const int32_t* pred_rowptr,
                                 const int32_t* pred_col, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs,
                                 float* Ms, float* wpack, int save_for_backward, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xz || !Xr || !Xh || !Wz_h || !Ur || !bu || !Wh_h || !pred_rowptr ||
         !pred_col || !Hs || !Qs || !wpack)
         return GGPM_ERR_ARG;
@@ -431,6 +432,7 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
                                  const float* Ms, const float* dHD, float* dXz, float* dXr, float* dXh,
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !dHD || !dXz || !dXr || !dXh ||
         !dWz_h || !dUr || !dbu || !dWh_h || !work)

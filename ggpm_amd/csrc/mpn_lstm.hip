@@ -324,6 +324,7 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
                                  const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
                                  float* Qs, float* Ss, float* Is, float* Os, float* Us, float* wpack,
                                  int save_for_backward, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xi || !Xo || !Xu || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h ||
         !pred_rowptr || !pred_col || !Hs || !Cs || !Qs || !wpack)
         return GGPM_ERR_ARG;
@@ -394,6 +395,7 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
                                   float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                                   float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
                                   size_t work_bytes, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Cs || !Qs || !Ss || !Is || !Os || !Us || !dHD || !dXi || !dXo || !dXu ||
         !dXf || !dWi_h || !dWo_h || !dWu_h || !dWf_h || !work)
