@@ -14,6 +14,7 @@
 //   P3  dG = dm_pre.Wh_h, dS = ds_dir + dz_pre.Wz_h   P4  dXr accumulation over predecessors
 // Weight gradients are three tall split-K GEMMs over the [depth*E1, Hp] stashes (gemm.hip).
 #include "tile_mma.h"
+#include <cstdlib>
 
 __global__ void ggpm_pack_weight_kernel(const float* __restrict__ W, int ldw, int H, int Hp, int transpose,
                                         float* __restrict__ dst) {
@@ -40,6 +41,7 @@ void ggpm_launch_pack(const float* W, int ldw, int H, int Hp, int transpose, flo
 namespace {
 
 constexpr int ROWS = 16;
+constexpr int NWAVES = 16;   // waves per workgroup: 4 per SIMD hide the L2 latency of the weight stream
 
 struct GruFwdArgs {
     int E1, Hp;
@@ -51,6 +53,7 @@ struct GruFwdArgs {
     const float* bu;               // [Hp] zero padded
     const int32_t *rowptr, *col;
     int write_q;                   // 0 on the last depth: q^depth is never consumed, skip P3
+    int ablate;                    // timing experiments only (GGPM_ABLATE): 1 no gather, 2 no GEMM, 4 no P3
 };
 
 __global__ void gru_init_state(float* __restrict__ H0, float* __restrict__ Q0, const float* __restrict__ bu,
@@ -67,65 +70,91 @@ __global__ void pad_bias(const float* __restrict__ b, int H, int Hp, float* __re
     if (c < Hp) out[c] = (c < H) ? b[c] : 0.f;
 }
 
-template <int TPW, bool STASH>
-__global__ void __launch_bounds__(256) gru_step_fwd(GruFwdArgs a) {
+template <int TPW, int NW, bool STASH>
+__global__ void __launch_bounds__(NW * 64) gru_step_fwd(GruFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;                 // s tile
     float* Tg = lds + ROWS * LD;     // g tile
     float* Th = lds + 2 * ROWS * LD; // h' tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
 
-    // ---- P1: gather predecessors
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lr = wave * 4 + rr;
+    // ---- P1: gather predecessors (one wave per row; 4 independent predecessor rows in flight)
+    for (int lr = wave; lr < ROWS; lr += NW) {
         const int row = r0 + lr;
-        int lo = 0, hi = 0;
-        if (row < a.E1) { lo = a.rowptr[row]; hi = a.rowptr[row + 1]; }
-        for (int c = lane * 4; c < Hp; c += 256) {
+        const GgpmRowList rl = ggpm_row_list(a.rowptr, row, a.E1);
+        for (int c0 = 0; c0 < Hp; c0 += 256) {
+            const int c = c0 + lane * 4;
+            const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing
             float4 s = ggpm_zero4(), g = ggpm_zero4();
-            if (hi > lo) {
-                const float4 xr = ggpm_ld4(a.Xr + (size_t)row * Hp + c);
-                for (int j = lo; j < hi; ++j) {
-                    const size_t p = (size_t)a.col[j] * Hp + c;
-                    const float4 h = ggpm_ld4(a.Hprev + p);
-                    const float4 q = ggpm_ld4(a.Qprev + p);
-                    const float4 r = ggpm_sigmoid4(xr + q);
-                    s = s + h;
-                    g = g + r * h;
+            if (rl.n > 0 && !(a.ablate & 1)) {
+                const float4 xr = ggpm_ld4(a.Xr + (size_t)row * Hp + cs);
+                for (int base = 0; base < rl.n; base += 64) {
+                    const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
+                    const int m = min(64, rl.n - base);
+                    for (int j = 0; j < m; j += 4) {
+                        float4 h[4], q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                            h[u] = ggpm_ld4(a.Hprev + p);
+                            q[u] = ggpm_ld4(a.Qprev + p);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            s = s + h[u];
+                            g = g + ggpm_sigmoid4(xr + q[u]) * h[u];   // null slots: h[0] == 0
+                        }
+                    }
                 }
             }
-            ggpm_st4(Ts + lr * LD + c, s);
-            ggpm_st4(Tg + lr * LD + c, g);
-            if (STASH && row < a.E1) {
-                ggpm_st4(a.S + (size_t)row * Hp + c, s);
-                ggpm_st4(a.G + (size_t)row * Hp + c, g);
+            if (on) {
+                ggpm_st4(Ts + lr * LD + c, s);
+                ggpm_st4(Tg + lr * LD + c, g);
+                if (STASH && row < a.E1) {
+                    ggpm_st4(a.S + (size_t)row * Hp + c, s);
+                    ggpm_st4(a.G + (size_t)row * Hp + c, g);
+                }
             }
         }
+    }
+
+    // prefetch the hoisted input terms of this wave's tiles while the other waves finish their gathers
+    const int lr = lane & 15, row = r0 + lr;
+    const bool live = row < a.E1;
+    const bool act = live && row != 0;
+    float4 xz[TPW], xh[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + NW * i;
+        const int c = 16 * t + 4 * (lane >> 4);
+        const bool ok = act && t < NT;
+        xz[i] = ok ? ggpm_ld4(a.Xz + (size_t)row * Hp + c) : ggpm_zero4();
+        xh[i] = ok ? ggpm_ld4(a.Xh + (size_t)row * Hp + c) : ggpm_zero4();
     }
     __syncthreads();
 
     // ---- P2: gate GEMMs + gate math
-    const int lr = lane & 15, row = r0 + lr;
-    const bool live = row < a.E1;
     {
         f32x4 accz[TPW], accm[TPW];
         ggpm_zero_acc<TPW>(accz);
         ggpm_zero_acc<TPW>(accm);
-        ggpm_tile_gemm<TPW>(Ts, LD, a.Wz, KC, NT, wave, lane, accz);
-        ggpm_tile_gemm<TPW>(Tg, LD, a.Wh, KC, NT, wave, lane, accm);
+        if (!(a.ablate & 2)) {
+            ggpm_tile_gemm<TPW, NW>(Ts, LD, a.Wz, KC, NT, wave, lane, accz);
+            ggpm_tile_gemm<TPW, NW>(Tg, LD, a.Wh, KC, NT, wave, lane, accm);
+        }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
-            if (live && row != 0) {
-                const float4 xz = ggpm_ld4(a.Xz + (size_t)row * Hp + c);
-                const float4 xh = ggpm_ld4(a.Xh + (size_t)row * Hp + c);
+            if (act) {
                 const float4 s = ggpm_ld4(Ts + lr * LD + c);
-                const float4 pz = ggpm_f4(accz[i]) + xz, pm = ggpm_f4(accm[i]) + xh;
+                const float4 pz = ggpm_f4(accz[i]) + xz[i], pm = ggpm_f4(accm[i]) + xh[i];
                 z = ggpm_sigmoid4(pz);
                 m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
                 h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
@@ -141,16 +170,16 @@ __global__ void __launch_bounds__(256) gru_step_fwd(GruFwdArgs a) {
             }
         }
     }
-    __syncthreads();
 
     // ---- P3: q' = U_r h' + b_u
-    if (a.write_q) {
+    if (a.write_q && !(a.ablate & 4)) {
+        __syncthreads();
         f32x4 accq[TPW];
         ggpm_zero_acc<TPW>(accq);
-        ggpm_tile_gemm<TPW>(Th, LD, a.Ur, KC, NT, wave, lane, accq);
+        ggpm_tile_gemm<TPW, NW>(Th, LD, a.Ur, KC, NT, wave, lane, accq);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT || !live) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(accq[i]) + ggpm_ld4(a.bu + c));
@@ -176,66 +205,97 @@ struct GruBwdArgs {
     const int32_t *srowptr, *scol; // successors
 };
 
-template <int TPW>
-__global__ void __launch_bounds__(256) gru_step_bwd(GruBwdArgs a) {
+template <int TPW, int NW>
+__global__ void __launch_bounds__(NW * 64) gru_step_bwd(GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T0 = lds;                  // dh partial -> ds_dir
     float* T1 = lds + ROWS * LD;      // dq -> dz_pre
     float* T2 = lds + 2 * ROWS * LD;  // dm_pre -> dG
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
 
     // ---- P1: gather over successors of p:  dh_p += dS_e + dG_e*r ; dq_p += dG_e * h_p * r(1-r)
+    // (null slots read row 0, where dS = dG = 0)
     if (!a.first) {
-        for (int rr = 0; rr < 4; ++rr) {
-            const int lr = wave * 4 + rr;
+        for (int lr = wave; lr < ROWS; lr += NW) {
             const int p = r0 + lr;
-            int lo = 0, hi = 0;
-            if (p < a.E1) { lo = a.srowptr[p]; hi = a.srowptr[p + 1]; }
-            for (int c = lane * 4; c < Hp; c += 256) {
+            const GgpmRowList rl = ggpm_row_list(a.srowptr, p, a.E1);
+            for (int c0 = 0; c0 < Hp; c0 += 256) {
+                const int c = c0 + lane * 4;
+                const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing
                 float4 dh = ggpm_zero4(), dq = ggpm_zero4();
-                if (hi > lo) {
-                    const float4 hp = ggpm_ld4(a.Hcur + (size_t)p * Hp + c);
-                    const float4 qp = ggpm_ld4(a.Qcur + (size_t)p * Hp + c);
-                    for (int j = lo; j < hi; ++j) {
-                        const size_t e = (size_t)a.scol[j] * Hp + c;
-                        const float4 r = ggpm_sigmoid4(ggpm_ld4(a.Xr + e) + qp);
-                        const float4 dg = ggpm_ld4(a.dGin + e);
-                        const float4 ds = ggpm_ld4(a.dSin + e);
-                        dh = dh + ds + dg * r;
-                        const float4 one_r = make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w);
-                        dq = dq + dg * hp * r * one_r;
+                if (rl.n > 0) {   // wave-uniform: every lane takes part in the list broadcast below
+                    const float4 hp = ggpm_ld4(a.Hcur + (size_t)p * Hp + cs);
+                    const float4 qp = ggpm_ld4(a.Qcur + (size_t)p * Hp + cs);
+                    for (int base = 0; base < rl.n; base += 64) {
+                        const int chunk = ggpm_list_chunk(a.scol, rl, base, lane);
+                        const int m = min(64, rl.n - base);
+                        for (int j = 0; j < m; j += 4) {
+                            float4 xr[4], dg[4], ds[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const size_t e = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                                xr[u] = ggpm_ld4(a.Xr + e);
+                                dg[u] = ggpm_ld4(a.dGin + e);
+                                ds[u] = ggpm_ld4(a.dSin + e);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float4 r = ggpm_sigmoid4(xr[u] + qp);
+                                const float4 one_r = make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w);
+                                dh = dh + ds[u] + dg[u] * r;
+                                dq = dq + dg[u] * hp * r * one_r;
+                            }
+                        }
                     }
                 }
-                ggpm_st4(T0 + lr * LD + c, dh);
-                ggpm_st4(T1 + lr * LD + c, dq);
-                if (p < a.E1) ggpm_st4(a.DQ + (size_t)p * Hp + c, dq);
+                if (on) {
+                    ggpm_st4(T0 + lr * LD + c, dh);
+                    ggpm_st4(T1 + lr * LD + c, dq);
+                    if (p < a.E1) ggpm_st4(a.DQ + (size_t)p * Hp + c, dq);
+                }
             }
         }
-        __syncthreads();
     }
 
-    // ---- P2: dh = partial + dq . U_r ; gate derivatives
+    // prefetch this wave's stash operands for P2
     const int lr = lane & 15, row = r0 + lr;
     const bool live = row < a.E1;
+    const bool act = live && row != 0;
+    float4 st_s[TPW], st_z[TPW], st_m[TPW], st_dh[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + NW * i;
+        const int c = 16 * t + 4 * (lane >> 4);
+        const bool ok = act && t < NT;
+        const size_t o = (size_t)row * Hp + c;
+        st_s[i] = ok ? ggpm_ld4(a.S + o) : ggpm_zero4();
+        st_z[i] = ok ? ggpm_ld4(a.Z + o) : ggpm_zero4();
+        st_m[i] = ok ? ggpm_ld4(a.M + o) : ggpm_zero4();
+        st_dh[i] = (ok && a.first) ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+    }
+    if (!a.first) __syncthreads();
+
+    // ---- P2: dh = partial + dq . U_r ; gate derivatives
     {
         f32x4 acc[TPW];
         ggpm_zero_acc<TPW>(acc);
         if (!a.first) {
-            ggpm_tile_gemm<TPW>(T1, LD, a.UrT, KC, NT, wave, lane, acc);
+            ggpm_tile_gemm<TPW, NW>(T1, LD, a.UrT, KC, NT, wave, lane, acc);
             __syncthreads();   // every wave is done reading T1 before it is overwritten below
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
-            if (live && row != 0) {
-                const size_t o = (size_t)row * Hp + c;
-                float4 dh = a.first ? ggpm_ld4(a.dHD + o) : (ggpm_f4(acc[i]) + ggpm_ld4(T0 + lr * LD + c));
-                const float4 s = ggpm_ld4(a.S + o), z = ggpm_ld4(a.Z + o), m = ggpm_ld4(a.M + o);
+            if (act) {
+                const float4 dh = a.first ? st_dh[i] : (ggpm_f4(acc[i]) + ggpm_ld4(T0 + lr * LD + c));
+                const float4 s = st_s[i], z = st_z[i], m = st_m[i];
                 const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s.x, s.y, s.z, s.w};
                 const float zv[4] = {z.x, z.y, z.z, z.w}, mv[4] = {m.x, m.y, m.z, m.w};
                 float o_ds[4], o_dz[4], o_dm[4];
@@ -261,19 +321,19 @@ __global__ void __launch_bounds__(256) gru_step_bwd(GruBwdArgs a) {
             }
         }
     }
-    __syncthreads();
 
     // ---- P3: dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h   (consumed by launch t-1)
     if (!a.last) {
+        __syncthreads();
         f32x4 accg[TPW], accs[TPW];
         ggpm_zero_acc<TPW>(accg);
         ggpm_zero_acc<TPW>(accs);
-        ggpm_tile_gemm<TPW>(T2, LD, a.WhT, KC, NT, wave, lane, accg);
-        ggpm_tile_gemm<TPW>(T1, LD, a.WzT, KC, NT, wave, lane, accs);
+        ggpm_tile_gemm<TPW, NW>(T2, LD, a.WhT, KC, NT, wave, lane, accg);
+        ggpm_tile_gemm<TPW, NW>(T1, LD, a.WzT, KC, NT, wave, lane, accs);
         __syncthreads();       // T2 is about to be overwritten with dG
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             const float4 dg = ggpm_f4(accg[i]);
@@ -287,25 +347,40 @@ __global__ void __launch_bounds__(256) gru_step_bwd(GruBwdArgs a) {
         }
         __syncthreads();
 
-        // ---- P4: dXr_e += sum_p dG_e * h_p * r(1-r),  r = sigmoid(Xr_e + q_p)
-        for (int rr = 0; rr < 4; ++rr) {
-            const int l2 = wave * 4 + rr;
+        // ---- P4: dXr_e += sum_p dG_e * h_p * r(1-r),  r = sigmoid(Xr_e + q_p)   (null slots: h[0] == 0)
+        for (int l2 = wave; l2 < ROWS; l2 += NW) {
             const int e = r0 + l2;
-            if (e >= a.E1) continue;
-            const int lo = a.rowptr[e], hi = a.rowptr[e + 1];
-            if (hi <= lo) continue;
-            for (int c = lane * 4; c < Hp; c += 256) {
-                const size_t o = (size_t)e * Hp + c;
+            const GgpmRowList rl = ggpm_row_list(a.rowptr, e, a.E1);
+            if (rl.n <= 0) continue;
+            for (int c0 = 0; c0 < Hp; c0 += 256) {
+                const int c = c0 + lane * 4;
+                const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing     // no early exit: every lane takes part in the list broadcast
+                const size_t o = (size_t)e * Hp + cs;
                 const float4 xr = ggpm_ld4(a.Xr + o);
-                const float4 dg = ggpm_ld4(T2 + l2 * LD + c);
+                const float4 dxr_old = ggpm_ld4(a.dXr + o);
+                const float4 dg = ggpm_ld4(T2 + l2 * LD + cs);
                 float4 accx = ggpm_zero4();
-                for (int j = lo; j < hi; ++j) {
-                    const size_t p = (size_t)a.col[j] * Hp + c;
-                    const float4 r = ggpm_sigmoid4(xr + ggpm_ld4(a.Qprv + p));
-                    const float4 one_r = make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w);
-                    accx = accx + dg * ggpm_ld4(a.Hprv + p) * r * one_r;
+                for (int base = 0; base < rl.n; base += 64) {
+                    const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
+                    const int m = min(64, rl.n - base);
+                    for (int j = 0; j < m; j += 4) {
+                        float4 h[4], q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                            h[u] = ggpm_ld4(a.Hprv + p);
+                            q[u] = ggpm_ld4(a.Qprv + p);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 r = ggpm_sigmoid4(xr + q[u]);
+                            const float4 one_r = make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w);
+                            accx = accx + dg * h[u] * r * one_r;
+                        }
+                    }
                 }
-                ggpm_st4(a.dXr + o, ggpm_ld4(a.dXr + o) + accx);
+                if (on) ggpm_st4(a.dXr + o, dxr_old + accx);
             }
         }
     }
@@ -320,19 +395,19 @@ inline void set_lds(K kernel, size_t bytes) {
 template <int TPW>
 int launch_fwd(const GruFwdArgs& a, bool stash, size_t lds_bytes, int grid, hipStream_t s) {
     if (stash) {
-        set_lds(gru_step_fwd<TPW, true>, lds_bytes);
-        gru_step_fwd<TPW, true><<<grid, 256, lds_bytes, s>>>(a);
+        set_lds(gru_step_fwd<TPW, NWAVES, true>, lds_bytes);
+        gru_step_fwd<TPW, NWAVES, true><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     } else {
-        set_lds(gru_step_fwd<TPW, false>, lds_bytes);
-        gru_step_fwd<TPW, false><<<grid, 256, lds_bytes, s>>>(a);
+        set_lds(gru_step_fwd<TPW, NWAVES, false>, lds_bytes);
+        gru_step_fwd<TPW, NWAVES, false><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     }
     return 0;
 }
 
 template <int TPW>
 int launch_bwd(const GruBwdArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
-    set_lds(gru_step_bwd<TPW>, lds_bytes);
-    gru_step_bwd<TPW><<<grid, 256, lds_bytes, s>>>(a);
+    set_lds(gru_step_bwd<TPW, NWAVES>, lds_bytes);
+    gru_step_bwd<TPW, NWAVES><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     return 0;
 }
 
@@ -348,13 +423,6 @@ extern "C" size_t ggpm_gru_pack_floats(int H) {
         case 1: CALL(1); break;                 \
         case 2: CALL(2); break;                 \
         case 3: CALL(3); break;                 \
-        case 4: CALL(4); break;                 \
-        case 5: CALL(5); break;                 \
-        case 6: CALL(6); break;                 \
-        case 7: CALL(7); break;                 \
-        case 8: CALL(8); break;                 \
-        case 9: CALL(9); break;                 \
-        case 10: CALL(10); break;               \
         default: return GGPM_ERR_UNSUPPORTED;   \
     }
 
@@ -369,9 +437,9 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
         return GGPM_ERR_ARG;
     if (save_for_backward && (!Ss || !Gs || !Zs || !Ms)) return GGPM_ERR_ARG;
     const int Hp = ggpm_padded_hidden(H);
-    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, 4);
+    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, NWAVES);
     const size_t lds_bytes = (size_t)3 * ROWS * (Hp + 4) * sizeof(float);
-    if (tpw > 10 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
+    if (tpw > 3 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
     float* pWz = wpack; float* pWh = wpack + HH; float* pUr = wpack + 2 * HH; float* pbu = wpack + 3 * HH;
@@ -400,6 +468,7 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
             a.S = a.G = a.Z = a.M = nullptr;
         }
         a.write_q = (t < depth);
+        { const char* e = getenv("GGPM_ABLATE"); a.ablate = e ? atoi(e) : 0; }
         ggpm_timing_begin(0, s, flops);
 #define CALL(T) launch_fwd<T>(a, save_for_backward != 0, lds_bytes, grid, s)
         GGPM_DISPATCH_TPW(tpw, CALL)
@@ -439,9 +508,9 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
         return GGPM_ERR_ARG;
     if (work_bytes < ggpm_gru_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
-    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, 4);
+    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, NWAVES);
     const size_t lds_bytes = (size_t)3 * ROWS * (Hp + 4) * sizeof(float);
-    if (tpw > 10 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
+    if (tpw > 3 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 

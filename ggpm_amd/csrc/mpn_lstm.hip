@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int ROWS = 16;
+constexpr int NWAVES = 16;
 
 struct LstmFwdArgs {
     int E1, Hp;
@@ -26,62 +27,91 @@ struct LstmFwdArgs {
     int write_q;
 };
 
-template <int TPW, bool STASH>
-__global__ void __launch_bounds__(256) lstm_step_fwd(LstmFwdArgs a) {
+template <int TPW, int NW, bool STASH>
+__global__ void __launch_bounds__(NW * 64) lstm_step_fwd(LstmFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;
     float* Tf = lds + ROWS * LD;
     float* Th = lds + 2 * ROWS * LD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
 
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lr = wave * 4 + rr;
+    // ---- P1: gather predecessors (null slots read row 0: h = c = 0)
+    for (int lr = wave; lr < ROWS; lr += NW) {
         const int row = r0 + lr;
-        int lo = 0, hi = 0;
-        if (row < a.E1) { lo = a.rowptr[row]; hi = a.rowptr[row + 1]; }
-        for (int c = lane * 4; c < Hp; c += 256) {
+        const GgpmRowList rl = ggpm_row_list(a.rowptr, row, a.E1);
+        for (int c0 = 0; c0 < Hp; c0 += 256) {
+            const int c = c0 + lane * 4;
+            const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing
             float4 s = ggpm_zero4(), fc = ggpm_zero4();
-            if (hi > lo) {
-                const float4 xf = ggpm_ld4(a.Xf + (size_t)row * Hp + c);
-                for (int j = lo; j < hi; ++j) {
-                    const size_t p = (size_t)a.col[j] * Hp + c;
-                    const float4 h = ggpm_ld4(a.Hprev + p);
-                    const float4 cc = ggpm_ld4(a.Cprev + p);
-                    const float4 f = ggpm_sigmoid4(xf + ggpm_ld4(a.Qprev + p));
-                    s = s + h;
-                    fc = fc + f * cc;
+            if (rl.n > 0) {
+                const float4 xf = ggpm_ld4(a.Xf + (size_t)row * Hp + cs);
+                for (int base = 0; base < rl.n; base += 64) {
+                    const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
+                    const int m = min(64, rl.n - base);
+                    for (int j = 0; j < m; j += 4) {
+                        float4 h[4], cc[4], q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                            h[u] = ggpm_ld4(a.Hprev + p);
+                            cc[u] = ggpm_ld4(a.Cprev + p);
+                            q[u] = ggpm_ld4(a.Qprev + p);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            s = s + h[u];
+                            fc = fc + ggpm_sigmoid4(xf + q[u]) * cc[u];
+                        }
+                    }
                 }
             }
-            ggpm_st4(Ts + lr * LD + c, s);
-            ggpm_st4(Tf + lr * LD + c, fc);
-            if (STASH && row < a.E1) ggpm_st4(a.S + (size_t)row * Hp + c, s);
+            if (on) {
+                ggpm_st4(Ts + lr * LD + c, s);
+                ggpm_st4(Tf + lr * LD + c, fc);
+                if (STASH && row < a.E1) ggpm_st4(a.S + (size_t)row * Hp + c, s);
+            }
         }
     }
-    __syncthreads();
 
     const int lr = lane & 15, row = r0 + lr;
     const bool live = row < a.E1;
+    const bool act = live && row != 0;
+    float4 xi[TPW], xo[TPW], xu[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + NW * i;
+        const int c = 16 * t + 4 * (lane >> 4);
+        const bool ok = act && t < NT;
+        const size_t o = (size_t)row * Hp + c;
+        xi[i] = ok ? ggpm_ld4(a.Xi + o) : ggpm_zero4();
+        xo[i] = ok ? ggpm_ld4(a.Xo + o) : ggpm_zero4();
+        xu[i] = ok ? ggpm_ld4(a.Xu + o) : ggpm_zero4();
+    }
+    __syncthreads();
+
+    // ---- P2: [Wi_h; Wo_h; Wu_h] . s + gate math
     {
         f32x4 acci[TPW], acco[TPW], accu[TPW];
         ggpm_zero_acc<TPW>(acci);
         ggpm_zero_acc<TPW>(acco);
         ggpm_zero_acc<TPW>(accu);
-        ggpm_tile_gemm<TPW>(Ts, LD, a.Wi, KC, NT, wave, lane, acci);
-        ggpm_tile_gemm<TPW>(Ts, LD, a.Wo, KC, NT, wave, lane, acco);
-        ggpm_tile_gemm<TPW>(Ts, LD, a.Wu, KC, NT, wave, lane, accu);
+        ggpm_tile_gemm<TPW, NW>(Ts, LD, a.Wi, KC, NT, wave, lane, acci);
+        ggpm_tile_gemm<TPW, NW>(Ts, LD, a.Wo, KC, NT, wave, lane, acco);
+        ggpm_tile_gemm<TPW, NW>(Ts, LD, a.Wu, KC, NT, wave, lane, accu);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
-            if (live && row != 0) {
-                const size_t o = (size_t)row * Hp + c;
-                const float4 pi = ggpm_f4(acci[i]) + ggpm_ld4(a.Xi + o);
-                const float4 po = ggpm_f4(acco[i]) + ggpm_ld4(a.Xo + o);
-                const float4 pu = ggpm_f4(accu[i]) + ggpm_ld4(a.Xu + o);
+            if (act) {
+                const float4 pi = ggpm_f4(acci[i]) + xi[i];
+                const float4 po = ggpm_f4(acco[i]) + xo[i];
+                const float4 pu = ggpm_f4(accu[i]) + xu[i];
                 const float4 fc = ggpm_ld4(Tf + lr * LD + c);
                 gi = ggpm_sigmoid4(pi);
                 go = ggpm_sigmoid4(po);
@@ -102,15 +132,16 @@ __global__ void __launch_bounds__(256) lstm_step_fwd(LstmFwdArgs a) {
             }
         }
     }
-    __syncthreads();
 
+    // ---- P3: qf' = Wf_h h'
     if (a.write_q) {
+        __syncthreads();
         f32x4 accq[TPW];
         ggpm_zero_acc<TPW>(accq);
-        ggpm_tile_gemm<TPW>(Th, LD, a.Wf, KC, NT, wave, lane, accq);
+        ggpm_tile_gemm<TPW, NW>(Th, LD, a.Wf, KC, NT, wave, lane, accq);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT || !live) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(accq[i]));
@@ -135,69 +166,101 @@ struct LstmBwdArgs {
     const int32_t *rowptr, *col, *srowptr, *scol;
 };
 
-template <int TPW>
-__global__ void __launch_bounds__(256) lstm_step_bwd(LstmBwdArgs a) {
+template <int TPW, int NW>
+__global__ void __launch_bounds__(NW * 64) lstm_step_bwd(LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T0 = lds;                  // dh partial -> di_pre
     float* T1 = lds + ROWS * LD;      // dqf -> do_pre
     float* T2 = lds + 2 * ROWS * LD;  // dc -> du_pre
     float* T3 = lds + 3 * ROWS * LD;  // dFC (= total dc of this depth)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
 
+    // ---- P1: gather over successors (null slots read row 0 where dS = dFC = 0)
     if (!a.first) {
-        for (int rr = 0; rr < 4; ++rr) {
-            const int lr = wave * 4 + rr;
+        for (int lr = wave; lr < ROWS; lr += NW) {
             const int p = r0 + lr;
-            int lo = 0, hi = 0;
-            if (p < a.E1) { lo = a.srowptr[p]; hi = a.srowptr[p + 1]; }
-            for (int c = lane * 4; c < Hp; c += 256) {
+            const GgpmRowList rl = ggpm_row_list(a.srowptr, p, a.E1);
+            for (int c0 = 0; c0 < Hp; c0 += 256) {
+                const int c = c0 + lane * 4;
+                const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing
                 float4 dh = ggpm_zero4(), dq = ggpm_zero4(), dc = ggpm_zero4();
-                if (hi > lo) {
-                    const float4 cp = ggpm_ld4(a.Ccur + (size_t)p * Hp + c);
-                    const float4 qp = ggpm_ld4(a.Qcur + (size_t)p * Hp + c);
-                    for (int j = lo; j < hi; ++j) {
-                        const size_t e = (size_t)a.scol[j] * Hp + c;
-                        const float4 f = ggpm_sigmoid4(ggpm_ld4(a.Xf + e) + qp);
-                        const float4 dfc = ggpm_ld4(a.dFCin + e);
-                        dh = dh + ggpm_ld4(a.dSin + e);
-                        dc = dc + dfc * f;
-                        const float4 one_f = make_float4(1.f - f.x, 1.f - f.y, 1.f - f.z, 1.f - f.w);
-                        dq = dq + dfc * cp * f * one_f;
+                if (rl.n > 0) {
+                    const float4 cp = ggpm_ld4(a.Ccur + (size_t)p * Hp + cs);
+                    const float4 qp = ggpm_ld4(a.Qcur + (size_t)p * Hp + cs);
+                    for (int base = 0; base < rl.n; base += 64) {
+                        const int chunk = ggpm_list_chunk(a.scol, rl, base, lane);
+                        const int m = min(64, rl.n - base);
+                        for (int j = 0; j < m; j += 4) {
+                            float4 xf[4], dfc[4], ds[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const size_t e = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                                xf[u] = ggpm_ld4(a.Xf + e);
+                                dfc[u] = ggpm_ld4(a.dFCin + e);
+                                ds[u] = ggpm_ld4(a.dSin + e);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float4 f = ggpm_sigmoid4(xf[u] + qp);
+                                const float4 one_f = make_float4(1.f - f.x, 1.f - f.y, 1.f - f.z, 1.f - f.w);
+                                dh = dh + ds[u];
+                                dc = dc + dfc[u] * f;
+                                dq = dq + dfc[u] * cp * f * one_f;
+                            }
+                        }
                     }
                 }
-                ggpm_st4(T0 + lr * LD + c, dh);
-                ggpm_st4(T1 + lr * LD + c, dq);
-                ggpm_st4(T2 + lr * LD + c, dc);
-                if (p < a.E1) ggpm_st4(a.DQ + (size_t)p * Hp + c, dq);
+                if (on) {
+                    ggpm_st4(T0 + lr * LD + c, dh);
+                    ggpm_st4(T1 + lr * LD + c, dq);
+                    ggpm_st4(T2 + lr * LD + c, dc);
+                    if (p < a.E1) ggpm_st4(a.DQ + (size_t)p * Hp + c, dq);
+                }
             }
         }
-        __syncthreads();
     }
 
     const int lr = lane & 15, row = r0 + lr;
     const bool live = row < a.E1;
+    const bool act = live && row != 0;
+    float4 st_i[TPW], st_o[TPW], st_u[TPW], st_c[TPW], st_dh[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + NW * i;
+        const int c = 16 * t + 4 * (lane >> 4);
+        const bool ok = act && t < NT;
+        const size_t o = (size_t)row * Hp + c;
+        st_i[i] = ok ? ggpm_ld4(a.I + o) : ggpm_zero4();
+        st_o[i] = ok ? ggpm_ld4(a.O + o) : ggpm_zero4();
+        st_u[i] = ok ? ggpm_ld4(a.U + o) : ggpm_zero4();
+        st_c[i] = ok ? ggpm_ld4(a.Ccur + o) : ggpm_zero4();
+        st_dh[i] = (ok && a.first) ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+    }
+    if (!a.first) __syncthreads();
+
+    // ---- P2: dh = partial + dqf . Wf_h ; gate derivatives
     {
         f32x4 acc[TPW];
         ggpm_zero_acc<TPW>(acc);
         if (!a.first) {
-            ggpm_tile_gemm<TPW>(T1, LD, a.WfT, KC, NT, wave, lane, acc);
+            ggpm_tile_gemm<TPW, NW>(T1, LD, a.WfT, KC, NT, wave, lane, acc);
             __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
-            if (live && row != 0) {
-                const size_t o = (size_t)row * Hp + c;
+            if (act) {
                 float4 dh, dc;
-                if (a.first) { dh = ggpm_ld4(a.dHD + o); dc = ggpm_zero4(); }
+                if (a.first) { dh = st_dh[i]; dc = ggpm_zero4(); }
                 else { dh = ggpm_f4(acc[i]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
-                const float4 gi = ggpm_ld4(a.I + o), go = ggpm_ld4(a.O + o), gu = ggpm_ld4(a.U + o);
-                const float4 cc = ggpm_ld4(a.Ccur + o);
+                const float4 gi = st_i[i], go = st_o[i], gu = st_u[i], cc = st_c[i];
                 const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
                 const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, ov[4] = {go.x, go.y, go.z, go.w};
                 const float uv[4] = {gu.x, gu.y, gu.z, gu.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
@@ -232,40 +295,57 @@ __global__ void __launch_bounds__(256) lstm_step_bwd(LstmBwdArgs a) {
             }
         }
     }
-    __syncthreads();
 
     if (!a.last) {
+        __syncthreads();
+        // ---- P3: dS = di_pre . Wi_h + do_pre . Wo_h + du_pre . Wu_h
         f32x4 accs[TPW];
         ggpm_zero_acc<TPW>(accs);
-        ggpm_tile_gemm<TPW>(T0, LD, a.WiT, KC, NT, wave, lane, accs);
-        ggpm_tile_gemm<TPW>(T1, LD, a.WoT, KC, NT, wave, lane, accs);
-        ggpm_tile_gemm<TPW>(T2, LD, a.WuT, KC, NT, wave, lane, accs);
+        ggpm_tile_gemm<TPW, NW>(T0, LD, a.WiT, KC, NT, wave, lane, accs);
+        ggpm_tile_gemm<TPW, NW>(T1, LD, a.WoT, KC, NT, wave, lane, accs);
+        ggpm_tile_gemm<TPW, NW>(T2, LD, a.WuT, KC, NT, wave, lane, accs);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t >= NT || !live) continue;
             const int c = 16 * t + 4 * (lane >> 4);
             ggpm_st4(a.dSout + (size_t)row * Hp + c, ggpm_f4(accs[i]));
         }
 
-        for (int rr = 0; rr < 4; ++rr) {
-            const int l2 = wave * 4 + rr;
+        // ---- P4: dXf_e += sum_p dFC_e * c_p * f(1-f),  f = sigmoid(Xf_e + qf_p)   (null slots: c[0] == 0)
+        for (int l2 = wave; l2 < ROWS; l2 += NW) {
             const int e = r0 + l2;
-            if (e >= a.E1) continue;
-            const int lo = a.rowptr[e], hi = a.rowptr[e + 1];
-            if (hi <= lo) continue;
-            for (int c = lane * 4; c < Hp; c += 256) {
-                const size_t o = (size_t)e * Hp + c;
+            const GgpmRowList rl = ggpm_row_list(a.rowptr, e, a.E1);
+            if (rl.n <= 0) continue;
+            for (int c0 = 0; c0 < Hp; c0 += 256) {
+                const int c = c0 + lane * 4;
+                const bool on = c < Hp;
+            const int cs = on ? c : 0;   // lanes past the row end load column 0 (no branch) and store nothing
+                const size_t o = (size_t)e * Hp + cs;
                 const float4 xf = ggpm_ld4(a.Xf + o);
-                const float4 dfc = ggpm_ld4(T3 + l2 * LD + c);
+                const float4 old = ggpm_ld4(a.dXf + o);
+                const float4 dfc = ggpm_ld4(T3 + l2 * LD + cs);
                 float4 accx = ggpm_zero4();
-                for (int j = lo; j < hi; ++j) {
-                    const size_t p = (size_t)a.col[j] * Hp + c;
-                    const float4 f = ggpm_sigmoid4(xf + ggpm_ld4(a.Qprv + p));
-                    const float4 one_f = make_float4(1.f - f.x, 1.f - f.y, 1.f - f.z, 1.f - f.w);
-                    accx = accx + dfc * ggpm_ld4(a.Cprv + p) * f * one_f;
+                for (int base = 0; base < rl.n; base += 64) {
+                    const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
+                    const int m = min(64, rl.n - base);
+                    for (int j = 0; j < m; j += 4) {
+                        float4 cc[4], q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp + cs;
+                            cc[u] = ggpm_ld4(a.Cprv + p);
+                            q[u] = ggpm_ld4(a.Qprv + p);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 f = ggpm_sigmoid4(xf + q[u]);
+                            const float4 one_f = make_float4(1.f - f.x, 1.f - f.y, 1.f - f.z, 1.f - f.w);
+                            accx = accx + dfc * cc[u] * f * one_f;
+                        }
+                    }
                 }
-                ggpm_st4(a.dXf + o, ggpm_ld4(a.dXf + o) + accx);
+                if (on) ggpm_st4(a.dXf + o, old + accx);
             }
         }
     }
@@ -280,19 +360,19 @@ inline void set_lds(K kernel, size_t bytes) {
 template <int TPW>
 int launch_fwd(const LstmFwdArgs& a, bool stash, size_t lds_bytes, int grid, hipStream_t s) {
     if (stash) {
-        set_lds(lstm_step_fwd<TPW, true>, lds_bytes);
-        lstm_step_fwd<TPW, true><<<grid, 256, lds_bytes, s>>>(a);
+        set_lds(lstm_step_fwd<TPW, NWAVES, true>, lds_bytes);
+        lstm_step_fwd<TPW, NWAVES, true><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     } else {
-        set_lds(lstm_step_fwd<TPW, false>, lds_bytes);
-        lstm_step_fwd<TPW, false><<<grid, 256, lds_bytes, s>>>(a);
+        set_lds(lstm_step_fwd<TPW, NWAVES, false>, lds_bytes);
+        lstm_step_fwd<TPW, NWAVES, false><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     }
     return 0;
 }
 
 template <int TPW>
 int launch_bwd(const LstmBwdArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
-    set_lds(lstm_step_bwd<TPW>, lds_bytes);
-    lstm_step_bwd<TPW><<<grid, 256, lds_bytes, s>>>(a);
+    set_lds(lstm_step_bwd<TPW, NWAVES>, lds_bytes);
+    lstm_step_bwd<TPW, NWAVES><<<grid, NWAVES * 64, lds_bytes, s>>>(a);
     return 0;
 }
 
@@ -303,13 +383,6 @@ int launch_bwd(const LstmBwdArgs& a, size_t lds_bytes, int grid, hipStream_t s) 
         case 1: CALL(1); break;                 \
         case 2: CALL(2); break;                 \
         case 3: CALL(3); break;                 \
-        case 4: CALL(4); break;                 \
-        case 5: CALL(5); break;                 \
-        case 6: CALL(6); break;                 \
-        case 7: CALL(7); break;                 \
-        case 8: CALL(8); break;                 \
-        case 9: CALL(9); break;                 \
-        case 10: CALL(10); break;               \
         default: return GGPM_ERR_UNSUPPORTED;   \
     }
 
@@ -330,9 +403,9 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
         return GGPM_ERR_ARG;
     if (save_for_backward && (!Ss || !Is || !Os || !Us)) return GGPM_ERR_ARG;
     const int Hp = ggpm_padded_hidden(H);
-    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, 4);
+    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, NWAVES);
     const size_t lds_bytes = (size_t)3 * ROWS * (Hp + 4) * sizeof(float);
-    if (tpw > 10 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
+    if (tpw > 3 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
     float* pWi = wpack; float* pWo = wpack + HH; float* pWu = wpack + 2 * HH; float* pWf = wpack + 3 * HH;
@@ -402,9 +475,9 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
         return GGPM_ERR_ARG;
     if (work_bytes < ggpm_lstm_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
-    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, 4);
+    const int NT = Hp / 16, tpw = ggpm_ceil_div(NT, NWAVES);
     const size_t lds_bytes = (size_t)4 * ROWS * (Hp + 4) * sizeof(float);
-    if (tpw > 10 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
+    if (tpw > 3 || lds_bytes > 160 * 1024) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 

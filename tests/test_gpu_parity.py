@@ -114,15 +114,16 @@ def _random_level(rs, E, I, K=4):
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
-@pytest.mark.parametrize("E,I,H,depth", [(5, 7, 16, 1), (40, 13, 24, 3), (333, 62, 300, 6), (200, 270, 250, 4),
-                                         (17, 20, 600, 2), (1000, 62, 64, 2)])
-def test_message_function_matches_oracle(rnn, E, I, H, depth):
+@pytest.mark.parametrize("E,I,H,depth,K", [(5, 7, 16, 1, 4), (40, 13, 24, 3, 4), (333, 62, 300, 6, 4),
+                                           (200, 270, 250, 4, 4), (17, 20, 600, 2, 4), (1000, 62, 64, 2, 4),
+                                           (150, 10, 300, 2, 13), (200, 10, 32, 2, 70)])
+def test_message_function_matches_oracle(rnn, E, I, H, depth, K):
     """rnn.GRU / rnn.LSTM forward + backward vs the padded-order oracle on random predecessor tables."""
     from ggpm_amd import rnn as R
     from ggpm_amd.params import rnn_param_shapes, seeded_state_dict
     from oracle import ref_encoder as ref
     rs = np.random.RandomState(E + I + H + depth)
-    x, bgraph = _random_level(rs, E, I)
+    x, bgraph = _random_level(rs, E, I, K)   # K > 12 / > 64 exercise the chunked list walk
     sd = seeded_state_dict(rnn_param_shapes(rnn, I, H), seed=E + H)
     mod = (R.GRU if rnn == "GRU" else R.LSTM)(I, H, depth).to(_dev())
     mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
