@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: molecule sharding + flat-gradient all-reduce (ggpm_amd/parallel.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ggpm_amd.parallel import FlatGradSync, broadcast_parameters, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+def _data(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.randn(4, 6, generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _model(seed=rank)                 # different init per rank ...
+    broadcast_parameters(model, src=0)        # ... replicated from rank 0
+    sync = FlatGradSync(model.parameters())
+    out = []
+    for step in range(2):
+        mine = shard_indices(4, rank, world)  # batches 0..3 round-robin
+        sync.zero_grad()
+        for b in mine[step::2]:
+            model(_data(b)).pow(2).mean().backward()
+        sync.check_views()
+        sync.all_reduce()
+        out.append(sync.flat.clone())
+    q.put((rank, [o.numpy() for o in out], [p.detach().numpy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_partition():
+    parts = [shard_indices(10, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(10))
+    assert parts[1] == [1, 5, 9]
+
+
+def test_flat_grad_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # replicated parameters and identical reduced gradients on both ranks
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a == b).all()
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a == b).all()
+    # equals the single-process mean over the two ranks' batches
+    ref = _model(seed=0)
+    for step in range(2):
+        grads = []
+        for rank in range(world):
+            ref.zero_grad()
+            for bidx in shard_indices(4, rank, world)[step::2]:
+                ref(_data(bidx)).pow(2).mean().backward()
+            grads.append(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]))
+        mean = (grads[0] + grads[1]) / 2
+        assert torch.allclose(torch.from_numpy(res[0][1][step]), mean, atol=1e-7)
