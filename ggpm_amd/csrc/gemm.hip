@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;   // LDT: padded LDS row (floats), 16B multiple
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 68;   // LDT: padded LDS row (floats), 16B multiple
 
 struct GemmArgs {
     int M, N, K;
@@ -35,44 +35,57 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-// Load a BKx64 operand tile into LDS (k-major).  CONTIG_K: global element (row r, k) at P[r*ld + k]
-// (k contiguous) else at P[k*ld + r] (row contiguous).
+// One BK x 64 operand tile = 512 float4 = 2 per thread.  CONTIG_K: global element (row r, k) at
+// P[r*ld + k] (k contiguous) else at P[k*ld + r] (row contiguous).  fetch: global -> registers (issued
+// one k-step ahead so the loads fly under the MFMAs); stash: registers -> LDS (k-major).
 template <bool CONTIG_K>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend,
-                                          bool vec, float (*T)[LDT]) {
-    const int t = threadIdx.x;
-    if (CONTIG_K) {
-        const int r = t >> 2, kq = (t & 3) * 4;
-        const int gr = r0 + r, gk = k0 + kq;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gr < R) {
-            const float* src = P + (size_t)gr * ld + gk;
-            if (vec && gk + 3 < kend) {
-                float4 x = ggpm_ld4(src);
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            } else {
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int ld, int r0, int R, int k0, int kend,
+                                           bool vec, float4 (&v)[2]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (gk + i < kend) v[i] = src[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) T[kq + i][r] = v[i];
-    } else {
-        const int k = t >> 4, rq = (t & 15) * 4;
-        const int gk = k0 + k, gr = r0 + rq;
+    for (int i = 0; i < 2; ++i) {
+        const int f = threadIdx.x + 256 * i;
         float4 x = ggpm_zero4();
-        if (gk < kend) {
-            const float* src = P + (size_t)gk * ld + gr;
-            if (vec && gr + 3 < R) {
-                x = ggpm_ld4(src);
-            } else {
-                if (gr + 0 < R) x.x = src[0];
-                if (gr + 1 < R) x.y = src[1];
-                if (gr + 2 < R) x.z = src[2];
-                if (gr + 3 < R) x.w = src[3];
+        if (CONTIG_K) {
+            const int gr = r0 + (f >> 3), gk = k0 + (f & 7) * 4;
+            if (gr < R && gk < kend) {
+                const float* src = P + (size_t)gr * ld + gk;
+                if (vec && gk + 3 < kend) x = ggpm_ld4(src);
+                else {
+                    x.x = src[0];
+                    if (gk + 1 < kend) x.y = src[1];
+                    if (gk + 2 < kend) x.z = src[2];
+                    if (gk + 3 < kend) x.w = src[3];
+                }
+            }
+        } else {
+            const int gk = k0 + (f >> 4), gr = r0 + (f & 15) * 4;
+            if (gk < kend && gr < R) {
+                const float* src = P + (size_t)gk * ld + gr;
+                if (vec && gr + 3 < R) x = ggpm_ld4(src);
+                else {
+                    x.x = src[0];
+                    if (gr + 1 < R) x.y = src[1];
+                    if (gr + 2 < R) x.z = src[2];
+                    if (gr + 3 < R) x.w = src[3];
+                }
             }
         }
-        *reinterpret_cast<float4*>(&T[k][rq]) = x;
+        v[i] = x;
+    }
+}
+
+template <bool CONTIG_K>
+__device__ __forceinline__ void stash_tile(const float4 (&v)[2], float (*T)[LDT]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = threadIdx.x + 256 * i;
+        if (CONTIG_K) {
+            const int r = f >> 3, kq = (f & 7) * 4;
+            T[kq + 0][r] = v[i].x; T[kq + 1][r] = v[i].y; T[kq + 2][r] = v[i].z; T[kq + 3][r] = v[i].w;
+        } else {
+            const int k = f >> 4, rq = (f & 15) * 4;
+            *reinterpret_cast<float4*>(&T[k][rq]) = v[i];
+        }
     }
 }
 
@@ -91,10 +104,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     if (n0 < g.N) {
+        float4 ra[2], rb[2];
+        fetch_tile<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA != 0, ra);
+        fetch_tile<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB != 0, rb);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            load_tile<!TA>(g.A, g.lda, m0, g.M, k0, kend, g.vecA != 0, As);
-            load_tile<TB>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB != 0, Bs);
+            stash_tile<!TA>(ra, As);
+            stash_tile<TB>(rb, Bs);
             __syncthreads();
+            if (k0 + BK < kend) {       // next k-step's operands fly under this step's MFMAs
+                fetch_tile<!TA>(g.A, g.lda, m0, g.M, k0 + BK, kend, g.vecA != 0, ra);
+                fetch_tile<TB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB != 0, rb);
+            }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -153,25 +173,36 @@ inline int choose_splits(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-constexpr int CS_ROWS = 64;   // row chunks of the column-sum first stage
+constexpr int CS_ROWS = 256;   // row chunks of the column-sum first stage
 
-__global__ void colsum_stage1(const float* __restrict__ A, int lda, int M, int N, float* __restrict__ ws) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 1: block = 64 columns x 4 row lanes; grid (ceil(N/64), CS_ROWS); chunk c sums rows [c*per, (c+1)*per)
+__global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A, int lda, int M, int N,
+                                                     float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     const int chunk = blockIdx.y;
-    if (n >= N) return;
     const int per = (M + CS_ROWS - 1) / CS_ROWS;
     const int lo = chunk * per, hi = min(M, lo + per);
     float v = 0.f;
-    for (int m = lo; m < hi; ++m) v += A[(size_t)m * lda + n];
-    ws[(size_t)chunk * N + n] = v;
+    if (n < N)
+        for (int m = lo + rl; m < hi; m += 4) v += A[(size_t)m * lda + n];
+    red[rl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (rl == 0 && n < N) ws[(size_t)chunk * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void colsum_stage2(const float* __restrict__ ws, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// stage 2: block = 64 columns x 4 chunk lanes; fixed order -> deterministic
+__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ ws, int N, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     float v = 0.f;
-    for (int c = 0; c < CS_ROWS; ++c) v += ws[(size_t)c * N + n];
-    out[n] = v;
+    if (n < N)
+        for (int c = rl; c < CS_ROWS; c += 4) v += ws[(size_t)c * N + n];
+    red[rl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (rl == 0 && n < N) out[n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void act_backward_k(const float* __restrict__ dy, const float* __restrict__ y, int rows, int cols,
@@ -237,9 +268,9 @@ extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, fl
     GGPM_CLEAR_STALE_ERROR();
     if (!A || !out || !ws || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    dim3 g1(ggpm_ceil_div(N, 256), CS_ROWS);
+    dim3 g1(ggpm_ceil_div(N, 64), CS_ROWS);
     colsum_stage1<<<g1, 256, 0, s>>>(A, lda, M, N, ws);
-    colsum_stage2<<<ggpm_ceil_div(N, 256), 256, 0, s>>>(ws, N, out);
+    colsum_stage2<<<ggpm_ceil_div(N, 64), 256, 0, s>>>(ws, N, out);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

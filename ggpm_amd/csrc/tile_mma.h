@@ -1,105 +1,106 @@
-// Workgroup-level "16 message rows x Hp features" tile algebra shared by the fused GRU / LSTM
-// depth-step kernels.
+// Workgroup-level "message rows x feature columns" tile algebra shared by the GRU / LSTM depth-step kernels.
 //
-// Geometry (gfx950, wave64): a workgroup of 4 waves owns R = 16 consecutive message rows for ALL
-// Hp feature columns.  Activations live in LDS tiles [16][LD] (LD = Hp + 4 floats); weights are read
-// straight from L2 in a pre-packed fragment order (each wave-instruction = one contiguous 1 KiB).
-// The contraction runs on v_mfma_f32_16x16x4_f32 with the WEIGHT as the A operand and the
-// activation tile as the B operand:
-//      D[i][j] += sum_kk  W[out = 16*t + i][k]  *  X[row j][k]
-// so that lane l ends up holding 4 consecutive output features (16*t + 4*(l>>4) + 0..3) of message
-// row (l & 15): a float4 that lines up with the row-major feature matrices for the fused epilogues.
+// Geometry (gfx950, wave64).  A workgroup owns RT*16 consecutive message rows and a COLUMN GROUP of TG
+// adjacent 16-wide output tiles (one tile per wave).  The grid is (row tiles) x (column groups) with TG chosen
+// per level so that even the small motif/attachment levels (a few hundred messages) spread over all 256 CUs
+// while the big atom level keeps the redundant full-row gathers at 2x.  Activations (the contraction operand, full K = Hp wide) sit in LDS tiles
+// [RT*16][LD] (LD = Hp + 4 floats); weights are streamed straight from L2 in a pre-packed fragment order
+// (one wave instruction = one contiguous 1 KiB) through a PF-deep register prefetch ring.
 //
-// k order inside a 16-wide chunk: MFMA step s (0..3) takes k = 16*kc + 4*(l>>4) + s from BOTH
-// operands (each lane loads one float4 per chunk per operand); the MFMA sums over the four lane
-// groups, so all 16 k of the chunk are covered after 4 steps.  MFMA f32 is an exact fmaf chain, so the
-// summation order is fixed and results are run-to-run bitwise identical.
+// The contraction runs on v_mfma_f32_16x16x4_f32 with the WEIGHT as the A operand and the activation
+// tile as the B operand:   D[i][j] += sum_kk W[out = 16*t + i][k] * X[row j][k]
+// so lane l ends up holding 4 consecutive output features (16*t + 4*(l>>4) + 0..3) of message row (l & 15):
+// a float4 that lines up with the row-major feature matrices for the fused epilogues.
+// k order inside a 16-wide chunk: MFMA step s (0..3) takes k = 16*kc + 4*(l>>4) + s from BOTH operands (one
+// float4 per lane per chunk per operand).  MFMA f32 is an exact fmaf chain: the summation order is fixed by
+// this code, so results are run-to-run bitwise identical.
 #pragma once
 #include "common.h"
+
+constexpr int GGPM_NW = 4;        // waves per workgroup of the "B" kernels (one output tile per wave)
+constexpr int GGPM_NWA = 16;      // waves per workgroup of the "A" kernels: all 16 gather, the first TG own a tile
+constexpr int GGPM_PF = 4;        // weight-fragment prefetch depth (k chunks)
 
 // Packed weight tile order: [out tile t][k chunk kc][lane 0..63][4 floats].
 __device__ __forceinline__ size_t ggpm_pack_index(int t, int kc, int KC, int lane) {
     return (((size_t)t * KC + kc) * 64 + lane) * 4;
 }
 
-// Branch-free inner product for the N tiles a wave owns (t = wave + NW*i, all valid).
-//   acc[i] += Wp(tile t) x tile^T  over KC chunks of 16 k.
-// The weight fragments are software-prefetched PF chunks ahead through a register ring so that enough
-// bytes are in flight per CU to stream the packed weights from L2 at the rate the MFMAs consume them
-// (16 rows per workgroup = 8 FLOP per weight byte); the prefetch index is clamped instead of branched, so
-// the loop body is straight-line: PF*N global_load_dwordx4 + 1 ds_read_b128 + 4*N MFMAs.
-template <int N, int NW, int PF>
-__device__ __forceinline__ void ggpm_tile_gemm_n(const float* __restrict__ tile, int LD,
-                                                 const float* __restrict__ Wp, int KC, int wave, int lane,
-                                                 f32x4* __restrict__ acc) {
-    const float* brow = tile + (lane & 15) * LD + 4 * (lane >> 4);
-    const float* wp[N];
+// acc[op][r] += Wp[op](tile t) x tile[op](row tile r)^T   for NOPS independent products sharing the k loop
+// (e.g. the z and m gates of a GRU step).  Straight-line body: NOPS refill loads + NOPS*RT ds_read_b128 +
+// 4*NOPS*RT MFMAs per k chunk; the refill index is clamped instead of branched.
+template <int NOPS, int RT>
+__device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS], int LD,
+                                               const float* const (&wps)[NOPS], int KC, int t, int lane,
+                                               f32x4 (&acc)[NOPS][RT]) {
+    constexpr int PF = GGPM_PF;
+    const int boff = (lane & 15) * LD + 4 * (lane >> 4);
+    const float* wp[NOPS];
 #pragma unroll
-    for (int i = 0; i < N; ++i) wp[i] = Wp + ggpm_pack_index(wave + NW * i, 0, KC, lane);
-    f32x4 ring[PF][N];
+    for (int o = 0; o < NOPS; ++o) wp[o] = wps[o] + ggpm_pack_index(t, 0, KC, lane);
+    f32x4 ring[PF][NOPS];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int kk = min(d, KC - 1);
 #pragma unroll
-        for (int i = 0; i < N; ++i) ring[d][i] = *reinterpret_cast<const f32x4*>(wp[i] + (size_t)kk * 256);
+        for (int o = 0; o < NOPS; ++o) ring[d][o] = *reinterpret_cast<const f32x4*>(wp[o] + (size_t)kk * 256);
     }
     int kc = 0;
     for (; kc + PF <= KC; kc += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(brow + (kc + d) * 16);
-            f32x4 a[N];
+            f32x4 a[NOPS], b[NOPS][RT];
 #pragma unroll
-            for (int i = 0; i < N; ++i) a[i] = ring[d][i];
+            for (int o = 0; o < NOPS; ++o) {
+                a[o] = ring[d][o];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    b[o][r] = *reinterpret_cast<const f32x4*>(tiles[o] + r * 16 * LD + boff + (kc + d) * 16);
+            }
             const int kn = min(kc + d + PF, KC - 1);
 #pragma unroll
-            for (int i = 0; i < N; ++i) ring[d][i] = *reinterpret_cast<const f32x4*>(wp[i] + (size_t)kn * 256);
+            for (int o = 0; o < NOPS; ++o) ring[d][o] = *reinterpret_cast<const f32x4*>(wp[o] + (size_t)kn * 256);
             __builtin_amdgcn_sched_barrier(0);   // keep the refill loads HERE (PF chunks ahead of their use)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i], 0, 0, 0);
-            }
+                for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[o][s], b[o][r][s], acc[o][r], 0, 0, 0);
         }
     }
     // remainder (KC % PF chunks): their fragments already sit in ring[0 .. rem)
 #pragma unroll
     for (int d = 0; d < PF - 1; ++d) {
         if (kc + d < KC) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(brow + (kc + d) * 16);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int o = 0; o < NOPS; ++o)
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[d][i][s], b[s], acc[i], 0, 0, 0);
-            }
+                for (int r = 0; r < RT; ++r) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tiles[o] + r * 16 * LD + boff + (kc + d) * 16);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[d][o][s], b[s], acc[o][r], 0, 0, 0);
+                }
         }
     }
 }
 
-// Number of output tiles (16 columns each) wave `wave` of NW owns out of NT.
-template <int NW>
-__device__ __forceinline__ int ggpm_tiles_of_wave(int NT, int wave) {
-    return wave < NT ? (NT - wave + NW - 1) / NW : 0;
+template <int NOPS, int RT>
+__device__ __forceinline__ void ggpm_zero_acc(f32x4 (&acc)[NOPS][RT]) {
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[o][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// Dispatch on the (wave-uniform) tile count so that every instantiation is branch-free.
-template <int TPW, int NW>
-__device__ __forceinline__ void ggpm_tile_gemm(const float* __restrict__ tile, int LD,
-                                               const float* __restrict__ Wp, int KC, int NT, int wave,
-                                               int lane, f32x4 (&acc)[TPW]) {
-    constexpr int PF = 4;
-    const int n = ggpm_tiles_of_wave<NW>(NT, wave);
-    if (n == 1) ggpm_tile_gemm_n<1, NW, PF>(tile, LD, Wp, KC, wave, lane, acc);
-    if constexpr (TPW >= 2) { if (n == 2) ggpm_tile_gemm_n<2, NW, PF>(tile, LD, Wp, KC, wave, lane, acc); }
-    if constexpr (TPW >= 3) { if (n == 3) ggpm_tile_gemm_n<3, NW, PF>(tile, LD, Wp, KC, wave, lane, acc); }
-}
+__device__ __forceinline__ float4 ggpm_f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // ---- CSR row walk helpers for the gather phases -------------------------------------------------------
-// One wave owns one destination row.  The row's list is loaded ONCE, coalesced (lane j holds entry j), and
+// One wave walks one destination row.  The row's list is loaded ONCE, coalesced (lane j holds entry j), and
 // entries are then broadcast with v_readlane; slots past the end read index 0, the all-zero pad row of
-// the reference layout, so the 4-way unrolled gather needs no branches and all its loads are independent.
+// the reference layout, so unrolled gathers need no branches and all their loads are independent.
 struct GgpmRowList { int lo, n; };
 
 __device__ __forceinline__ GgpmRowList ggpm_row_list(const int32_t* __restrict__ rowptr, int row, int rows) {
@@ -120,16 +121,33 @@ __device__ __forceinline__ int ggpm_list_at(int chunk, int j, int m) {
     return (j < m) ? __builtin_amdgcn_readlane(chunk, j) : 0;
 }
 
-template <int TPW>
-__device__ __forceinline__ void ggpm_zero_acc(f32x4 (&acc)[TPW]) {
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+// Copy ROWS full feature rows [r0, r0+ROWS) of a [rows][Hp] matrix into an LDS tile [ROWS][LD]
+// (rows past the end are zero filled).  All NW waves take part; 16 B per lane, coalesced.
+template <int ROWS>
+__device__ __forceinline__ void ggpm_load_rows_to_lds(const float* __restrict__ src, int r0, int rows, int Hp,
+                                                      int LD, float* __restrict__ tile) {
+    const int q = Hp >> 2;    // float4 per row
+    for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
+        const int lr = it / q, c = (it - lr * q) * 4;
+        const int row = r0 + lr;
+        const float4 v = row < rows ? ggpm_ld4(src + (size_t)row * Hp + c) : ggpm_zero4();
+        ggpm_st4(tile + lr * LD + c, v);
+    }
 }
-
-__device__ __forceinline__ float4 ggpm_f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // Pack W (or W^T) into fragment order, zero padded to Hp x Hp.
 //   src(out, k) = transpose ? W[k*ldw + out] : W[out*ldw + k]     for out, k < H
 __global__ void ggpm_pack_weight_kernel(const float* __restrict__ W, int ldw, int H, int Hp, int transpose,
                                         float* __restrict__ dst);
 void ggpm_launch_pack(const float* W, int ldw, int H, int Hp, int transpose, float* dst, hipStream_t s);
+// Output tiles per column group of the A kernels for a level of E1 messages and NT = Hp/16 tiles: as few
+// groups as still give >= ~256 workgroups (every group repeats the full-row gather), 4..16 tiles each.
+static inline int ggpm_tiles_per_group(int E1, int NT) {
+    const int row_tiles = (E1 + 15) / 16;
+    int groups = (256 + row_tiles - 1) / row_tiles;
+    if (groups < 1) groups = 1;
+    int tg = (NT + groups - 1) / groups;
+    if (tg < 4) tg = 4;
+    if (tg > GGPM_NWA) tg = GGPM_NWA;
+    return tg;
+}

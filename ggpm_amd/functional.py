@@ -114,7 +114,7 @@ def gemm(ta: int, tb: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B:
 
 def colsum(A: torch.Tensor, M: int, N: int) -> torch.Tensor:
     out = torch.empty(N, dtype=torch.float32, device=A.device)
-    ws = torch.empty(64 * N, dtype=torch.float32, device=A.device)
+    ws = torch.empty(256 * N, dtype=torch.float32, device=A.device)
     _lib.check(_lib.load().ggpm_colsum(_p(A), _ld(A), M, N, _p(out), _p(ws), _stream()), "colsum")
     return out
 
@@ -309,27 +309,27 @@ class _GruMessages(torch.autograd.Function):
         if save:
             Hs = torch.empty(depth + 1, E1, Hp, **f32)
             Qs = torch.empty(depth, E1, Hp, **f32)
-            St = torch.empty(4, depth, E1, Hp, **f32)
-            Ss, Gs, Zs, Ms = St[0], St[1], St[2], St[3]
+            St = torch.empty(5, depth, E1, Hp, **f32)
+            Ss, Gs, Zs, Ms, Rs = St[0], St[1], St[2], St[3], St[4]
         else:
             Hs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
-            Ss = Gs = Zs = Ms = None
+            Ss = Gs = Zs = Ms = Rs = None
         _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(Xz), _p(Xr), _p(Xh), _p(Wz_h), Wz_h.stride(0), _p(Ur),
                                         Ur.stride(0), _p(bu), _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col),
-                                        _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(wpack), int(save),
-                                        _stream()), "gru_forward")
+                                        _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack),
+                                        int(save), _stream()), "gru_forward")
         out = Hs[depth] if save else Hs[depth & 1]
         if save:
             ctx.save_for_backward(Xr, Wz_h, Ur, Wh_h)
-            ctx.stash = (Hs, Qs, Ss, Gs, Zs, Ms)
+            ctx.stash = (Hs, Qs, Ss, Gs, Zs, Ms, Rs)
             ctx.pred, ctx.depth, ctx.H = pred, depth, H
         return out
 
     @staticmethod
     def backward(ctx, dHD):
         Xr, Wz_h, Ur, Wh_h = ctx.saved_tensors
-        Hs, Qs, Ss, Gs, Zs, Ms = ctx.stash
+        Hs, Qs, Ss, Gs, Zs, Ms, Rs = ctx.stash
         lib = _lib.load()
         H, depth, pred = ctx.H, ctx.depth, ctx.pred
         E1, Hp = Xr.shape[0], padded_hidden(H)
@@ -346,7 +346,7 @@ class _GruMessages(torch.autograd.Function):
         work = torch.empty((wb + 3) // 4, **f32)
         _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), Wz_h.stride(0), _p(Ur), Ur.stride(0),
                                          _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
-                                         _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(dHD),
+                                         _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(dHD),
                                          _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz), H, _p(dUr), H, _p(dbu), _p(dWh), H,
                                          _p(work), work.numel() * 4, _stream()), "gru_backward")
         ctx.stash = None
@@ -373,21 +373,21 @@ class _LstmMessages(torch.autograd.Function):
             Hs = torch.empty(depth + 1, E1, Hp, **f32)
             Cs = torch.empty(depth + 1, E1, Hp, **f32)
             Qs = torch.empty(depth, E1, Hp, **f32)
-            St = torch.empty(4, depth, E1, Hp, **f32)
-            Ss, Is, Os, Us = St[0], St[1], St[2], St[3]
+            St = torch.empty(5, depth, E1, Hp, **f32)
+            Ss, Is, Os, Us, Fs = St[0], St[1], St[2], St[3], St[4]
         else:
             Hs = torch.empty(2, E1, Hp, **f32)
             Cs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
-            Ss = Is = Os = Us = None
+            Ss = Is = Os = Us = Fs = None
         _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(Xi), _p(Xo), _p(Xu), _p(Xf), _p(Wi_h), Wi_h.stride(0),
                                          _p(Wo_h), Wo_h.stride(0), _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0),
                                          _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os),
-                                         _p(Us), _p(wpack), int(save), _stream()), "lstm_forward")
+                                         _p(Us), _p(Fs), _p(wpack), int(save), _stream()), "lstm_forward")
         k = depth if save else depth & 1
         if save:
             ctx.save_for_backward(Xf, Wi_h, Wo_h, Wu_h, Wf_h)
-            ctx.stash = (Hs, Cs, Qs, Ss, Is, Os, Us)
+            ctx.stash = (Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
             ctx.pred, ctx.depth, ctx.H = pred, depth, H
         c_out = Cs[k]
         ctx.mark_non_differentiable(c_out)
@@ -396,7 +396,7 @@ class _LstmMessages(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dHD, _dC):
         Xf, Wi_h, Wo_h, Wu_h, Wf_h = ctx.saved_tensors
-        Hs, Cs, Qs, Ss, Is, Os, Us = ctx.stash
+        Hs, Cs, Qs, Ss, Is, Os, Us, Fs = ctx.stash
         lib = _lib.load()
         H, depth, pred = ctx.H, ctx.depth, ctx.pred
         E1, Hp = Xf.shape[0], padded_hidden(H)
@@ -410,7 +410,7 @@ class _LstmMessages(torch.autograd.Function):
         _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wi_h), Wi_h.stride(0), _p(Wo_h), Wo_h.stride(0),
                                           _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0), _p(pred.rowptr),
                                           _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
-                                          _p(Is), _p(Os), _p(Us), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dX[3]),
+                                          _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dX[3]),
                                           _p(dW[0]), H, _p(dW[1]), H, _p(dW[2]), H, _p(dW[3]), H, _p(work),
                                           work.numel() * 4, _stream()), "lstm_backward")
         ctx.stash = None

@@ -78,7 +78,7 @@ size_t ggpm_gemm_workspace_bytes(int M, int N, int K);
 int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
               int ldb, float* C, int ldc, int n_pad, const float* bias, int accumulate, int act,
               int zero_row0, float* splitk_ws, size_t splitk_ws_bytes, ggpm_stream_t stream);
-/* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 64*N floats. */
+/* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 256*N floats. */
 int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream);
 /* dpre = dy * act'(y) given the activation OUTPUT y; optional row-0 zeroing. In-place allowed. */
 int ggpm_act_backward(const float* dy, const float* y, int rows, int cols, int ld, int act,
@@ -110,17 +110,19 @@ int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1,
  * are computed once by ggpm_gemm; per depth
  *     s_e = sum_p h_p,  g_e = sum_p sigmoid(Xr_e + q_p) * h_p,   q_p = U_r h_p + b_u,
  *     z = sigmoid(Xz + Wz_h s), m = tanh(Xh + Wh_h g), h' = (1-z) s + z m, row 0 := 0.
- * One fused kernel per depth: CSR gather -> LDS tiles -> MFMA gate GEMMs -> gate math -> MFMA q' GEMM.
- * Stash layout ([t] = depth slot): Hs[depth+1][E1][Hp] (Hs[0]=0, Hs[depth] = result), Qs/Ss/Gs/Zs/Ms
- * [depth][E1][Hp].  With save_for_backward = 0 only Hs[2][E1][Hp] and Qs[2][E1][Hp] are needed and the
- * result is Hs[depth & 1].   wpack: ggpm_gru_pack_floats(H) floats of scratch.
+ * Two launches per depth over a (row tiles) x (column groups) grid: A = CSR gather -> LDS tiles -> MFMA gate
+ * GEMMs -> gate math -> h'; B = MFMA q' GEMM from the h' rows.
+ * Stash layout ([t] = depth slot): Hs[depth+1][E1][Hp] (Hs[0]=0, Hs[depth] = result), Qs/Ss/Gs/Zs/Ms/Rs
+ * [depth][E1][Hp] (Rs = sum_p h_p r(1-r), which lets the backward form dXr without a gather).  With
+ * save_for_backward = 0 only Hs[2][E1][Hp] and Qs[2][E1][Hp] are needed and the result is Hs[depth & 1].
+ * wpack: ggpm_gru_pack_floats(H) floats of scratch.
  */
 size_t ggpm_gru_pack_floats(int H);
 int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
                      const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
                      const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
-                     float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* wpack,
-                     int save_for_backward, ggpm_stream_t stream);
+                     float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs,
+                     float* wpack, int save_for_backward, ggpm_stream_t stream);
 /* Backward of the above (replaces autograd's replay of ggpm/rnn.py:41-50): given dHD = dL/dh_D it
  * overwrites dXz/dXr/dXh [E1][Hp] and the weight gradients (written as [H,H] blocks with the given
  * leading dimension so they can land inside the full W_z/W_h gradient tensors), dbu[H].
@@ -130,7 +132,7 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
                       const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
                       const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* succ_rowptr,
                       const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss,
-                      const float* Gs, const float* Zs, const float* Ms, const float* dHD, float* dXz,
+                      const float* Gs, const float* Zs, const float* Ms, const float* Rs, const float* dHD, float* dXz,
                       float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
                       float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
                       ggpm_stream_t stream);
@@ -141,14 +143,14 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
  *     s = sum_p h_p,  fc = sum_p sigmoid(Xf_e + qf_p) * c_p,
  *     i = sigmoid(Xi + Wi_h s), o = sigmoid(Xo + Wo_h s), u = tanh(Xu + Wu_h s),
  *     c' = i u + fc,  h' = o tanh(c'),  rows 0 := 0.
- * Stash: Hs, Cs [depth+1][E1][Hp]; Qs (qf), Ss, Is, Os, Us [depth][E1][Hp].
+ * Stash: Hs, Cs [depth+1][E1][Hp]; Qs (qf), Ss, Is, Os, Us, Fs [depth][E1][Hp] (Fs = sum_p c_p f(1-f)).
  */
 size_t ggpm_lstm_pack_floats(int H);
 int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, const float* Xo, const float* Xu,
                       const float* Xf, const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
                       const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
                       const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
-                      float* Qs, float* Ss, float* Is, float* Os, float* Us, float* wpack,
+                      float* Qs, float* Ss, float* Is, float* Os, float* Us, float* Fs, float* wpack,
                       int save_for_backward, ggpm_stream_t stream);
 size_t ggpm_lstm_backward_workspace_bytes(int E1, int H, int depth);
 int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
@@ -156,8 +158,8 @@ int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* W
                        int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col,
                        const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
                        const float* Cs, const float* Qs, const float* Ss, const float* Is,
-                       const float* Os, const float* Us, const float* dHD, float* dXi, float* dXo,
-                       float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                       const float* Os, const float* Us, const float* Fs, const float* dHD, float* dXi,
+                       float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                        float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
                        size_t work_bytes, ggpm_stream_t stream);
 
