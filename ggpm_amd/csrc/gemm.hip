@@ -173,7 +173,7 @@ inline int choose_splits(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-constexpr int CS_ROWS = 256;   // row chunks of the column-sum first stage
+constexpr int CS_ROWS = 256;   // max row chunks of the column-sum first stage (workspace = 256*N floats)
 
 // stage 1: block = 64 columns x 4 row lanes; grid (ceil(N/64), CS_ROWS); chunk c sums rows [c*per, (c+1)*per)
 __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A, int lda, int M, int N,
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     const int chunk = blockIdx.y;
-    const int per = (M + CS_ROWS - 1) / CS_ROWS;
+    const int per = (M + gridDim.y - 1) / gridDim.y;
     const int lo = chunk * per, hi = min(M, lo + per);
     float v = 0.f;
     if (n < N)
@@ -193,13 +193,14 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A
 }
 
 // stage 2: block = 64 columns x 4 chunk lanes; fixed order -> deterministic
-__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ ws, int N, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ ws, int N, int chunks,
+                                                     float* __restrict__ out) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     float v = 0.f;
     if (n < N)
-        for (int c = rl; c < CS_ROWS; c += 4) v += ws[(size_t)c * N + n];
+        for (int c = rl; c < chunks; c += 4) v += ws[(size_t)c * N + n];
     red[rl][threadIdx.x & 63] = v;
     __syncthreads();
     if (rl == 0 && n < N) out[n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -268,9 +269,11 @@ extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, fl
     GGPM_CLEAR_STALE_ERROR();
     if (!A || !out || !ws || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    dim3 g1(ggpm_ceil_div(N, 64), CS_ROWS);
+    int chunks = ggpm_ceil_div(M, 128);          // >= 128 rows per chunk, at most CS_ROWS chunks
+    if (chunks > CS_ROWS) chunks = CS_ROWS;
+    dim3 g1(ggpm_ceil_div(N, 64), chunks);
     colsum_stage1<<<g1, 256, 0, s>>>(A, lda, M, N, ws);
-    colsum_stage2<<<ggpm_ceil_div(N, 64), 256, 0, s>>>(ws, N, out);
+    colsum_stage2<<<ggpm_ceil_div(N, 64), 256, 0, s>>>(ws, N, chunks, out);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

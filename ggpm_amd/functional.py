@@ -293,18 +293,33 @@ def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_t
     return hnode, hmess
 
 
-class _GruMessages(torch.autograd.Function):
-    """GRU.forward over CSR predecessors (ggpm/rnn.py:41-50): returns h_D [E1, Hp]."""
+def _split_cols(W: torch.Tensor, I: int):
+    """(x-half view, h-half view) of a [H, I+H] gate weight; both share W's row stride."""
+    return W[:, :I], W[:, I:]
+
+
+class _GruLevel(torch.autograd.Function):
+    """GRU.forward (ggpm/rnn.py:41-50) for one level: hoisted input GEMMs + fused depth loop.
+
+    One autograd node per level: the backward writes the x-half and the h-half gradient of every gate weight
+    straight into ONE full-shape gradient tensor (no slice/cat/add kernels from autograd).
+    Returns h_D as [E1, Hp] (pad columns zero).
+    """
 
     @staticmethod
-    def forward(ctx, Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred, depth, H):
-        _need_gpu(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h)
+    def forward(ctx, x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H):
+        _need_gpu(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h)
         lib = _lib.load()
-        E1, Hp = Xz.shape[0], padded_hidden(H)
-        assert _ld(Xz) == Hp and _ld(Xr) == Hp and _ld(Xh) == Hp
-        dev = Xz.device
+        E1, Hp = x.shape[0], padded_hidden(H)
+        f32 = dict(dtype=torch.float32, device=x.device)
         save = any(ctx.needs_input_grad)
-        f32 = dict(dtype=torch.float32, device=dev)
+        X = torch.empty(3, E1, Hp, **f32)
+        Wz_x, Wz_h = _split_cols(W_z, I)
+        Wh_x, Wh_h = _split_cols(W_h, I)
+        ldx = _ld(x)
+        gemm(0, 1, E1, H, I, x, ldx, Wz_x, W_z.stride(0), X[0], Hp, Hp, bias=b_z)
+        gemm(0, 1, E1, H, I, x, ldx, W_r, W_r.stride(0), X[1], Hp, Hp)
+        gemm(0, 1, E1, H, I, x, ldx, Wh_x, W_h.stride(0), X[2], Hp, Hp, bias=b_h)
         wpack = torch.empty(int(lib.ggpm_gru_pack_floats(H)), **f32)
         if save:
             Hs = torch.empty(depth + 1, E1, Hp, **f32)
@@ -315,59 +330,79 @@ class _GruMessages(torch.autograd.Function):
             Hs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
             Ss = Gs = Zs = Ms = Rs = None
-        _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(Xz), _p(Xr), _p(Xh), _p(Wz_h), Wz_h.stride(0), _p(Ur),
-                                        Ur.stride(0), _p(bu), _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col),
+        _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0), _p(U_r),
+                                        U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col),
                                         _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack),
                                         int(save), _stream()), "gru_forward")
-        out = Hs[depth] if save else Hs[depth & 1]
         if save:
-            ctx.save_for_backward(Xr, Wz_h, Ur, Wh_h)
-            ctx.stash = (Hs, Qs, Ss, Gs, Zs, Ms, Rs)
-            ctx.pred, ctx.depth, ctx.H = pred, depth, H
-        return out
+            ctx.save_for_backward(x, W_z, W_r, U_r, W_h)
+            ctx.stash = (X[1], Hs, Qs, Ss, Gs, Zs, Ms, Rs)
+            ctx.meta = (pred, depth, I, H)
+            return Hs[depth]
+        return Hs[depth & 1]
 
     @staticmethod
     def backward(ctx, dHD):
-        Xr, Wz_h, Ur, Wh_h = ctx.saved_tensors
-        Hs, Qs, Ss, Gs, Zs, Ms, Rs = ctx.stash
+        x, W_z, W_r, U_r, W_h = ctx.saved_tensors
+        Xr, Hs, Qs, Ss, Gs, Zs, Ms, Rs = ctx.stash
+        pred, depth, I, H = ctx.meta
         lib = _lib.load()
-        H, depth, pred = ctx.H, ctx.depth, ctx.pred
-        E1, Hp = Xr.shape[0], padded_hidden(H)
+        E1, Hp = x.shape[0], padded_hidden(H)
         succ = pred.T
         dHD = dHD.contiguous()
-        assert dHD.shape == (E1, Hp)
-        f32 = dict(dtype=torch.float32, device=Xr.device)
+        f32 = dict(dtype=torch.float32, device=x.device)
         dX = torch.empty(3, E1, Hp, **f32)
-        dWz = torch.empty(H, H, **f32)
-        dUr = torch.empty(H, H, **f32)
-        dWh = torch.empty(H, H, **f32)
-        dbu = torch.empty(H, **f32)
+        dW_z, dW_r, dU_r, dW_h = (torch.empty(W_z.shape, **f32), torch.empty(W_r.shape, **f32),
+                                  torch.empty(H, H, **f32), torch.empty(W_h.shape, **f32))
+        db_u = torch.empty(H, **f32)
+        Wz_x, Wz_h = _split_cols(W_z, I)
+        Wh_x, Wh_h = _split_cols(W_h, I)
+        dWz_x, dWz_h = _split_cols(dW_z, I)
+        dWh_x, dWh_h = _split_cols(dW_h, I)
         wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
-        _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), Wz_h.stride(0), _p(Ur), Ur.stride(0),
-                                         _p(Wh_h), Wh_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
+        _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
+                                         _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
                                          _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(dHD),
-                                         _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz), H, _p(dUr), H, _p(dbu), _p(dWh), H,
-                                         _p(work), work.numel() * 4, _stream()), "gru_backward")
+                                         _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0), _p(dU_r), H,
+                                         _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4, _stream()),
+                   "gru_backward")
         ctx.stash = None
-        return dX[0], dX[1], dX[2], dWz, dUr, dbu, dWh, None, None, None
+        ldx = _ld(x)
+        # x-halves of the gate weights and the gate biases
+        gemm(1, 0, H, I, E1, dX[0], Hp, x, ldx, dWz_x, dW_z.stride(0), I, splitk=True)
+        gemm(1, 0, H, I, E1, dX[1], Hp, x, ldx, dW_r, dW_r.stride(0), I, splitk=True)
+        gemm(1, 0, H, I, E1, dX[2], Hp, x, ldx, dWh_x, dW_h.stride(0), I, splitk=True)
+        db_z = colsum(dX[0], E1, H)
+        db_h = colsum(dX[2], E1, H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(0, 0, E1, I, H, dX[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x.shape[1])
+            gemm(0, 0, E1, I, H, dX[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
+            gemm(0, 0, E1, I, H, dX[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
+        return dx, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None, None
 
 
-def gru_messages(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred: CSR, depth: int, H: int) -> torch.Tensor:
-    return _GruMessages.apply(Xz, Xr, Xh, Wz_h, Ur, bu, Wh_h, pred, depth, H)
+def gru_level(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred: CSR, depth: int, I: int, H: int) -> torch.Tensor:
+    return _GruLevel.apply(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H)
 
 
-class _LstmMessages(torch.autograd.Function):
-    """LSTM.forward over CSR predecessors (ggpm/rnn.py:96-108): returns (h_D, c_D), each [E1, Hp]."""
+class _LstmLevel(torch.autograd.Function):
+    """LSTM.forward (ggpm/rnn.py:96-108) for one level; returns (h_D, c_D) as [E1, Hp] tensors."""
 
     @staticmethod
-    def forward(ctx, Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred, depth, H):
-        _need_gpu(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h)
+    def forward(ctx, x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H):
+        _need_gpu(x, W_i, W_o, W_u, W_f)
         lib = _lib.load()
-        E1, Hp = Xi.shape[0], padded_hidden(H)
-        assert _ld(Xi) == Hp and _ld(Xo) == Hp and _ld(Xu) == Hp and _ld(Xf) == Hp
+        E1, Hp = x.shape[0], padded_hidden(H)
+        f32 = dict(dtype=torch.float32, device=x.device)
         save = any(ctx.needs_input_grad)
-        f32 = dict(dtype=torch.float32, device=Xi.device)
+        Ws, bs = (W_i, W_o, W_u, W_f), (b_i, b_o, b_u, b_f)
+        X = torch.empty(4, E1, Hp, **f32)
+        ldx = _ld(x)
+        for k in range(4):
+            gemm(0, 1, E1, H, I, x, ldx, Ws[k][:, :I], Ws[k].stride(0), X[k], Hp, Hp, bias=bs[k])
         wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H)), **f32)
         if save:
             Hs = torch.empty(depth + 1, E1, Hp, **f32)
@@ -380,42 +415,58 @@ class _LstmMessages(torch.autograd.Function):
             Cs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
             Ss = Is = Os = Us = Fs = None
-        _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(Xi), _p(Xo), _p(Xu), _p(Xf), _p(Wi_h), Wi_h.stride(0),
-                                         _p(Wo_h), Wo_h.stride(0), _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0),
+        Wh = [w[:, I:] for w in Ws]
+        _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(X[3]), _p(Wh[0]), W_i.stride(0),
+                                         _p(Wh[1]), W_o.stride(0), _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0),
                                          _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os),
                                          _p(Us), _p(Fs), _p(wpack), int(save), _stream()), "lstm_forward")
         k = depth if save else depth & 1
         if save:
-            ctx.save_for_backward(Xf, Wi_h, Wo_h, Wu_h, Wf_h)
-            ctx.stash = (Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
-            ctx.pred, ctx.depth, ctx.H = pred, depth, H
+            ctx.save_for_backward(x, W_i, W_o, W_u, W_f)
+            ctx.stash = (X[3], Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
+            ctx.meta = (pred, depth, I, H)
         c_out = Cs[k]
         ctx.mark_non_differentiable(c_out)
         return Hs[k], c_out
 
     @staticmethod
     def backward(ctx, dHD, _dC):
-        Xf, Wi_h, Wo_h, Wu_h, Wf_h = ctx.saved_tensors
-        Hs, Cs, Qs, Ss, Is, Os, Us, Fs = ctx.stash
+        x, W_i, W_o, W_u, W_f = ctx.saved_tensors
+        Xf, Hs, Cs, Qs, Ss, Is, Os, Us, Fs = ctx.stash
+        pred, depth, I, H = ctx.meta
         lib = _lib.load()
-        H, depth, pred = ctx.H, ctx.depth, ctx.pred
-        E1, Hp = Xf.shape[0], padded_hidden(H)
+        E1, Hp = x.shape[0], padded_hidden(H)
         succ = pred.T
         dHD = dHD.contiguous()
-        f32 = dict(dtype=torch.float32, device=Xf.device)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        Ws = (W_i, W_o, W_u, W_f)
         dX = torch.empty(4, E1, Hp, **f32)
-        dW = torch.empty(4, H, H, **f32)
+        dWs = [torch.empty(w.shape, **f32) for w in Ws]
+        Wh = [w[:, I:] for w in Ws]
+        dWh = [w[:, I:] for w in dWs]
         wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
-        _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wi_h), Wi_h.stride(0), _p(Wo_h), Wo_h.stride(0),
-                                          _p(Wu_h), Wu_h.stride(0), _p(Wf_h), Wf_h.stride(0), _p(pred.rowptr),
+        _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0),
+                                          _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr),
                                           _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
-                                          _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dX[3]),
-                                          _p(dW[0]), H, _p(dW[1]), H, _p(dW[2]), H, _p(dW[3]), H, _p(work),
+                                          _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]),
+                                          _p(dX[3]), _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
+                                          _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0), _p(work),
                                           work.numel() * 4, _stream()), "lstm_backward")
         ctx.stash = None
-        return dX[0], dX[1], dX[2], dX[3], dW[0], dW[1], dW[2], dW[3], None, None, None
+        ldx = _ld(x)
+        dbs = []
+        for k in range(4):
+            gemm(1, 0, H, I, E1, dX[k], Hp, x, ldx, dWs[k][:, :I], dWs[k].stride(0), I, splitk=True)
+            dbs.append(colsum(dX[k], E1, H))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            for k in range(4):
+                gemm(0, 0, E1, I, H, dX[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx, x.shape[1] if k == 0 else I,
+                     accumulate=k > 0)
+        return (dx, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3], None, None, None, None)
 
 
-def lstm_messages(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred: CSR, depth: int, H: int):
-    return _LstmMessages.apply(Xi, Xo, Xu, Xf, Wi_h, Wo_h, Wu_h, Wf_h, pred, depth, H)
+def lstm_level(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred: CSR, depth: int, I: int, H: int):
+    return _LstmLevel.apply(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H)

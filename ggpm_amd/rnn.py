@@ -43,12 +43,8 @@ class GRU(nn.Module):
         """h_D as a [E+1, Hp] tensor (pad columns zero)."""
         I, H = self.input_size, self.hidden_size
         pred = _as_csr(bgraph, fmess.shape[0])
-        Wz, Wh = self.W_z.weight, self.W_h.weight
-        Xz = F_.linear([fmess], [I], Wz[:, :I], self.W_z.bias)
-        Xr = F_.linear([fmess], [I], self.W_r.weight, None)
-        Xh = F_.linear([fmess], [I], Wh[:, :I], self.W_h.bias)
-        return F_.gru_messages(Xz, Xr, Xh, Wz[:, I:], self.U_r.weight, self.U_r.bias, Wh[:, I:], pred,
-                               self.depth, H)
+        return F_.gru_level(fmess, self.W_z.weight, self.W_z.bias, self.W_r.weight, self.U_r.weight,
+                            self.U_r.bias, self.W_h.weight, self.W_h.bias, pred, self.depth, I, H)
 
     def forward(self, fmess, bgraph):
         return self.forward_padded(fmess, bgraph)[:, :self.hidden_size]
@@ -81,10 +77,9 @@ class LSTM(nn.Module):
     def forward_padded(self, fmess, bgraph):
         I, H = self.input_size, self.hidden_size
         pred = _as_csr(bgraph, fmess.shape[0])
-        lin = [self.W_i[0], self.W_o[0], self.W[0], self.W_f[0]]
-        X = [F_.linear([fmess], [I], l.weight[:, :I], l.bias) for l in lin]
-        Wh = [l.weight[:, I:] for l in lin]
-        return F_.lstm_messages(X[0], X[1], X[2], X[3], Wh[0], Wh[1], Wh[2], Wh[3], pred, self.depth, H)
+        i, o, u, f = self.W_i[0], self.W_o[0], self.W[0], self.W_f[0]
+        return F_.lstm_level(fmess, i.weight, i.bias, o.weight, o.bias, u.weight, u.bias, f.weight, f.bias,
+                             pred, self.depth, I, H)
 
     def forward(self, fmess, bgraph):
         h, c = self.forward_padded(fmess, bgraph)
