@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--pool", type=int, default=16, help="distinct pre-tensorized batches per rank (cycled)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -169,13 +170,18 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("GGPM_BENCH_ONE_DEVICE"):      # rehearsal of N ranks on a 1-GPU box (use --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from ggpm_amd import _lib
     from ggpm_amd.encoder import PreparedBatch
@@ -263,21 +269,31 @@ def main():
             step(i)
         torch.cuda.synchronize()
         lib.ggpm_timing_enable(0)
-        cls = (0, 1) if a.rnn == "GRU" else (2, 3)
-        best = None
-        for which, name in zip(cls, ("fwd", "bwd")):
+        names = ["gru_fwd_a", "gru_bwd_a", "lstm_fwd_a", "lstm_bwd_a", "gru_fwd_b", "gru_bwd_b", "lstm_fwd_b",
+                 "lstm_bwd_b"]
+        per_kernel, best = {}, None
+        for which, kname in enumerate(names):
             n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
             lib.ggpm_timing_collect(which, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
-            if n.value and (best is None or ms.value > best[2]):
-                best = ("%s_step_%s" % (a.rnn.lower(), name), n.value, ms.value, fl.value)
+            if n.value:
+                per_kernel[kname] = {"launches": n.value, "avg_launch_us": round(1e3 * ms.value / n.value, 3),
+                                     "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 3)}
+                if best is None or ms.value > best[2]:
+                    best = (kname, n.value, ms.value, fl.value)
         if best and rank == 0:
             kname, n, ms, fl = best
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    traffic = json.load(f).get(a.rnn, {}).get(kname)
+            except Exception:
+                pass
             result["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3),
                                   "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                                  "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
                                   "launches": n, "avg_launch_us": round(1e3 * ms / n, 3),
-                                  "flops_per_launch_avg": round(fl / n, 1)}
+                                  "flops_per_launch_avg": round(fl / n, 1), "all_depth_kernels": per_kernel}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("roofline pass done; cpu baseline on %d threads" % host_cores())

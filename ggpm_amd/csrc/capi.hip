@@ -21,7 +21,7 @@ extern "C" int ggpm_padded_hidden(int H) { return ggpm_round_up(H, 16); }
 // ---------------------------------------------------------------- timing sink (debug/bench only)
 namespace {
 struct Span { hipEvent_t a, b; double flops; };
-constexpr int NCLASS = 4;
+constexpr int NCLASS = 8;
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Span> g_spans[NCLASS];

@@ -146,64 +146,66 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         }
     }
 
-    // prefetch the hoisted input terms of this wave's tile while the other waves finish their gathers
-    const bool has_tile = wave < a.tg && t < NT;
-    const int c = 16 * (has_tile ? t : 0) + 4 * (lane >> 4);
-    const int lr = lane & 15, row = r0 + lr;
-    const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-    const float4 xz = ggpm_ld4(a.Xz + o);
-    const float4 xh = ggpm_ld4(a.Xh + o);
     __syncthreads();
-    if (!has_tile) return;
 
-    // ---- P2: gate GEMMs + gate math
-    f32x4 acc[2][RT];
-    ggpm_zero_acc<2, RT>(acc);
-    if (!(a.ablate & 2)) {
-        const float* const tiles[2] = {Ts, Tg};
-        const float* const wps[2] = {a.Wz, a.Wh};
-        ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    if (row >= a.E1) return;
-    float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
-    if (row != 0) {
-        const float4 s = ggpm_ld4(Ts + lr * LD + c);
-        const float4 pz = ggpm_f4(acc[0][0]) + xz, pm = ggpm_f4(acc[1][0]) + xh;
-        z = ggpm_sigmoid4(pz);
-        m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
-        h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
-                        (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
-    }
-    ggpm_st4(a.Hnew + o, h);
-    if (STASH) {
-        ggpm_st4(a.Z + o, z);
-        ggpm_st4(a.M + o, m);
+    // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
+    const int lr = lane & 15, row = r0 + lr;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = t; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+        const float4 xz = ggpm_ld4(a.Xz + o);      // in flight under the GEMM
+        const float4 xh = ggpm_ld4(a.Xh + o);
+        f32x4 acc[2][RT];
+        ggpm_zero_acc<2, RT>(acc);
+        if (!(a.ablate & 2)) {
+            const float* const tiles[2] = {Ts, Tg};
+            const float* const wps[2] = {a.Wz, a.Wh};
+            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        if (row >= a.E1) continue;
+        float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
+        if (row != 0) {
+            const float4 s = ggpm_ld4(Ts + lr * LD + c);
+            const float4 pz = ggpm_f4(acc[0][0]) + xz, pm = ggpm_f4(acc[1][0]) + xh;
+            z = ggpm_sigmoid4(pz);
+            m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
+            h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
+                            (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
+        }
+        ggpm_st4(a.Hnew + o, h);
+        if (STASH) {
+            ggpm_st4(a.Z + o, z);
+            ggpm_st4(a.M + o, m);
+        }
     }
 }
 
-// Kernel B (4 waves, 4 tiles per group): q' = U_r h' + b_u (h' rows come back from L2).
-__global__ void __launch_bounds__(GGPM_NW * 64) gru_fwd_b(GruFwdArgs a) {
+// Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
+__global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
-    const int t = blockIdx.y * GGPM_NW + wave;
+    const int grp = blockIdx.y;
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
-    const int c = 16 * (t < NT ? t : 0) + 4 * (lane >> 4);
-    const float4 b = ggpm_ld4(a.bu + c);
     __syncthreads();
-    if (t >= NT) return;
-    f32x4 acc[1][RT];
-    ggpm_zero_acc<1, RT>(acc);
-    if (!(a.ablate & 2)) {
-        const float* const tiles[1] = {Th};
-        const float* const wps[1] = {a.Ur};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
     const int row = r0 + (lane & 15);
-    if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const float4 b = ggpm_ld4(a.bu + c);
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        if (!(a.ablate & 2)) {
+            const float* const tiles[1] = {Th};
+            const float* const wps[1] = {a.Ur};
+            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -293,52 +295,52 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         }
     }
 
-    // prefetch this wave's stash operands
-    const bool has_tile = wave < a.tg && t < NT;
-    const int c = 16 * (has_tile ? t : 0) + 4 * (lane >> 4);
-    const int lr = lane & 15, row = r0 + lr;
-    const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-    const float4 s = ggpm_ld4(a.S + o), z = ggpm_ld4(a.Z + o), m = ggpm_ld4(a.M + o);
-    const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-    const float4 oxz = ggpm_ld4(a.dXz + o), oxh = ggpm_ld4(a.dXh + o);
     if (!a.first) __syncthreads();
-    if (!has_tile) return;
 
-    // ---- P2: dh = partial + dq . U_r ; gate derivatives
-    f32x4 acc[1][RT];
-    ggpm_zero_acc<1, RT>(acc);
-    if (!a.first) {
-        const float* const tiles[1] = {T1};
-        const float* const wps[1] = {a.UrT};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    if (row >= a.E1) return;
-    float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
-    if (row != 0) {
-        const float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
-        const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s.x, s.y, s.z, s.w};
-        const float zv[4] = {z.x, z.y, z.z, z.w}, mv[4] = {m.x, m.y, m.z, m.w};
-        float o_ds[4], o_dz[4], o_dm[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o_ds[k] = dhv[k] * (1.f - zv[k]);
-            o_dz[k] = dhv[k] * (mv[k] - sv[k]) * zv[k] * (1.f - zv[k]);
-            o_dm[k] = dhv[k] * zv[k] * (1.f - mv[k] * mv[k]);
+    // ---- P2: dh = partial + dq . U_r ; gate derivatives, for this wave's tiles
+    const int lr = lane & 15, row = r0 + lr;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = t; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+        const float4 s = ggpm_ld4(a.S + o), z = ggpm_ld4(a.Z + o), m = ggpm_ld4(a.M + o);
+        const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+        const float4 oxz = ggpm_ld4(a.dXz + o), oxh = ggpm_ld4(a.dXh + o);
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        if (!a.first) {
+            const float* const tiles[1] = {T1};
+            const float* const wps[1] = {a.UrT};
+            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        dsdir = make_float4(o_ds[0], o_ds[1], o_ds[2], o_ds[3]);
-        dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
-        dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
+        if (row >= a.E1) continue;
+        float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
+        if (row != 0) {
+            const float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
+            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s.x, s.y, s.z, s.w};
+            const float zv[4] = {z.x, z.y, z.z, z.w}, mv[4] = {m.x, m.y, m.z, m.w};
+            float o_ds[4], o_dz[4], o_dm[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o_ds[k] = dhv[k] * (1.f - zv[k]);
+                o_dz[k] = dhv[k] * (mv[k] - sv[k]) * zv[k] * (1.f - zv[k]);
+                o_dm[k] = dhv[k] * zv[k] * (1.f - mv[k] * mv[k]);
+            }
+            dsdir = make_float4(o_ds[0], o_ds[1], o_ds[2], o_ds[3]);
+            dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
+            dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
+        }
+        ggpm_st4(a.DSD + o, dsdir);
+        ggpm_st4(a.DZP + o, dzp);
+        ggpm_st4(a.DMP + o, dmp);
+        ggpm_st4(a.dXz + o, oxz + dzp);
+        ggpm_st4(a.dXh + o, oxh + dmp);
     }
-    ggpm_st4(a.DSD + o, dsdir);
-    ggpm_st4(a.DZP + o, dzp);
-    ggpm_st4(a.DMP + o, dmp);
-    ggpm_st4(a.dXz + o, oxz + dzp);
-    ggpm_st4(a.dXh + o, oxh + dmp);
 }
 
-// Kernel B (4 waves): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
+// Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
-__global__ void __launch_bounds__(GGPM_NW * 64) gru_bwd_b(GruBwdArgs a) {
+__global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T1 = lds;                  // dz_pre rows
@@ -346,27 +348,29 @@ __global__ void __launch_bounds__(GGPM_NW * 64) gru_bwd_b(GruBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
-    const int t = blockIdx.y * GGPM_NW + wave;
+    const int grp = blockIdx.y;
     ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
     ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
-    const int c = 16 * (t < NT ? t : 0) + 4 * (lane >> 4);
-    const int e = r0 + (lane & 15);
-    const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
-    const float4 dsd = ggpm_ld4(a.DSD + o), rco = ggpm_ld4(a.R + o), oxr = ggpm_ld4(a.dXr + o);
     __syncthreads();
-    if (t >= NT) return;
-    f32x4 acc[2][RT];
-    ggpm_zero_acc<2, RT>(acc);
-    {
-        const float* const tiles[2] = {T2, T1};
-        const float* const wps[2] = {a.WhT, a.WzT};
-        ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, t, lane, acc);
+    const int e = r0 + (lane & 15);
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
+        const float4 dsd = ggpm_ld4(a.DSD + o), rco = ggpm_ld4(a.R + o), oxr = ggpm_ld4(a.dXr + o);
+        f32x4 acc[2][RT];
+        ggpm_zero_acc<2, RT>(acc);
+        {
+            const float* const tiles[2] = {T2, T1};
+            const float* const wps[2] = {a.WhT, a.WzT};
+            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        if (e >= a.E1) continue;
+        const float4 dg = ggpm_f4(acc[0][0]);
+        ggpm_st4(a.dGout + o, dg);
+        ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
+        ggpm_st4(a.dXr + o, oxr + dg * rco);
     }
-    if (e >= a.E1) return;
-    const float4 dg = ggpm_f4(acc[0][0]);
-    ggpm_st4(a.dGout + o, dg);
-    ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
-    ggpm_st4(a.dXr + o, oxr + dg * rco);
 }
 
 template <typename K>
@@ -376,15 +380,15 @@ inline void set_lds(K kernel, size_t bytes) {
 }
 
 inline int pick_tg(int E1, int NT) {
-    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= GGPM_NWA) return v; }   // tuning override
+    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
     return ggpm_tiles_per_group(E1, NT);
 }
 
-void launch_fwd(const GruFwdArgs& a, bool stash, bool with_b, hipStream_t s) {
+void launch_fwd(const GruFwdArgs& a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    dim3 grid_b(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, GGPM_NW));
     const size_t lds_a = (size_t)2 * ROWS * (Hp + 4) * sizeof(float), lds_b = lds_a / 2;
+    ggpm_timing_begin(0, s, 2 * flops1);
     if (stash) {
         set_lds(gru_fwd_a<true>, lds_a);
         gru_fwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
@@ -392,22 +396,28 @@ void launch_fwd(const GruFwdArgs& a, bool stash, bool with_b, hipStream_t s) {
         set_lds(gru_fwd_a<false>, lds_a);
         gru_fwd_a<false><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     }
+    ggpm_timing_end(0, s);
     if (with_b) {
         set_lds(gru_fwd_b, lds_b);
-        gru_fwd_b<<<grid_b, GGPM_NW * 64, lds_b, s>>>(a);
+        ggpm_timing_begin(4, s, 1 * flops1);
+        gru_fwd_b<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a);
+        ggpm_timing_end(4, s);
     }
 }
 
-void launch_bwd(const GruBwdArgs& a, bool with_b, hipStream_t s) {
+void launch_bwd(const GruBwdArgs& a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    dim3 grid_b(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, GGPM_NW));
     const size_t lds = (size_t)2 * ROWS * (Hp + 4) * sizeof(float);
     set_lds(gru_bwd_a, lds);
+    ggpm_timing_begin(1, s, 1 * flops1);
     gru_bwd_a<<<grid_a, GGPM_NWA * 64, lds, s>>>(a);
+    ggpm_timing_end(1, s);
     if (with_b) {
         set_lds(gru_bwd_b, lds);
-        gru_bwd_b<<<grid_b, GGPM_NW * 64, lds, s>>>(a);
+        ggpm_timing_begin(5, s, 2 * flops1);
+        gru_bwd_b<<<grid_a, GGPM_NWA * 64, lds, s>>>(a);
+        ggpm_timing_end(5, s);
     }
 }
 
@@ -447,7 +457,7 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
     gru_init_state<<<ig, 256, 0, s>>>(Hs, Qs, pbu, E1, Hp);
 
     const int tg = pick_tg(E1, Hp / 16);
-    const double flops = 2.0 * 3.0 * (double)(E1 - 1) * H * H;   // algorithmic: 3 gate products per message
+    const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     const char* abl = getenv("GGPM_ABLATE");
     for (int t = 1; t <= depth; ++t) {
         GruFwdArgs a;
@@ -466,9 +476,7 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
             a.Qprev = Qs + (size_t)((t - 1) & 1) * slot; a.Qnew = Qs + (size_t)(t & 1) * slot;
             a.S = a.G = a.Z = a.M = a.R = nullptr;
         }
-        ggpm_timing_begin(0, s, flops);
-        launch_fwd(a, save_for_backward != 0, t < depth, s);
-        ggpm_timing_end(0, s);
+        launch_fwd(a, save_for_backward != 0, t < depth, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
@@ -527,7 +535,7 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     (void)hipMemsetAsync(dXh, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);
-    const double flops = 2.0 * 3.0 * (double)(E1 - 1) * H * H;
+    const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     for (int t = depth; t >= 1; --t) {
         GruBwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
@@ -544,9 +552,7 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
         a.srowptr = succ_rowptr; a.scol = succ_col;
-        ggpm_timing_begin(1, s, flops);
-        launch_bwd(a, t > 1, s);
-        ggpm_timing_end(1, s);
+        launch_bwd(a, t > 1, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
 

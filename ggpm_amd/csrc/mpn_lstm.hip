@@ -107,65 +107,68 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         }
     }
 
-    const bool has_tile = wave < a.tg && t < NT;
-    const int c = 16 * (has_tile ? t : 0) + 4 * (lane >> 4);
-    const int lr = lane & 15, row = r0 + lr;
-    const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-    const float4 xi = ggpm_ld4(a.Xi + o), xo = ggpm_ld4(a.Xo + o), xu = ggpm_ld4(a.Xu + o);
     __syncthreads();
-    if (!has_tile) return;
 
-    f32x4 acc[3][RT];
-    ggpm_zero_acc<3, RT>(acc);
-    {
-        const float* const tiles[3] = {Ts, Ts, Ts};
-        const float* const wps[3] = {a.Wi, a.Wo, a.Wu};
-        ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    if (row >= a.E1) return;
-    float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
-    if (row != 0) {
-        const float4 pi = ggpm_f4(acc[0][0]) + xi;
-        const float4 po = ggpm_f4(acc[1][0]) + xo;
-        const float4 pu = ggpm_f4(acc[2][0]) + xu;
-        const float4 fc = ggpm_ld4(Tf + lr * LD + c);
-        gi = ggpm_sigmoid4(pi);
-        go = ggpm_sigmoid4(po);
-        gu = make_float4(tanhf(pu.x), tanhf(pu.y), tanhf(pu.z), tanhf(pu.w));
-        cn = gi * gu + fc;
-        h = go * make_float4(tanhf(cn.x), tanhf(cn.y), tanhf(cn.z), tanhf(cn.w));
-    }
-    ggpm_st4(a.Hnew + o, h);
-    ggpm_st4(a.Cnew + o, cn);
-    if (STASH) {
-        ggpm_st4(a.I + o, gi);
-        ggpm_st4(a.O + o, go);
-        ggpm_st4(a.U + o, gu);
+    const int lr = lane & 15, row = r0 + lr;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = t; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+        const float4 xi = ggpm_ld4(a.Xi + o), xo = ggpm_ld4(a.Xo + o), xu = ggpm_ld4(a.Xu + o);
+        f32x4 acc[3][RT];
+        ggpm_zero_acc<3, RT>(acc);
+        {
+            const float* const tiles[3] = {Ts, Ts, Ts};
+            const float* const wps[3] = {a.Wi, a.Wo, a.Wu};
+            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        if (row >= a.E1) continue;
+        float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
+        if (row != 0) {
+            const float4 pi = ggpm_f4(acc[0][0]) + xi;
+            const float4 po = ggpm_f4(acc[1][0]) + xo;
+            const float4 pu = ggpm_f4(acc[2][0]) + xu;
+            const float4 fc = ggpm_ld4(Tf + lr * LD + c);
+            gi = ggpm_sigmoid4(pi);
+            go = ggpm_sigmoid4(po);
+            gu = make_float4(tanhf(pu.x), tanhf(pu.y), tanhf(pu.z), tanhf(pu.w));
+            cn = gi * gu + fc;
+            h = go * make_float4(tanhf(cn.x), tanhf(cn.y), tanhf(cn.z), tanhf(cn.w));
+        }
+        ggpm_st4(a.Hnew + o, h);
+        ggpm_st4(a.Cnew + o, cn);
+        if (STASH) {
+            ggpm_st4(a.I + o, gi);
+            ggpm_st4(a.O + o, go);
+            ggpm_st4(a.U + o, gu);
+        }
     }
 }
 
-// Kernel B (4 waves): qf' = Wf_h h'.
-__global__ void __launch_bounds__(GGPM_NW * 64) lstm_fwd_b(LstmFwdArgs a) {
+// Kernel B (same geometry as A): qf' = Wf_h h'.
+__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
-    const int t = blockIdx.y * GGPM_NW + wave;
+    const int grp = blockIdx.y;
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
-    if (t >= NT) return;
-    f32x4 acc[1][RT];
-    ggpm_zero_acc<1, RT>(acc);
-    {
-        const float* const tiles[1] = {Th};
-        const float* const wps[1] = {a.Wf};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    const int c = 16 * t + 4 * (lane >> 4);
     const int row = r0 + (lane & 15);
-    if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        {
+            const float* const tiles[1] = {Th};
+            const float* const wps[1] = {a.Wf};
+            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        const int c = 16 * tt + 4 * (lane >> 4);
+        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -261,60 +264,61 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         }
     }
 
-    const bool has_tile = wave < a.tg && t < NT;
-    const int c = 16 * (has_tile ? t : 0) + 4 * (lane >> 4);
-    const int lr = lane & 15, row = r0 + lr;
-    const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-    const float4 gi = ggpm_ld4(a.I + o), go = ggpm_ld4(a.O + o), gu = ggpm_ld4(a.U + o), cc = ggpm_ld4(a.Ccur + o);
-    const float4 fco = ggpm_ld4(a.F + o);
-    const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-    const float4 oxi = ggpm_ld4(a.dXi + o), oxo = ggpm_ld4(a.dXo + o), oxu = ggpm_ld4(a.dXu + o), oxf = ggpm_ld4(a.dXf + o);
     if (!a.first) __syncthreads();
-    if (!has_tile) return;
 
-    f32x4 acc[1][RT];
-    ggpm_zero_acc<1, RT>(acc);
-    if (!a.first) {
-        const float* const tiles[1] = {T1};
-        const float* const wps[1] = {a.WfT};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    if (row >= a.E1) return;
-    float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
-    if (row != 0) {
-        float4 dh, dc;
-        if (a.first) { dh = dhd; dc = ggpm_zero4(); }
-        else { dh = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
-        const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
-        const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, ov[4] = {go.x, go.y, go.z, go.w};
-        const float uv[4] = {gu.x, gu.y, gu.z, gu.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
-        float r_i[4], r_o[4], r_u[4], r_c[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float tc = tanhf(cv[k]);
-            const float dct = dcv[k] + dhv[k] * ov[k] * (1.f - tc * tc);
-            r_c[k] = dct;
-            r_o[k] = dhv[k] * tc * ov[k] * (1.f - ov[k]);
-            r_i[k] = dct * uv[k] * iv[k] * (1.f - iv[k]);
-            r_u[k] = dct * iv[k] * (1.f - uv[k] * uv[k]);
+    const int lr = lane & 15, row = r0 + lr;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = t; tt < t_end; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+        const float4 gi = ggpm_ld4(a.I + o), go = ggpm_ld4(a.O + o), gu = ggpm_ld4(a.U + o), cc = ggpm_ld4(a.Ccur + o);
+        const float4 fco = ggpm_ld4(a.F + o);
+        const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+        const float4 oxi = ggpm_ld4(a.dXi + o), oxo = ggpm_ld4(a.dXo + o), oxu = ggpm_ld4(a.dXu + o), oxf = ggpm_ld4(a.dXf + o);
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        if (!a.first) {
+            const float* const tiles[1] = {T1};
+            const float* const wps[1] = {a.WfT};
+            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        dip = make_float4(r_i[0], r_i[1], r_i[2], r_i[3]);
-        dop = make_float4(r_o[0], r_o[1], r_o[2], r_o[3]);
-        dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
-        dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
+        if (row >= a.E1) continue;
+        float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
+        if (row != 0) {
+            float4 dh, dc;
+            if (a.first) { dh = dhd; dc = ggpm_zero4(); }
+            else { dh = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
+            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+            const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, ov[4] = {go.x, go.y, go.z, go.w};
+            const float uv[4] = {gu.x, gu.y, gu.z, gu.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
+            float r_i[4], r_o[4], r_u[4], r_c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tc = tanhf(cv[k]);
+                const float dct = dcv[k] + dhv[k] * ov[k] * (1.f - tc * tc);
+                r_c[k] = dct;
+                r_o[k] = dhv[k] * tc * ov[k] * (1.f - ov[k]);
+                r_i[k] = dct * uv[k] * iv[k] * (1.f - iv[k]);
+                r_u[k] = dct * iv[k] * (1.f - uv[k] * uv[k]);
+            }
+            dip = make_float4(r_i[0], r_i[1], r_i[2], r_i[3]);
+            dop = make_float4(r_o[0], r_o[1], r_o[2], r_o[3]);
+            dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
+            dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
+        }
+        ggpm_st4(a.DI + o, dip);
+        ggpm_st4(a.DO + o, dop);
+        ggpm_st4(a.DU + o, dup);
+        ggpm_st4(a.dFCout + o, dfc);
+        ggpm_st4(a.dXi + o, oxi + dip);
+        ggpm_st4(a.dXo + o, oxo + dop);
+        ggpm_st4(a.dXu + o, oxu + dup);
+        ggpm_st4(a.dXf + o, oxf + dfc * fco);      // dXf_e += dFC_e * sum_p c_p f(1-f)
     }
-    ggpm_st4(a.DI + o, dip);
-    ggpm_st4(a.DO + o, dop);
-    ggpm_st4(a.DU + o, dup);
-    ggpm_st4(a.dFCout + o, dfc);
-    ggpm_st4(a.dXi + o, oxi + dip);
-    ggpm_st4(a.dXo + o, oxo + dop);
-    ggpm_st4(a.dXu + o, oxu + dup);
-    ggpm_st4(a.dXf + o, oxf + dfc * fco);      // dXf_e += dFC_e * sum_p c_p f(1-f)
 }
 
-// Kernel B (4 waves): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
-__global__ void __launch_bounds__(GGPM_NW * 64) lstm_bwd_b(LstmBwdArgs a) {
+// Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
+__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ta = lds;
@@ -323,23 +327,25 @@ __global__ void __launch_bounds__(GGPM_NW * 64) lstm_bwd_b(LstmBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
-    const int t = blockIdx.y * GGPM_NW + wave;
+    const int grp = blockIdx.y;
     ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
     ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
     ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
     __syncthreads();
-    if (t >= NT) return;
-    f32x4 acc[3][RT];
-    ggpm_zero_acc<3, RT>(acc);
-    {
-        const float* const tiles[3] = {Ta, Tb, Tc};
-        const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
-        ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, t, lane, acc);
-    }
-    const int c = 16 * t + 4 * (lane >> 4);
     const int e = r0 + (lane & 15);
-    if (e < a.E1)
-        ggpm_st4(a.dSout + (size_t)e * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
+        f32x4 acc[3][RT];
+        ggpm_zero_acc<3, RT>(acc);
+        {
+            const float* const tiles[3] = {Ta, Tb, Tc};
+            const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
+            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        const int c = 16 * tt + 4 * (lane >> 4);
+        if (e < a.E1)
+            ggpm_st4(a.dSout + (size_t)e * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
+    }
 }
 
 template <typename K>
@@ -351,15 +357,15 @@ inline void set_lds(K kernel, size_t bytes) {
 inline size_t lds_tiles(int n, int Hp) { return (size_t)n * ROWS * (Hp + 4) * sizeof(float); }
 
 inline int pick_tg(int E1, int NT) {
-    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= GGPM_NWA) return v; }   // tuning override
+    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
     return ggpm_tiles_per_group(E1, NT);
 }
 
-void launch_fwd(const LstmFwdArgs& a, bool stash, bool with_b, hipStream_t s) {
+void launch_fwd(const LstmFwdArgs& a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    dim3 grid_b(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, GGPM_NW));
     const size_t la = lds_tiles(2, Hp), lb = lds_tiles(1, Hp);
+    ggpm_timing_begin(2, s, 3 * flops1);
     if (stash) {
         set_lds(lstm_fwd_a<true>, la);
         lstm_fwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
@@ -367,22 +373,28 @@ void launch_fwd(const LstmFwdArgs& a, bool stash, bool with_b, hipStream_t s) {
         set_lds(lstm_fwd_a<false>, la);
         lstm_fwd_a<false><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
     }
+    ggpm_timing_end(2, s);
     if (with_b) {
         set_lds(lstm_fwd_b, lb);
-        lstm_fwd_b<<<grid_b, GGPM_NW * 64, lb, s>>>(a);
+        ggpm_timing_begin(6, s, 1 * flops1);
+        lstm_fwd_b<<<grid_a, GGPM_NWA * 64, lb, s>>>(a);
+        ggpm_timing_end(6, s);
     }
 }
 
-void launch_bwd(const LstmBwdArgs& a, bool with_b, hipStream_t s) {
+void launch_bwd(const LstmBwdArgs& a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    dim3 grid_b(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, GGPM_NW));
     const size_t l3 = lds_tiles(3, Hp);
     set_lds(lstm_bwd_a, l3);
+    ggpm_timing_begin(3, s, 1 * flops1);
     lstm_bwd_a<<<grid_a, GGPM_NWA * 64, l3, s>>>(a);
+    ggpm_timing_end(3, s);
     if (with_b) {
         set_lds(lstm_bwd_b, l3);
-        lstm_bwd_b<<<grid_b, GGPM_NW * 64, l3, s>>>(a);
+        ggpm_timing_begin(7, s, 3 * flops1);
+        lstm_bwd_b<<<grid_a, GGPM_NWA * 64, l3, s>>>(a);
+        ggpm_timing_end(7, s);
     }
 }
 
@@ -420,7 +432,7 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
     (void)hipMemsetAsync(Qs, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);
-    const double flops = 2.0 * 4.0 * (double)(E1 - 1) * H * H;
+    const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     for (int t = 1; t <= depth; ++t) {
         LstmFwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
@@ -438,9 +450,7 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
             a.Qprev = Qs + (size_t)((t - 1) & 1) * slot; a.Qnew = Qs + (size_t)(t & 1) * slot;
             a.S = a.I = a.O = a.U = a.F = nullptr;
         }
-        ggpm_timing_begin(2, s, flops);
-        launch_fwd(a, save_for_backward != 0, t < depth, s);
-        ggpm_timing_end(2, s);
+        launch_fwd(a, save_for_backward != 0, t < depth, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
@@ -501,7 +511,7 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
     (void)hipMemsetAsync(dXf, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);
-    const double flops = 2.0 * 4.0 * (double)(E1 - 1) * H * H;
+    const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     for (int t = depth; t >= 1; --t) {
         LstmBwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
@@ -518,9 +528,7 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
         a.dXi = dXi; a.dXo = dXo; a.dXu = dXu; a.dXf = dXf;
         a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT;
         a.srowptr = succ_rowptr; a.scol = succ_col;
-        ggpm_timing_begin(3, s, flops);
-        launch_bwd(a, t > 1, s);
-        ggpm_timing_end(3, s);
+        launch_bwd(a, t > 1, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
 

@@ -140,14 +140,16 @@ __device__ __forceinline__ void ggpm_load_rows_to_lds(const float* __restrict__ 
 __global__ void ggpm_pack_weight_kernel(const float* __restrict__ W, int ldw, int H, int Hp, int transpose,
                                         float* __restrict__ dst);
 void ggpm_launch_pack(const float* W, int ldw, int H, int Hp, int transpose, float* dst, hipStream_t s);
-// Output tiles per column group of the A kernels for a level of E1 messages and NT = Hp/16 tiles: as few
-// groups as still give >= ~256 workgroups (every group repeats the full-row gather), 4..16 tiles each.
+// Output tiles per column group of the depth-step kernels for a level of E1 messages and NT = Hp/16 tiles.
+// One 16-wave workgroup fits a CU at a time, so the grid is kept at <= ~256 workgroups: big levels use ONE
+// group (no redundant gathers; waves loop over tiles wave, wave+16, ...), small levels split the columns so
+// that a few hundred messages still reach all CUs.
 static inline int ggpm_tiles_per_group(int E1, int NT) {
     const int row_tiles = (E1 + 15) / 16;
-    int groups = (256 + row_tiles - 1) / row_tiles;
+    int groups = 256 / row_tiles;
     if (groups < 1) groups = 1;
     int tg = (NT + groups - 1) / groups;
     if (tg < 4) tg = 4;
-    if (tg > GGPM_NWA) tg = GGPM_NWA;
+    if (tg > NT) tg = NT;
     return tg;
 }

@@ -164,10 +164,11 @@ int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* W
                        size_t work_bytes, ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ instrumentation
- * When a timing sink is installed, every fused depth-step launch is bracketed by HIP events on its own
- * stream; ggpm_timing_collect() synchronises those events and returns launches / total milliseconds
- * for kernel class `which` (0 gru fwd, 1 gru bwd, 2 lstm fwd, 3 lstm bwd). Used by bench.py for
- * roofline.achieved; off by default (no events, no overhead). */
+ * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own
+ * stream; ggpm_timing_collect() synchronises those events and returns launches / total milliseconds /
+ * algorithmic flops for kernel class `which` (0 gru_fwd_a, 1 gru_bwd_a, 2 lstm_fwd_a, 3 lstm_bwd_a,
+ * 4 gru_fwd_b, 5 gru_bwd_b, 6 lstm_fwd_b, 7 lstm_bwd_b). Used by bench.py for roofline.achieved; off by
+ * default (no events, no overhead). */
 int ggpm_timing_enable(int on);
 int ggpm_timing_collect(int which, int* launches, double* total_ms, double* flops);
 

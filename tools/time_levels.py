@@ -25,7 +25,7 @@ for name, t, I in (("atom", graph, 62), ("tree", tree, H + 20)):
         h.sum().backward()
     torch.cuda.synchronize()
     lib.ggpm_timing_enable(0)
-    for which, nm in ((0, "gru fwd"), (1, "gru bwd"), (2, "lstm fwd"), (3, "lstm bwd")):
+    for which, nm in enumerate(["gru_fwd_a", "gru_bwd_a", "lstm_fwd_a", "lstm_bwd_a", "gru_fwd_b", "gru_bwd_b", "lstm_fwd_b", "lstm_bwd_b"]):
         n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
         lib.ggpm_timing_collect(which, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         if n.value:
