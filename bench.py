@@ -236,6 +236,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    host_enqueue = time.perf_counter() - t0     # host time to enqueue K steps (diagnostic: host- vs GPU-bound)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -243,7 +244,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    log("timed region done: %.3f ms/step" % (1e3 * elapsed / a.steps))
+    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,
+                                                                         1e3 * host_enqueue / a.steps))
     flops_step, atoms = algorithmic_work(pool, H, a.depth, 3 if a.rnn == "GRU" else 4)
     mols = a.steps * a.batch * world
     result = {

@@ -373,10 +373,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     }
 }
 
+// Raise the dynamic-LDS limit of a kernel once per (kernel, size) instead of once per launch: the attribute call
+// costs host microseconds and a level issues ~40 launches per direction.  (A benign race between autograd
+// threads at worst repeats the call.)
 template <typename K>
 inline void set_lds(K kernel, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bytes);
+    static size_t have = 0;            // one static per kernel instantiation
+    if (bytes > have) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+        have = bytes;
+    }
 }
 
 inline int pick_tg(int E1, int NT) {
@@ -503,7 +510,8 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
                                  const float* Qs, const float* Ss, const float* Gs, const float* Zs,
                                  const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr, float* dXh,
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
-                                 int ld_dwh, float* work, size_t work_bytes, ggpm_stream_t stream) {
+                                 int ld_dwh, float* work, size_t work_bytes, int weight_grads,
+                                 ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
@@ -556,7 +564,32 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     }
     GGPM_CHECK_LAUNCH();
 
-    // weight gradients: tall contractions over every (depth, message) row of the stashes
+    if (!weight_grads) return GGPM_OK;
+    return ggpm_gru_weight_grads(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
+                                 ld_dwh, stream);
+}
+
+// Weight gradients of the GRU message function: tall contractions over every (depth, message) row of the
+// stashes ggpm_gru_backward left in `work`.  Separate entry point so that the host can run them on a second
+// stream while the next level's (latency-bound) depth loop occupies the main one.
+extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
+                                     float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr,
+                                     int ld_dur, float* dbu, float* dWh_h, int ld_dwh, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !Gs || !work || !dWz_h || !dUr || !dbu || !dWh_h)
+        return GGPM_ERR_ARG;
+    if (work_bytes < ggpm_gru_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
+    const int Hp = ggpm_padded_hidden(H);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
+    float* w = work;
+    float* DMP = w; w += (size_t)depth * slot;
+    float* DZP = w; w += (size_t)depth * slot;
+    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
+    w += 5 * slot + 3 * HH;
+    float* csws = w; w += (size_t)256 * Hp;
+    float* skws = w;
+    const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = depth * E1;
     int rc;
     rc = ggpm_gemm(1, 0, H, H, KD, DMP, Hp, Gs, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);

@@ -348,10 +348,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     }
 }
 
+// Raise the dynamic-LDS limit of a kernel once per (kernel, size) instead of once per launch: the attribute call
+// costs host microseconds and a level issues ~40 launches per direction.  (A benign race between autograd
+// threads at worst repeats the call.)
 template <typename K>
 inline void set_lds(K kernel, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bytes);
+    static size_t have = 0;            // one static per kernel instantiation
+    if (bytes > have) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+        have = bytes;
+    }
 }
 
 inline size_t lds_tiles(int n, int Hp) { return (size_t)n * ROWS * (Hp + 4) * sizeof(float); }
@@ -478,7 +485,7 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
                                   float* dXo,
                                   float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                                   float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
-                                  size_t work_bytes, ggpm_stream_t stream) {
+                                  size_t work_bytes, int weight_grads, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Cs || !Qs || !Ss || !Is || !Os || !Us || !Fs || !dHD || !dXi || !dXo || !dXu ||
@@ -532,6 +539,30 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
     }
     GGPM_CHECK_LAUNCH();
 
+    if (!weight_grads) return GGPM_OK;
+    return ggpm_lstm_weight_grads(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
+                                  dWf_h, ld_dwf, stream);
+}
+
+// Weight gradients of the LSTM message function from the stashes ggpm_lstm_backward left in `work`.
+extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
+                                      size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                                      float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !work || !dWi_h || !dWo_h || !dWu_h || !dWf_h)
+        return GGPM_ERR_ARG;
+    if (work_bytes < ggpm_lstm_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
+    const int Hp = ggpm_padded_hidden(H);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
+    float* w = work;
+    float* DI = w; w += (size_t)depth * slot;
+    float* DO = w; w += (size_t)depth * slot;
+    float* DU = w; w += (size_t)depth * slot;
+    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
+    w += 4 * slot + 4 * HH;
+    float* skws = w;
+    const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = depth * E1;
     int rc;
     rc = ggpm_gemm(1, 0, H, H, KD, DI, Hp, Ss, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);

@@ -34,6 +34,34 @@ class LevelGraph:
         self.cgr = F_.csr_from_padded(cgraph, ncols=n_lower) if cgraph is not None else None
 
 
+class _PinnedRing:
+    """Small ring of pinned int32 staging buffers: host lists (the ``scope`` roots) reach the GPU with an async
+    copy, so building a batch never blocks the host behind the GPU work already queued (a pageable
+    ``torch.tensor(list, device=...)`` copy waits for the stream and would serialise consecutive steps)."""
+
+    def __init__(self, slots: int = 32):
+        self.slots, self.bufs, self.events, self.i = slots, [None] * slots, [None] * slots, 0
+
+    def upload(self, values, device) -> torch.Tensor:
+        n = len(values)
+        k = self.i
+        self.i = (self.i + 1) % self.slots
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # slot reuse: its previous copy must have been consumed
+        if self.bufs[k] is None or self.bufs[k].numel() < n:
+            self.bufs[k] = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
+        self.bufs[k][:n] = torch.as_tensor(values, dtype=torch.int32)
+        out = torch.empty(n, dtype=torch.int32, device=device)
+        out.copy_(self.bufs[k][:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
+_RING = _PinnedRing()
+
+
 class PreparedBatch:
     """CSR structures of one tensorized batch; build once, reuse across forward calls of the same batch."""
 
@@ -44,7 +72,7 @@ class PreparedBatch:
         self.tree = LevelGraph(tfmess, tagraph, tbgraph, tcgraph, n_lower=gfnode.shape[0])
         self.motif_id = F_.extract_column(tfnode, 0)
         self.attach_id = F_.extract_column(tfnode, 1)
-        self.roots = torch.tensor([st for st, _ in tscope], dtype=torch.int32, device=tfnode.device)
+        self.roots = _RING.upload([st for st, _ in tscope], tfnode.device)
 
 
 class MPNEncoder(nn.Module):

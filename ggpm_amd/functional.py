@@ -293,6 +293,40 @@ def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_t
     return hnode, hmess
 
 
+# ----------------------------------------------------------------------------- second stream for weight gradients
+# The depth loops are latency bound (small dependent kernels); the weight-gradient GEMMs over the stashes are
+# throughput bound and independent of the remaining backward.  With GGPM_SIDE_STREAM=1 (default) they run on
+# a second HIP stream beside the next level's depth loop and accumulate straight into ``param.grad``; the main
+# stream re-joins at the end of the backward pass (autograd engine callback), so after ``loss.backward()``
+# returns every later main-stream consumer (clip_grad_norm_, all-reduce, optimizer) is ordered behind them.
+_SIDE = {}
+
+
+def side_stream_enabled() -> bool:
+    import os
+    return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def _accumulate_grad(param: torch.Tensor, g: torch.Tensor, main: torch.cuda.Stream) -> None:
+    """param.grad (+)= g on the CURRENT (side) stream."""
+    if param.grad is None:
+        g.record_stream(main)
+        param.grad = g
+    else:
+        param.grad.add_(g)
+
+
+def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+
+
 def _split_cols(W: torch.Tensor, I: int):
     """(x-half view, h-half view) of a [H, I+H] gate weight; both share W's row stride."""
     return W[:, :I], W[:, I:]
@@ -338,6 +372,7 @@ class _GruLevel(torch.autograd.Function):
             ctx.save_for_backward(x, W_z, W_r, U_r, W_h)
             ctx.stash = (X[1], Hs, Qs, Ss, Gs, Zs, Ms, Rs)
             ctx.meta = (pred, depth, I, H)
+            ctx.params = (W_z, b_z, W_r, U_r, b_u, W_h, b_h)
             return Hs[depth]
         return Hs[depth & 1]
 
@@ -361,26 +396,48 @@ class _GruLevel(torch.autograd.Function):
         dWh_x, dWh_h = _split_cols(dW_h, I)
         wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
+        use_side = side_stream_enabled() and all(getattr(p, "is_leaf", False) for p in ctx.params)
         _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
                                          _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
                                          _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(dHD),
                                          _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0), _p(dU_r), H,
-                                         _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4, _stream()),
-                   "gru_backward")
+                                         _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4,
+                                         0 if use_side else 1, _stream()), "gru_backward")
         ctx.stash = None
         ldx = _ld(x)
-        # x-halves of the gate weights and the gate biases
-        gemm(1, 0, H, I, E1, dX[0], Hp, x, ldx, dWz_x, dW_z.stride(0), I, splitk=True)
-        gemm(1, 0, H, I, E1, dX[1], Hp, x, ldx, dW_r, dW_r.stride(0), I, splitk=True)
-        gemm(1, 0, H, I, E1, dX[2], Hp, x, ldx, dWh_x, dW_h.stride(0), I, splitk=True)
-        db_z = colsum(dX[0], E1, H)
-        db_h = colsum(dX[2], E1, H)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:      # needed upstream right away: stays on the main stream
             dx = torch.empty_like(x)
             gemm(0, 0, E1, I, H, dX[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x.shape[1])
             gemm(0, 0, E1, I, H, dX[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
             gemm(0, 0, E1, I, H, dX[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
+
+        def weight_grads():
+            if use_side:
+                _lib.check(lib.ggpm_gru_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(Gs), _p(work), work.numel() * 4,
+                                                     _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),
+                                                     dW_h.stride(0), _stream()), "gru_weight_grads")
+            # x-halves of the gate weights and the gate biases
+            gemm(1, 0, H, I, E1, dX[0], Hp, x, ldx, dWz_x, dW_z.stride(0), I, splitk=True)
+            gemm(1, 0, H, I, E1, dX[1], Hp, x, ldx, dW_r, dW_r.stride(0), I, splitk=True)
+            gemm(1, 0, H, I, E1, dX[2], Hp, x, ldx, dWh_x, dW_h.stride(0), I, splitk=True)
+            return colsum(dX[0], E1, H), colsum(dX[2], E1, H)
+
+        if use_side:
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            for tns in (work, dX, Hs, Ss, x, dW_z, dW_r, dU_r, dW_h, db_u):
+                tns.record_stream(side)
+            with torch.cuda.stream(side):
+                db_z, db_h = weight_grads()
+                P_z, Pb_z, P_r, P_u, Pb_u, P_h, Pb_h = ctx.params
+                for prm, g in ((P_z, dW_z), (Pb_z, db_z), (P_r, dW_r), (P_u, dU_r), (Pb_u, db_u), (P_h, dW_h),
+                               (Pb_h, db_h)):
+                    _accumulate_grad(prm, g, main)
+            _join_later(main, side)
+            return dx, None, None, None, None, None, None, None, None, None, None, None
+        db_z, db_h = weight_grads()
         return dx, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None, None
 
 
@@ -425,6 +482,7 @@ class _LstmLevel(torch.autograd.Function):
             ctx.save_for_backward(x, W_i, W_o, W_u, W_f)
             ctx.stash = (X[3], Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
             ctx.meta = (pred, depth, I, H)
+            ctx.params = (W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f)
         c_out = Cs[k]
         ctx.mark_non_differentiable(c_out)
         return Hs[k], c_out
@@ -446,25 +504,49 @@ class _LstmLevel(torch.autograd.Function):
         dWh = [w[:, I:] for w in dWs]
         wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
+        use_side = side_stream_enabled() and all(getattr(p, "is_leaf", False) for p in ctx.params)
         _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0),
                                           _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr),
                                           _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
                                           _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]),
                                           _p(dX[3]), _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
                                           _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0), _p(work),
-                                          work.numel() * 4, _stream()), "lstm_backward")
+                                          work.numel() * 4, 0 if use_side else 1, _stream()), "lstm_backward")
         ctx.stash = None
         ldx = _ld(x)
-        dbs = []
-        for k in range(4):
-            gemm(1, 0, H, I, E1, dX[k], Hp, x, ldx, dWs[k][:, :I], dWs[k].stride(0), I, splitk=True)
-            dbs.append(colsum(dX[k], E1, H))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             for k in range(4):
                 gemm(0, 0, E1, I, H, dX[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx, x.shape[1] if k == 0 else I,
                      accumulate=k > 0)
+
+        def weight_grads():
+            if use_side:
+                _lib.check(lib.ggpm_lstm_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(work), work.numel() * 4,
+                                                      _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
+                                                      _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0),
+                                                      _stream()), "lstm_weight_grads")
+            out = []
+            for k in range(4):
+                gemm(1, 0, H, I, E1, dX[k], Hp, x, ldx, dWs[k][:, :I], dWs[k].stride(0), I, splitk=True)
+                out.append(colsum(dX[k], E1, H))
+            return out
+
+        if use_side:
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            for tns in [work, dX, Hs, Ss, x] + dWs:
+                tns.record_stream(side)
+            with torch.cuda.stream(side):
+                dbs = weight_grads()
+                for k in range(4):
+                    _accumulate_grad(ctx.params[2 * k], dWs[k], main)
+                    _accumulate_grad(ctx.params[2 * k + 1], dbs[k], main)
+            _join_later(main, side)
+            return (dx,) + (None,) * 12
+        dbs = weight_grads()
         return (dx, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3], None, None, None, None)
 
 

@@ -135,7 +135,12 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
                       const float* Gs, const float* Zs, const float* Ms, const float* Rs, const float* dHD, float* dXz,
                       float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
                       float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
-                      ggpm_stream_t stream);
+                      int weight_grads, ggpm_stream_t stream);
+/* The weight-gradient tail of ggpm_gru_backward (called with weight_grads = 0) as its own entry point, so the
+ * host may enqueue it on a second stream beside the next level's depth loop. Same `work` buffer. */
+int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs, float* work,
+                          size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
+                          float* dWh_h, int ld_dwh, ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM message function
  * LSTM.forward (ggpm/rnn.py:96-108) with LSTM.LSTM (ggpm/rnn.py:85-94), same restatement:
@@ -161,7 +166,10 @@ int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* W
                        const float* Os, const float* Us, const float* Fs, const float* dHD, float* dXi,
                        float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                        float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
-                       size_t work_bytes, ggpm_stream_t stream);
+                       size_t work_bytes, int weight_grads, ggpm_stream_t stream);
+int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work, size_t work_bytes,
+                           float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu,
+                           float* dWf_h, int ld_dwf, ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ instrumentation
  * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own
