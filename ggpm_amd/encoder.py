@@ -65,14 +65,15 @@ _RING = _PinnedRing()
 class PreparedBatch:
     """CSR structures of one tensorized batch; build once, reuse across forward calls of the same batch."""
 
-    def __init__(self, tree_tensors, graph_tensors):
+    def __init__(self, tree_tensors, graph_tensors, roots: Optional[torch.Tensor] = None):
         tfnode, tfmess, tagraph, tbgraph, tcgraph, tscope = tree_tensors
         gfnode, gfmess, gagraph, gbgraph, gscope = graph_tensors
         self.graph = LevelGraph(gfmess, gagraph, gbgraph)
         self.tree = LevelGraph(tfmess, tagraph, tbgraph, tcgraph, n_lower=gfnode.shape[0])
         self.motif_id = F_.extract_column(tfnode, 0)
         self.attach_id = F_.extract_column(tfnode, 1)
-        self.roots = _RING.upload([st for st, _ in tscope], tfnode.device)
+        # roots may be handed in as a device tensor (hipGraph capture: no host list inside the captured region)
+        self.roots = roots if roots is not None else _RING.upload([st for st, _ in tscope], tfnode.device)
 
 
 class MPNEncoder(nn.Module):
@@ -184,9 +185,10 @@ class HierMPNEncoder(nn.Module):
         return F_.linear([f, n], [H, H], self.W_root[0].weight, self.W_root[0].bias, act=F_.ACT_TANH)
 
     # ------------------------------------------------------------------ forward
-    def forward_padded(self, tree_tensors, graph_tensors, prep: Optional[PreparedBatch] = None):
+    def forward_padded(self, tree_tensors, graph_tensors, prep: Optional[PreparedBatch] = None,
+                       roots: Optional[torch.Tensor] = None):
         if prep is None:
-            prep = PreparedBatch(tree_tensors, graph_tensors)
+            prep = PreparedBatch(tree_tensors, graph_tensors, roots)
         hnode_a, hmess_a = self.embed_graph_padded(graph_tensors)
         hatom, _, _ = self.graph_encoder.forward_padded(hnode_a, hmess_a, prep.graph.agr, prep.graph.pred)
 

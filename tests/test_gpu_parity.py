@@ -207,3 +207,4 @@ def test_encoder_is_bitwise_reproducible(name):
         res.append([o.detach().clone() for o in outs] + [p.grad.clone() for p in model.parameters()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
