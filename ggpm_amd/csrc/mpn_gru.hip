@@ -16,26 +16,32 @@
 #include "tile_mma.h"
 #include <cstdlib>
 
-__global__ void ggpm_pack_weight_kernel(const float* __restrict__ W, int ldw, int H, int Hp, int transpose,
-                                        float* __restrict__ dst) {
-    const int KC = Hp / 16;
+__global__ void ggpm_pack_weight_kernel(GgpmPackArgs a) {
+    const int Hp = a.Hp, H = a.H, KC = Hp / 16;
     const int lane = threadIdx.x;            // 64
-    const int kc = blockIdx.x, t = blockIdx.y;
+    const int kc = blockIdx.x, t = blockIdx.y, m = blockIdx.z;
+    const float* __restrict__ W = a.W[m];
+    const int ldw = a.ldw[m];
     const int out = 16 * t + (lane & 15);
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = 16 * kc + 4 * (lane >> 4) + i;
         float x = 0.f;
-        if (out < H && k < H) x = transpose ? W[(size_t)k * ldw + out] : W[(size_t)out * ldw + k];
+        if (out < H && k < H) x = a.transpose ? W[(size_t)k * ldw + out] : W[(size_t)out * ldw + k];
         v[i] = x;
     }
-    ggpm_st4(dst + ggpm_pack_index(t, kc, KC, lane), make_float4(v[0], v[1], v[2], v[3]));
+    ggpm_st4(a.dst + (size_t)m * Hp * Hp + ggpm_pack_index(t, kc, KC, lane), make_float4(v[0], v[1], v[2], v[3]));
+    // optional bias pad (once, by the first block row of matrix 0)
+    if (a.bias && m == 0 && t == 0 && kc * 64 + lane < Hp) {
+        const int c = kc * 64 + lane;
+        a.bias_out[c] = (c < H) ? a.bias[c] : 0.f;
+    }
 }
 
-void ggpm_launch_pack(const float* W, int ldw, int H, int Hp, int transpose, float* dst, hipStream_t s) {
-    dim3 grid(Hp / 16, Hp / 16);
-    ggpm_pack_weight_kernel<<<grid, 64, 0, s>>>(W, ldw, H, Hp, transpose, dst);
+void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s) {
+    dim3 grid(a.Hp / 16, a.Hp / 16, nmat);
+    ggpm_pack_weight_kernel<<<grid, 64, 0, s>>>(a);
 }
 
 namespace {
@@ -456,10 +462,12 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
     float* pWz = wpack; float* pWh = wpack + HH; float* pUr = wpack + 2 * HH; float* pbu = wpack + 3 * HH;
-    ggpm_launch_pack(Wz_h, ld_wz, H, Hp, 0, pWz, s);
-    ggpm_launch_pack(Wh_h, ld_wh, H, Hp, 0, pWh, s);
-    ggpm_launch_pack(Ur, ld_ur, H, Hp, 0, pUr, s);
-    pad_bias<<<ggpm_ceil_div(Hp, 256), 256, 0, s>>>(bu, H, Hp, pbu);
+    {
+        GgpmPackArgs pk = {};
+        pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = bu; pk.bias_out = pbu;
+        ggpm_launch_pack(pk, 3, s);
+    }
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
     gru_init_state<<<ig, 256, 0, s>>>(Hs, Qs, pbu, E1, Hp);
 
@@ -535,9 +543,12 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
 
-    ggpm_launch_pack(Wz_h, ld_wz, H, Hp, 1, pWzT, s);
-    ggpm_launch_pack(Wh_h, ld_wh, H, Hp, 1, pWhT, s);
-    ggpm_launch_pack(Ur, ld_ur, H, Hp, 1, pUrT, s);
+    {
+        GgpmPackArgs pk = {};
+        pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWzT; pk.bias = nullptr; pk.bias_out = nullptr;
+        ggpm_launch_pack(pk, 3, s);
+    }
     (void)hipMemsetAsync(dXz, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXh, 0, slot * sizeof(float), s);

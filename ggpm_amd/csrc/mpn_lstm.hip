@@ -430,10 +430,13 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
     float* pWi = wpack; float* pWo = wpack + HH; float* pWu = wpack + 2 * HH; float* pWf = wpack + 3 * HH;
-    ggpm_launch_pack(Wi_h, ld_wi, H, Hp, 0, pWi, s);
-    ggpm_launch_pack(Wo_h, ld_wo, H, Hp, 0, pWo, s);
-    ggpm_launch_pack(Wu_h, ld_wu, H, Hp, 0, pWu, s);
-    ggpm_launch_pack(Wf_h, ld_wf, H, Hp, 0, pWf, s);
+    {
+        GgpmPackArgs pk = {};
+        pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
+        pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = nullptr; pk.bias_out = nullptr;
+        ggpm_launch_pack(pk, 4, s);
+    }
     (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(Qs, 0, slot * sizeof(float), s);
@@ -508,10 +511,13 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
 
-    ggpm_launch_pack(Wi_h, ld_wi, H, Hp, 1, pWiT, s);
-    ggpm_launch_pack(Wo_h, ld_wo, H, Hp, 1, pWoT, s);
-    ggpm_launch_pack(Wu_h, ld_wu, H, Hp, 1, pWuT, s);
-    ggpm_launch_pack(Wf_h, ld_wf, H, Hp, 1, pWfT, s);
+    {
+        GgpmPackArgs pk = {};
+        pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
+        pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWiT; pk.bias = nullptr; pk.bias_out = nullptr;
+        ggpm_launch_pack(pk, 4, s);
+    }
     (void)hipMemsetAsync(dXi, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXo, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXu, 0, slot * sizeof(float), s);

@@ -135,11 +135,19 @@ __device__ __forceinline__ void ggpm_load_rows_to_lds(const float* __restrict__ 
     }
 }
 
-// Pack W (or W^T) into fragment order, zero padded to Hp x Hp.
+// Pack up to 4 gate matrices W (or W^T) into fragment order, zero padded to Hp x Hp, in ONE launch
+// (blockIdx.z = matrix; matrix m lands at dst + m*Hp*Hp); optionally pads one bias vector to Hp.
 //   src(out, k) = transpose ? W[k*ldw + out] : W[out*ldw + k]     for out, k < H
-__global__ void ggpm_pack_weight_kernel(const float* __restrict__ W, int ldw, int H, int Hp, int transpose,
-                                        float* __restrict__ dst);
-void ggpm_launch_pack(const float* W, int ldw, int H, int Hp, int transpose, float* dst, hipStream_t s);
+struct GgpmPackArgs {
+    const float* W[4];
+    int ldw[4];
+    int H, Hp, transpose;
+    float* dst;
+    const float* bias;
+    float* bias_out;
+};
+__global__ void ggpm_pack_weight_kernel(GgpmPackArgs a);
+void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s);
 // Output tiles per column group of the depth-step kernels for a level of E1 messages and NT = Hp/16 tiles.
 // One 16-wave workgroup fits a CU at a time, so the grid is kept at <= ~256 workgroups: big levels use ONE
 // group (no redundant gathers; waves loop over tiles wave, wave+16, ...), small levels split the columns so

@@ -6,8 +6,8 @@ batch are disjoint graphs (ggpm/mol_graph.py:247-250) and the losses are means o
 parameters and the only exchange is ONE sum of the flat gradient per step, before clipping/Adam
 (vae_train.py:82-83) so that every rank applies the same update.
 
-All parameter gradients live in a single flat fp32 buffer (``p.grad`` are views into it): the all-reduce
-is one collective of ~18-20 MB at H=300 with no packing copies, and ``zero_grad`` is one memset.
+All parameter gradients are packed into a single flat fp32 buffer by one multi-tensor copy: the all-reduce
+is ONE collective of ~18-20 MB at H=300, and afterwards ``p.grad`` are views into the reduced buffer.
 Works with any torch.distributed backend ("nccl" = RCCL on ROCm, "gloo" for the CPU tests).
 """
 from __future__ import annotations
@@ -24,43 +24,58 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
 
 
 class FlatGradSync:
-    """Flat gradient buffer + averaged all-reduce for a replicated module."""
+    """Flat gradient buffer + averaged all-reduce for a replicated module.
+
+    ``zero_grad()`` drops the gradients (``p.grad = None``) so that backward ASSIGNS fresh gradient tensors
+    instead of launching one accumulate kernel per parameter; ``all_reduce()`` packs them into the flat buffer
+    with one multi-tensor copy, issues ONE collective and re-points every ``p.grad`` at its slice of the
+    reduced buffer (no unpack copy).  With a single rank nothing is packed at all.
+    """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
-        self.params = [p for p in params if p.requires_grad]
-        # tied embeddings appear once
         seen, uniq = set(), []
-        for p in self.params:
-            if id(p) not in seen:
+        for p in params:                         # tied embeddings appear once
+            if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 uniq.append(p)
         self.params = uniq
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
     def zero_grad(self) -> None:
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def check_views(self) -> None:
-        """autograd accumulates in place into an existing .grad; make sure nobody replaced the views."""
-        base = self.flat.untyped_storage().data_ptr()
-        for p in self.params:
-            if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
-                raise RuntimeError("a parameter's .grad no longer aliases the flat buffer "
-                                   "(use FlatGradSync.zero_grad(), not zero_grad(set_to_none=True))")
+        """Kept for API compatibility: gradients are (re)pointed at the flat buffer by all_reduce()."""
+        return None
+
+    def pack(self) -> None:
+        grads, views = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                grads.append(p.grad)
+                views.append(v)
+        if views:
+            torch._foreach_copy_(views, grads)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks then divide by world size (mean of per-rank batch-mean losses)."""
         if self.world_size == 1:
             return None
+        self.pack()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return work

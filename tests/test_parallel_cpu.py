@@ -40,9 +40,9 @@ def _worker(rank, world, port, q):
         sync.zero_grad()
         for b in mine[step::2]:
             model(_data(b)).pow(2).mean().backward()
-        sync.check_views()
         sync.all_reduce()
         out.append(sync.flat.clone())
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     q.put((rank, [o.numpy() for o in out], [p.detach().numpy() for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
