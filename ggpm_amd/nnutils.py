@@ -5,11 +5,17 @@ import numpy as np
 import torch
 
 is_cuda = torch.cuda.is_available()
-device = torch.device("cuda:0") if is_cuda else torch.device("cpu")
+device = torch.device("cuda:0") if is_cuda else torch.device("cpu")   # the reference's import-time choice
+
+
+def current_device() -> torch.device:
+    """The reference pins ``cuda:0`` at import (ggpm/nnutils.py:9-10); with one process per GPU the target is
+    whatever ``torch.cuda.set_device(local_rank)`` selected, which on a single GPU is the same ``cuda:0``."""
+    return torch.device("cuda", torch.cuda.current_device()) if is_cuda else torch.device("cpu")
 
 
 def to_cuda(inputs):
-    return inputs.to(device)
+    return inputs.to(current_device())
 
 
 def make_tensor(x):
