@@ -49,6 +49,9 @@ class FlatGradSync:
             off += n
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # rehearsal switch: run the pack + collective even with one rank (exercises the RCCL path on a 1-GPU box)
+        import os
+        self.force = dist.is_initialized() and os.environ.get("GGPM_FORCE_ALLREDUCE") == "1"
 
     def zero_grad(self) -> None:
         for p in self.params:
@@ -73,7 +76,7 @@ class FlatGradSync:
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks then divide by world size (mean of per-rank batch-mean losses)."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return None
         self.pack()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
