@@ -3,7 +3,7 @@
 Host side: Python mirror of the reference's classes (rnn.GRU/LSTM, encoder.MPNEncoder/HierMPNEncoder);
 device side: hand-written HIP kernels behind the C ABI in include/ggpm_hip.h (ggpm_amd/libggpm_hip.so).
 """
-__all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "HierEncoderVAE", "rsample", "make_cuda"]
+__all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "HierEncoderVAE", "rsample", "make_cuda"]
 
 
 def __getattr__(name):
@@ -11,7 +11,7 @@ def __getattr__(name):
     if name in ("GRU", "LSTM"):
         from . import rnn
         return getattr(rnn, name)
-    if name in ("MPNEncoder", "HierMPNEncoder", "PreparedBatch"):
+    if name in ("MPNEncoder", "HierMPNEncoder", "MotifEncoder", "PreparedBatch"):
         from . import encoder
         return getattr(encoder, name)
     if name in ("HierEncoderVAE", "rsample"):

@@ -205,3 +205,56 @@ class HierMPNEncoder(nn.Module):
         H = self.hidden_size
         outs = self.forward_padded(tree_tensors, graph_tensors, prep)
         return tuple(o[:, :H] for o in outs)
+
+
+class MotifEncoder(nn.Module):
+    """reference ggpm/encoder.py:252-341 (tree-only models 'prop' / 'prop-opt', ggpm/opvnet.py:4-9).
+
+    ``forward(tree_tensors) -> (root, node)``; one motif-level MPNEncoder on
+    ``hmess = [E_i(attachment)[src] | onehot(position)]`` with the motif embedding as node feature
+    (which, as in the reference, requires ``embed_size == hidden_size``).
+    """
+
+    def __init__(self, vocab, avocab, rnn_type, embed_size, hidden_size, depthT, depthG, dropout):
+        super().__init__()
+        self.vocab = vocab
+        self.hidden_size = hidden_size
+        self.embed_size = embed_size
+        self.dropout = dropout
+        self.atom_size = avocab.size()
+        self.bond_size = NUM_BOND_TYPES + MAX_POS
+        self.E_c = nn.Sequential(nn.Embedding(vocab.size()[0], embed_size), nn.Dropout(dropout))
+        self.E_i = nn.Sequential(nn.Embedding(vocab.size()[1], embed_size), nn.Dropout(dropout))
+        self.W_root = nn.Sequential(nn.Linear(hidden_size * 2, hidden_size), nn.Tanh())
+        self.E_a = to_cuda(torch.eye(self.atom_size))
+        self.E_pos = to_cuda(torch.eye(MAX_POS))
+        self.tree_encoder = MPNEncoder(rnn_type, hidden_size + MAX_POS, hidden_size, hidden_size, depthT, dropout)
+
+    def tie_embedding(self, other):
+        self.E_c, self.E_i = other.E_c, other.E_i
+        self.E_a = other.E_a
+
+    def forward_padded(self, tree_tensors):
+        H, He = self.hidden_size, self.embed_size
+        tfnode, tfmess, tagraph, tbgraph = tree_tensors[:4]
+        lvl = LevelGraph(tfmess, tagraph, tbgraph)
+        motif_id, attach_id = F_.extract_column(tfnode, 0), F_.extract_column(tfnode, 1)
+        roots = _RING.upload([st for st, _ in tree_tensors[-1]], tfnode.device)
+        ec, ei = self.E_c[0].weight, self.E_i[0].weight
+        hnode = F_.gather_rows(ec, motif_id, F_.csr_from_index(motif_id, ncols=ec.shape[0]), He, F_.padded_hidden(He))
+        hnode = self.E_c[1](hnode)
+        hatt = F_.gather_rows(ei, attach_id, F_.csr_from_index(attach_id, ncols=ei.shape[0]), He, F_.padded_hidden(He))
+        hatt = self.E_i[1](hatt)
+        ld = (H + MAX_POS + 3) // 4 * 4
+        hmess = F_.tree_message_input(hatt, lvl.src, lvl.src_csr, lvl.attr0, H, MAX_POS, ld)
+        node, _, nei = self.tree_encoder.forward_padded(hnode, hmess, lvl.agr, lvl.pred)
+        rcsr = F_.csr_from_index(roots, ncols=hnode.shape[0])
+        f = F_.gather_rows(hnode, roots, rcsr, H, F_.padded_hidden(H))
+        n = F_.gather_rows(nei, roots, rcsr, H, F_.padded_hidden(H))
+        root = F_.linear([f, n], [H, H], self.W_root[0].weight, self.W_root[0].bias, act=F_.ACT_TANH)
+        return root, node
+
+    def forward(self, tree_tensors):
+        H = self.hidden_size
+        root, node = self.forward_padded(tree_tensors)
+        return root[:, :H], node[:, :H]

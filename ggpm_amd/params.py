@@ -52,6 +52,19 @@ def encoder_param_shapes(rnn_type: str, hidden: int, n_motif: int, n_attach: int
     return s
 
 
+def motif_encoder_param_shapes(rnn_type: str, hidden: int, n_motif: int, n_attach: int):
+    """MotifEncoder (reference ggpm/encoder.py:252-341): embeddings + W_root + one tree-level MPNEncoder."""
+    H = hidden
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["E_c.0.weight"] = (n_motif, H)
+    s["E_i.0.weight"] = (n_attach, H)
+    s["W_root.0.weight"] = (H, 2 * H); s["W_root.0.bias"] = (H,)
+    s["tree_encoder.W_o.0.weight"] = (H, 2 * H); s["tree_encoder.W_o.0.bias"] = (H,)
+    for k, v in rnn_param_shapes(rnn_type, H + MAX_POS, H).items():
+        s["tree_encoder.rnn." + k] = v
+    return s
+
+
 def vae_head_shapes(hidden: int, latent: int):
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["R_mean.weight"] = (latent, hidden); s["R_mean.bias"] = (latent,)

@@ -188,6 +188,18 @@ def hier_encoder_forward(p: Params, rnn_type: str, depthT: int, depthG: int, tre
     return hroot, hnode, hinter, hatom
 
 
+# ---------------------------------------------------------------- MotifEncoder (ggpm/encoder.py:252-341)
+def motif_encoder_forward(p: Params, rnn_type: str, depthT: int, tree_tensors):
+    """MotifEncoder.embed_tree / forward -- ggpm/encoder.py:299-341. Returns (root, node)."""
+    fnode, fmess, agraph, bgraph = tree_tensors[:4]
+    hnode = p["E_c.0.weight"].index_select(0, fnode[:, 0])
+    hatt = p["E_i.0.weight"].index_select(0, fnode[:, 1])
+    hmess = torch.cat([hatt.index_select(0, fmess[:, 0]), _eye(MAX_POS, hnode).index_select(0, fmess[:, 2])], dim=-1)
+    node, mess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, hnode, hmess, agraph, bgraph)
+    root = embed_root(p, mess, (hnode, hmess, agraph, bgraph), [st for st, _ in tree_tensors[-1]])
+    return root, node
+
+
 # ---------------------------------------------------------------- KL (ggpm/property_vae.py:26-33)
 def rsample_kl(p: Params, hroot: Tensor, pre_mean: str = "R_mean", pre_var: str = "R_var",
                eps: Tensor | None = None) -> Tuple[Tensor, Tensor]:

@@ -5,14 +5,17 @@ import os
 import numpy as np
 import torch
 
-from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+from ggpm_amd.params import (encoder_param_shapes, vae_head_shapes, seeded_state_dict,
+                             motif_encoder_param_shapes)
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 N_PROBE = 64
 
 
-def case_names(prefix=""):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+def case_names(prefix="", motif=False):
+    """HierMPNEncoder fixtures by default; ``motif=True`` lists the MotifEncoder fixtures instead."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in names if n.startswith("motif_") == motif]
 
 
 class Golden:
@@ -46,8 +49,11 @@ class Golden:
         return tree, graph
 
     def params(self, dtype=torch.float32, device="cpu", requires_grad=False):
-        sd = seeded_state_dict(encoder_param_shapes(self.rnn, self.H, self.n_motif, self.n_attach), self.seed)
-        sd.update(seeded_state_dict(vae_head_shapes(self.H, self.latent), self.seed + 7))
+        if self.name.startswith("motif_"):
+            sd = seeded_state_dict(motif_encoder_param_shapes(self.rnn, self.H, self.n_motif, self.n_attach), self.seed)
+        else:
+            sd = seeded_state_dict(encoder_param_shapes(self.rnn, self.H, self.n_motif, self.n_attach), self.seed)
+            sd.update(seeded_state_dict(vae_head_shapes(self.H, self.latent), self.seed + 7))
         out = {}
         for k, v in sd.items():
             t = torch.from_numpy(v).to(dtype).to(device)

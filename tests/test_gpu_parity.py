@@ -208,3 +208,23 @@ def test_encoder_is_bitwise_reproducible(name):
     for a, b in zip(*res):
         assert torch.equal(a, b)
 
+
+
+@pytest.mark.parametrize("name", case_names(motif=True))
+def test_motif_encoder_matches_reference_golden(name):
+    """MotifEncoder drop-in (reference ggpm/encoder.py:252-341) vs vectors produced by the reference itself."""
+    from ggpm_amd.encoder import MotifEncoder
+    from ggpm_amd.nnutils import make_cuda
+    g = Golden(name)
+    enc = MotifEncoder(_Vocab((g.n_motif, g.n_attach)), _Vocab(38), g.rnn, g.H, g.H, g.depthT, g.depthT, 0.0).to(_dev())
+    enc.load_state_dict(g.params(), strict=True)
+    tree, _ = make_cuda(g.numpy_tensors())
+    root, node = enc(tree)
+    c = g.loss_coeffs([tuple(root.shape), tuple(node.shape)])
+    loss = (torch.from_numpy(c[0]).to(_dev()) * root).sum() + (torch.from_numpy(c[1]).to(_dev()) * node).sum()
+    loss.backward()
+    assert rel_err(root.detach().cpu().numpy(), g.z["root"]) < TOL
+    assert rel_err(node.detach().cpu().numpy(), g.z["node"]) < TOL
+    assert abs(float(loss.detach()) - float(g.z["loss"])) <= TOL * max(1.0, abs(float(g.z["loss"])))
+    for k, v in enc.named_parameters():
+        g.check_grad(k, v.grad.cpu().numpy(), rel=TOL)

@@ -70,3 +70,19 @@ def test_oracle_fp64_matches_reference_fp64(name):
     for k, v in p.items():
         grad = v.grad if v.grad is not None else torch.zeros_like(v)
         g.check_grad(k, grad.numpy(), rel=2e-7, tag="_f64")
+
+
+@pytest.mark.parametrize("name", case_names(motif=True))
+def test_oracle_motif_encoder_matches_reference(name):
+    """MotifEncoder: oracle restatement vs the reference's outputs and gradients."""
+    g = Golden(name)
+    p = g.params(requires_grad=True)
+    tree, _ = g.tensors()
+    root, node = ref.motif_encoder_forward(p, g.rnn, g.depthT, tree)
+    c = g.loss_coeffs([tuple(root.shape), tuple(node.shape)])
+    loss = (torch.from_numpy(c[0]) * root).sum() + (torch.from_numpy(c[1]) * node).sum()
+    loss.backward()
+    assert rel_err(root.detach().numpy(), g.z["root"]) <= 2e-5
+    assert rel_err(node.detach().numpy(), g.z["node"]) <= 2e-5
+    for k, v in p.items():
+        g.check_grad(k, v.grad.numpy(), rel=5e-5)
