@@ -228,3 +228,68 @@ def test_motif_encoder_matches_reference_golden(name):
     assert abs(float(loss.detach()) - float(g.z["loss"])) <= TOL * max(1.0, abs(float(g.z["loss"])))
     for k, v in enc.named_parameters():
         g.check_grad(k, v.grad.cpu().numpy(), rel=TOL)
+
+
+def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, grad_keys=()):
+    """Full encoder on a synthetic batch: HIP path vs the oracle (fp32, same weights)."""
+    from ggpm_amd import synth
+    from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+    from ggpm_amd.property_vae import HierEncoderVAE
+    from oracle import ref_encoder as ref
+    tree, graph = synth.tensorize(specs)
+    sd = seeded_state_dict(encoder_param_shapes(rnn, H, n_motif, n_attach), 5)
+    sd.update(seeded_state_dict(vae_head_shapes(H, latent), 6))
+
+    class A:
+        pass
+    a = A()
+    a.vocab, a.atom_vocab = _Vocab((n_motif, n_attach)), _Vocab(38)
+    a.rnn_type, a.embed_size, a.hidden_size = rnn, H, H
+    a.depthT = a.depthG = depth
+    a.dropout, a.latent_size = 0.0, latent
+    model = HierEncoderVAE(a).to(_dev())
+    model.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
+    z, kl, outs = model((tree, graph), perturb_z=False)
+    (kl + sum((o * o).sum() for o in outs)).backward()
+
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
+    routs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
+    _, rkl = ref.rsample_kl(p, routs[0])
+    (rkl + sum((o * o).sum() for o in routs)).backward()
+    for name, o, r in zip(("hroot", "hnode", "hinter", "hatom"), outs, routs):
+        assert rel_err(o.detach().cpu().numpy(), r.detach().numpy()) < TOL, name
+    assert abs(float(kl.detach()) - float(rkl.detach())) <= TOL * max(1.0, abs(float(rkl.detach())))
+    got = dict(model.named_parameters())
+    for k in grad_keys:
+        assert rel_err(got["encoder." + k].grad.cpu().numpy(), p[k].grad.numpy()) < TOL, k
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+def test_full_config2_batch_matches_oracle(rnn):
+    """BASELINE configs[1] at full size (32 molecules, ~38 atoms, H=300, depth 20) against the oracle."""
+    from ggpm_amd import synth
+    specs = synth.random_batch(4242, 32, motifs=(8, 12), n_motif_vocab=500, n_attach_vocab=1500)
+    keys = ["graph_encoder.rnn.W_z.weight", "tree_encoder.W_o.0.weight", "E_i.0.weight", "W_root.0.bias"] if rnn == "GRU" \
+        else ["graph_encoder.rnn.W_f.0.weight", "inter_encoder.rnn.W.0.bias", "E_c.0.weight", "W_i.0.weight"]
+    _oracle_vs_hip(rnn, 300, 20, specs, 500, 1500, latent=32, grad_keys=keys)
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+def test_large_hidden_polymers_match_oracle(rnn):
+    """configs[4] shape class: hidden 600 (Hp = 608, three LDS tiles of 16 rows), ~200-atom molecules."""
+    from ggpm_amd import synth
+    specs = synth.random_batch(77, 3, motifs=(40, 50), n_motif_vocab=60, n_attach_vocab=180)
+    _oracle_vs_hip(rnn, 600, 3, specs, 60, 180,
+                   grad_keys=["graph_encoder.rnn.U_r.weight" if rnn == "GRU" else "graph_encoder.rnn.W_o.0.weight"])
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+def test_ragged_and_degenerate_molecules(rnn):
+    """Edge cases of the layout: single-motif molecules (a tree level with NO messages at all), mixed sizes."""
+    from ggpm_amd import synth
+    only_single = synth.random_batch(9, 3, motifs=(1, 1), n_motif_vocab=11, n_attach_vocab=33)
+    _oracle_vs_hip(rnn, 24, 3, only_single, 11, 33, grad_keys=["W_root.0.weight"])
+    ragged = synth.random_batch(10, 2, motifs=(1, 1), n_motif_vocab=11, n_attach_vocab=33) + \
+        synth.random_batch(11, 3, motifs=(9, 14), n_motif_vocab=11, n_attach_vocab=33)
+    _oracle_vs_hip(rnn, 24, 4, ragged, 11, 33, grad_keys=["graph_encoder.W_o.0.weight", "E_c.0.weight"])
