@@ -38,12 +38,19 @@ SIGNATURES = {
     "ggpm_gru_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               P, I, P, I, P, P, I, P, c_size_t, I, P]),
     "ggpm_gru_weight_grads": (I, [I, I, I, P, P, P, P, c_size_t, P, I, P, I, P, P, I, P]),
+    "ggpm_gru_sparse_forward": (I, [I, I, I, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                     P, I, P, I, P, P, I, P, c_size_t, P]),
     "ggpm_lstm_pack_floats": (c_size_t, [I]),
     "ggpm_lstm_forward": (I, [I, I, I, P, P, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_lstm_backward_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_lstm_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, I, P]),
     "ggpm_lstm_weight_grads": (I, [I, I, I, P, P, P, c_size_t, P, I, P, I, P, I, P, I, P]),
+    "ggpm_lstm_sparse_forward": (I, [I, I, I, P, P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P,
+                                     P, I, P]),
+    "ggpm_lstm_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                      P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
     "ggpm_timing_enable": (I, [I]),
     "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
 }

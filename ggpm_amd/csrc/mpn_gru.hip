@@ -59,6 +59,7 @@ struct GruFwdArgs {
     const float* bu;               // [Hp] zero padded
     const int32_t *rowptr, *col;
     int ablate;                    // timing experiments only (GGPM_ABLATE): 1 no gather, 2 no GEMM
+    const unsigned char* frozen;   // sparse_forward only: rows with frozen[row] != 0 keep their state (h' = h)
 };
 
 __global__ void gru_init_state(float* __restrict__ H0, float* __restrict__ Q0, const float* __restrict__ bu,
@@ -171,7 +172,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         }
         if (row >= a.E1) continue;
         float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
-        if (row != 0) {
+        if (a.frozen && a.frozen[row]) {
+            h = ggpm_ld4(a.Hprev + o);             // z = m = 0 in the stash => the backward passes dh through
+        } else if (row != 0 || a.frozen) {
             const float4 s = ggpm_ld4(Ts + lr * LD + c);
             const float4 pz = ggpm_f4(acc[0][0]) + xz, pm = ggpm_f4(acc[1][0]) + xh;
             z = ggpm_sigmoid4(pz);
@@ -229,6 +232,12 @@ struct GruBwdArgs {
     float *dXz, *dXr, *dXh;        // running sums (zeroed by the driver)
     const float *WzT, *WhT, *UrT;  // packed transposes
     const int32_t *srowptr, *scol; // successors
+    // sparse_forward only: frozen rows pass their gradient straight through the depth loop (carry), and a final
+    // gather-only launch (t = 0) yields the gradient of the incoming state for them.
+    const unsigned char* frozen;
+    float* carry;                  // [E1,Hp] running dh of frozen rows (zeroed by the driver)
+    int final_pass;                // t == 0: P1 + dq.U_r only, result to dHin
+    float* dHin;                   // [E1,Hp]
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
@@ -309,9 +318,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        const float4 s = ggpm_ld4(a.S + o), z = ggpm_ld4(a.Z + o), m = ggpm_ld4(a.M + o);
+        float4 s = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4(), oxz = ggpm_zero4(), oxh = ggpm_zero4();
+        if (!a.final_pass) {
+            s = ggpm_ld4(a.S + o); z = ggpm_ld4(a.Z + o); m = ggpm_ld4(a.M + o);
+            oxz = ggpm_ld4(a.dXz + o); oxh = ggpm_ld4(a.dXh + o);
+        }
         const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-        const float4 oxz = ggpm_ld4(a.dXz + o), oxh = ggpm_ld4(a.dXh + o);
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
@@ -320,9 +332,21 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
         if (row >= a.E1) continue;
+        const bool frz = a.frozen && a.frozen[row];
+        if (a.final_pass) {        // gradient of the incoming state: frozen rows only (active rows started from 0)
+            float4 dh0 = ggpm_zero4();
+            if (frz) dh0 = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c) + ggpm_ld4(a.carry + o);
+            ggpm_st4(a.dHin + o, dh0);
+            continue;
+        }
         float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
-        if (row != 0) {
-            const float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
+        if (row != 0 || a.frozen) {
+            float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
+            if (frz) {             // h_t = h_{t-1} for frozen rows: carry the whole dh to the previous depth
+                dh = dh + ggpm_ld4(a.carry + o);
+                ggpm_st4(a.carry + o, dh);
+                dh = ggpm_zero4();   // nothing flows through gates (their stash is 0 anyway)
+            }
             const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s.x, s.y, s.z, s.w};
             const float zv[4] = {z.x, z.y, z.z, z.w}, mv[4] = {m.x, m.y, m.z, m.w};
             float o_ds[4], o_dz[4], o_dm[4];
@@ -446,12 +470,22 @@ static int gru_shape_ok(int Hp) {
     return (size_t)2 * 16 * (Hp + 4) * sizeof(float) <= 160 * 1024;
 }
 
-extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
-                                const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
-                                const float* Wh_h, int ld_wh, const int32_t* pred_rowptr,
-                                const int32_t* pred_col, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs,
-                                float* Ms, float* Rs, float* wpack, int save_for_backward,
-                                ggpm_stream_t stream) {
+namespace {
+__global__ void sparse_init_state(const float* __restrict__ h_in, const unsigned char* __restrict__ frozen,
+                                  float* __restrict__ H0, int Hp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= Hp) return;
+    H0[(size_t)r * Hp + c] = frozen[r] ? h_in[(size_t)r * Hp + c] : 0.f;    // rows being recomputed start from 0
+}
+}  // namespace
+
+static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
+                            const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
+                            const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
+                            float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs,
+                            float* wpack, int save_for_backward, const float* h_in, const unsigned char* frozen,
+                            ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xz || !Xr || !Xh || !Wz_h || !Ur || !bu || !Wh_h || !pred_rowptr ||
         !pred_col || !Hs || !Qs || !wpack)
@@ -469,7 +503,18 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
         ggpm_launch_pack(pk, 3, s);
     }
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
-    gru_init_state<<<ig, 256, 0, s>>>(Hs, Qs, pbu, E1, Hp);
+    const int tg0 = pick_tg(E1, Hp / 16);
+    if (frozen) {      // sparse_forward: start from the caller's state, q^0 = U_r h^0 + b_u by one B launch
+        sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
+        GruFwdArgs a0 = {};
+        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu;
+        const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
+        dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
+        set_lds(gru_fwd_b, lds_b);
+        gru_fwd_b<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0);
+    } else {
+        gru_init_state<<<ig, 256, 0, s>>>(Hs, Qs, pbu, E1, Hp);
+    }
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
@@ -479,6 +524,7 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xz = Xz; a.Xr = Xr; a.Xh = Xh;
         a.Wz = pWz; a.Wh = pWh; a.Ur = pUr; a.bu = pbu; a.rowptr = pred_rowptr; a.col = pred_col;
         a.ablate = abl ? atoi(abl) : 0;
+        a.frozen = frozen;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
             a.Qprev = Qs + (size_t)(t - 1) * slot;
@@ -497,13 +543,34 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
     return GGPM_OK;
 }
 
+extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
+                                const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
+                                const float* Wh_h, int ld_wh, const int32_t* pred_rowptr,
+                                const int32_t* pred_col, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs,
+                                float* Ms, float* Rs, float* wpack, int save_for_backward,
+                                ggpm_stream_t stream) {
+    return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
+                            Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, nullptr, nullptr, stream);
+}
+
+extern "C" int ggpm_gru_sparse_forward(int E1, int H, int depth, const float* h_in, const unsigned char* frozen,
+                                       const float* Xz, const float* Xr, const float* Xh, const float* Wz_h,
+                                       int ld_wz, const float* Ur, int ld_ur, const float* bu, const float* Wh_h,
+                                       int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs,
+                                       float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs,
+                                       float* wpack, int save_for_backward, ggpm_stream_t stream) {
+    if (!h_in || !frozen) return GGPM_ERR_ARG;
+    return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
+                            Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, h_in, frozen, stream);
+}
+
 extern "C" size_t ggpm_gru_backward_workspace_bytes(int E1, int H, int depth) {
     const size_t Hp = (size_t)ggpm_padded_hidden(H);
     const size_t slot = (size_t)E1 * Hp;
     size_t f = 0;
     f += 2 * (size_t)depth * slot;                     // DMP, DZP
-    f += (size_t)(depth > 1 ? depth - 1 : 1) * slot;   // DQ
-    f += 5 * slot;                                     // dS/dG double buffers + ds_dir scratch
+    f += (size_t)depth * slot;                         // DQ (slot t = dq^t; slot 0 only used by sparse_forward)
+    f += 6 * slot;                                     // dS/dG double buffers + ds_dir scratch + carry
     f += 3 * Hp * Hp;                                  // packed transposes
     f += 256 * Hp;                                     // colsum scratch
     size_t bytes = f * sizeof(float);
@@ -511,7 +578,11 @@ extern "C" size_t ggpm_gru_backward_workspace_bytes(int E1, int H, int depth) {
     return bytes + 256;
 }
 
-extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
+                                 float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
+                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, ggpm_stream_t stream);
+
+static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
                                  const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
                                  const int32_t* pred_rowptr, const int32_t* pred_col,
                                  const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
@@ -519,7 +590,7 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
                                  const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr, float* dXh,
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, int weight_grads,
-                                 ggpm_stream_t stream) {
+                                 const unsigned char* frozen, float* dHin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
@@ -534,10 +605,11 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     float* w = work;
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
-    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
+    float* DQ = w; w += (size_t)depth * slot;
     float* dSb[2]; float* dGb[2];
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dGb[0] = w; w += slot; dGb[1] = w; w += slot;
     float* DSD = w; w += slot;
+    float* carry = w; w += slot;
     float* pWzT = w; w += HH; float* pWhT = w; w += HH; float* pUrT = w; w += HH;
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
@@ -552,6 +624,7 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     (void)hipMemsetAsync(dXz, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXh, 0, slot * sizeof(float), s);
+    if (frozen) (void)hipMemsetAsync(carry, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
@@ -566,26 +639,67 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
         a.dHD = dHD;
         a.dSin = dSb[(t + 1) & 1]; a.dGin = dGb[(t + 1) & 1];
         a.dSout = dSb[t & 1]; a.dGout = dGb[t & 1];
-        a.DQ = (t < depth) ? DQ + (size_t)(t - 1) * slot : nullptr;
+        a.DQ = (t < depth) ? DQ + (size_t)t * slot : nullptr;
+        a.frozen = frozen; a.carry = carry; a.final_pass = 0; a.dHin = nullptr;
         a.DMP = DMP + (size_t)(t - 1) * slot; a.DZP = DZP + (size_t)(t - 1) * slot; a.DSD = DSD;
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
         a.srowptr = succ_rowptr; a.scol = succ_col;
-        launch_bwd(a, t > 1, flops1, s);
+        launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
 
+    if (frozen) {      // gradient of the incoming state: one more gather + dq.U_r launch at t = 0
+        GruBwdArgs a = {};
+        a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = 0; a.final_pass = 1;
+        a.Xr = Xr; a.Hcur = Hs; a.Qcur = Qs;
+        a.dSin = dSb[1]; a.dGin = dGb[1];          // written by the B launch of depth 1
+        a.DQ = DQ; a.UrT = pUrT; a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.frozen = frozen; a.carry = carry; a.dHin = dHin;
+        launch_bwd(a, false, flops1, s);
+        GGPM_CHECK_LAUNCH();
+    }
     if (!weight_grads) return GGPM_OK;
-    return ggpm_gru_weight_grads(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
-                                 ld_dwh, stream);
+    return gru_weight_grads_impl(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
+                                 ld_dwh, frozen != nullptr, stream);
+}
+
+extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+                                 const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                                 const int32_t* pred_rowptr, const int32_t* pred_col,
+                                 const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
+                                 const float* Qs, const float* Ss, const float* Gs, const float* Zs,
+                                 const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr,
+                                 float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
+                                 float* dWh_h, int ld_dwh, float* work, size_t work_bytes, int weight_grads,
+                                 ggpm_stream_t stream) {
+    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
+                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
+                             dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream);
+}
+
+// sparse_forward backward: additionally returns dHin (gradient of the incoming state; zero on the recomputed rows)
+extern "C" int ggpm_gru_sparse_backward(int E1, int H, int depth, const unsigned char* frozen, const float* Xr,
+                                        const float* Wz_h, int ld_wz, const float* Ur, int ld_ur,
+                                        const float* Wh_h, int ld_wh, const int32_t* pred_rowptr,
+                                        const int32_t* pred_col, const int32_t* succ_rowptr,
+                                        const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss,
+                                        const float* Gs, const float* Zs, const float* Ms, const float* Rs,
+                                        const float* dHD, float* dHin, float* dXz, float* dXr, float* dXh,
+                                        float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
+                                        int ld_dwh, float* work, size_t work_bytes, ggpm_stream_t stream) {
+    if (!frozen || !dHin) return GGPM_ERR_ARG;
+    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
+                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
+                             dWh_h, ld_dwh, work, work_bytes, 1, frozen, dHin, stream);
 }
 
 // Weight gradients of the GRU message function: tall contractions over every (depth, message) row of the
 // stashes ggpm_gru_backward left in `work`.  Separate entry point so that the host can run them on a second
 // stream while the next level's (latency-bound) depth loop occupies the main one.
-extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
-                                     float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr,
-                                     int ld_dur, float* dbu, float* dWh_h, int ld_dwh, ggpm_stream_t stream) {
+static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
+                                 float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
+                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !Gs || !work || !dWz_h || !dUr || !dbu || !dWh_h)
         return GGPM_ERR_ARG;
@@ -596,8 +710,8 @@ extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, 
     float* w = work;
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
-    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
-    w += 5 * slot + 3 * HH;
+    float* DQ = w; w += (size_t)depth * slot;
+    w += 6 * slot + 3 * HH;
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
@@ -607,11 +721,14 @@ extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, 
     if (rc) return rc;
     rc = ggpm_gemm(1, 0, H, H, KD, DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
     if (rc) return rc;
-    if (depth > 1) {
-        const int KQ = (depth - 1) * E1;
-        rc = ggpm_gemm(1, 0, H, H, KQ, DQ, Hp, Hs + slot, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
+    if (depth > 1 || with_slot0) {
+        // dq^t pairs with h^t; the dense level never produces dq^0 (h^0 = 0), sparse_forward does
+        const int first_slot = with_slot0 ? 0 : 1;
+        const int KQ = (depth - first_slot) * E1;
+        const float* dq0 = DQ + (size_t)first_slot * slot;
+        rc = ggpm_gemm(1, 0, H, H, KQ, dq0, Hp, Hs + (size_t)first_slot * slot, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
         if (rc) return rc;
-        rc = ggpm_colsum(DQ, Hp, KQ, H, dbu, csws, stream);
+        rc = ggpm_colsum(dq0, Hp, KQ, H, dbu, csws, stream);
         if (rc) return rc;
     } else {
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
@@ -619,4 +736,11 @@ extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, 
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
+                                     float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr,
+                                     int ld_dur, float* dbu, float* dWh_h, int ld_dwh, ggpm_stream_t stream) {
+    return gru_weight_grads_impl(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
+                                 ld_dwh, false, stream);
 }

@@ -25,6 +25,7 @@ struct LstmFwdArgs {
     float *S, *I, *O, *U, *F;        // stash slot (nullptr when not saving); F = sum_p c_p f(1-f)
     const float *Wi, *Wo, *Wu, *Wf;  // packed
     const int32_t *rowptr, *col;
+    const unsigned char* frozen;     // sparse_forward only: rows that keep their (h, c)
 };
 
 __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w); }
@@ -124,7 +125,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         }
         if (row >= a.E1) continue;
         float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
-        if (row != 0) {
+        if (a.frozen && a.frozen[row]) {
+            h = ggpm_ld4(a.Hprev + o);             // gates stashed as 0 => the backward passes dh, dc through
+            cn = ggpm_ld4(a.Cprev + o);
+        } else if (row != 0 || a.frozen) {
             const float4 pi = ggpm_f4(acc[0][0]) + xi;
             const float4 po = ggpm_f4(acc[1][0]) + xo;
             const float4 pu = ggpm_f4(acc[2][0]) + xu;
@@ -186,6 +190,12 @@ struct LstmBwdArgs {
     float *dXi, *dXo, *dXu, *dXf;    // running sums (zeroed by the driver)
     const float *WiT, *WoT, *WuT, *WfT;
     const int32_t *srowptr, *scol;
+    // sparse_forward only (see mpn_gru.hip): frozen rows carry dh / dc through the loop; final gather-only launch
+    const unsigned char* frozen;
+    const float* dCD;                // gradient of c_D (sparse_forward returns the cell state too)
+    float *carry_h, *carry_c;        // [E1,Hp] each, zeroed by the driver
+    int final_pass;
+    float *dHin, *dCin;
 };
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
@@ -271,10 +281,15 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        const float4 gi = ggpm_ld4(a.I + o), go = ggpm_ld4(a.O + o), gu = ggpm_ld4(a.U + o), cc = ggpm_ld4(a.Ccur + o);
-        const float4 fco = ggpm_ld4(a.F + o);
+        float4 gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4(), cc = ggpm_zero4(), fco = ggpm_zero4();
+        float4 oxi = ggpm_zero4(), oxo = ggpm_zero4(), oxu = ggpm_zero4(), oxf = ggpm_zero4();
+        if (!a.final_pass) {
+            gi = ggpm_ld4(a.I + o); go = ggpm_ld4(a.O + o); gu = ggpm_ld4(a.U + o); cc = ggpm_ld4(a.Ccur + o);
+            fco = ggpm_ld4(a.F + o);
+            oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o); oxf = ggpm_ld4(a.dXf + o);
+        }
         const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-        const float4 oxi = ggpm_ld4(a.dXi + o), oxo = ggpm_ld4(a.dXo + o), oxu = ggpm_ld4(a.dXu + o), oxf = ggpm_ld4(a.dXf + o);
+        const float4 dcd = (a.first && a.dCD) ? ggpm_ld4(a.dCD + o) : ggpm_zero4();
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
@@ -283,11 +298,30 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
         if (row >= a.E1) continue;
+        const bool frz = a.frozen && a.frozen[row];
+        if (a.final_pass) {        // gradient of the incoming (h, c): frozen rows only
+            float4 dh0 = ggpm_zero4(), dc0 = ggpm_zero4();
+            if (frz) {
+                dh0 = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c) + ggpm_ld4(a.carry_h + o);
+                dc0 = ggpm_ld4(T2 + lr * LD + c) + ggpm_ld4(a.carry_c + o);
+            }
+            ggpm_st4(a.dHin + o, dh0);
+            ggpm_st4(a.dCin + o, dc0);
+            continue;
+        }
         float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
-        if (row != 0) {
+        if (row != 0 || a.frozen) {
             float4 dh, dc;
-            if (a.first) { dh = dhd; dc = ggpm_zero4(); }
+            if (a.first) { dh = dhd; dc = dcd; }
             else { dh = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
+            if (frz) {             // (h, c)_t = (h, c)_{t-1}: carry both gradients to the previous depth
+                dh = dh + ggpm_ld4(a.carry_h + o);
+                dc = dc + ggpm_ld4(a.carry_c + o);
+                ggpm_st4(a.carry_h + o, dh);
+                ggpm_st4(a.carry_c + o, dc);
+                dh = ggpm_zero4();
+                dc = ggpm_zero4();
+            }
             const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
             const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, ov[4] = {go.x, go.y, go.z, go.w};
             const float uv[4] = {gu.x, gu.y, gu.z, gu.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
@@ -414,12 +448,26 @@ extern "C" size_t ggpm_lstm_pack_floats(int H) {
 
 static int lstm_shape_ok(int Hp) { return lds_tiles(3, Hp) <= 160 * 1024; }
 
-extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, const float* Xo, const float* Xu,
-                                 const float* Xf, const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
-                                 const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
-                                 const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
-                                 float* Qs, float* Ss, float* Is, float* Os, float* Us, float* Fs,
-                                 float* wpack, int save_for_backward, ggpm_stream_t stream) {
+namespace {
+__global__ void lstm_sparse_init_state(const float* __restrict__ h_in, const float* __restrict__ c_in,
+                                       const unsigned char* __restrict__ frozen, float* __restrict__ H0,
+                                       float* __restrict__ C0, int Hp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= Hp) return;
+    const size_t o = (size_t)r * Hp + c;
+    H0[o] = frozen[r] ? h_in[o] : 0.f;
+    C0[o] = frozen[r] ? c_in[o] : 0.f;
+}
+}  // namespace
+
+static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const float* Xo, const float* Xu,
+                             const float* Xf, const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
+                             const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
+                             const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs, float* Qs,
+                             float* Ss, float* Is, float* Os, float* Us, float* Fs, float* wpack,
+                             int save_for_backward, const float* h_in, const float* c_in,
+                             const unsigned char* frozen, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xi || !Xo || !Xu || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h ||
         !pred_rowptr || !pred_col || !Hs || !Cs || !Qs || !wpack)
@@ -437,16 +485,28 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
         pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = nullptr; pk.bias_out = nullptr;
         ggpm_launch_pack(pk, 4, s);
     }
-    (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(Qs, 0, slot * sizeof(float), s);
-
     const int tg = pick_tg(E1, Hp / 16);
+    if (frozen) {      // sparse_forward: start from the caller's (h, c); qf^0 = Wf_h h^0 by one B launch
+        dim3 ig(ggpm_ceil_div(Hp, 256), E1);
+        lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
+        LstmFwdArgs a0 = {};
+        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf;
+        const size_t lb = lds_tiles(1, Hp);
+        dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg));
+        set_lds(lstm_fwd_b, lb);
+        lstm_fwd_b<<<grid_a, GGPM_NWA * 64, lb, s>>>(a0);
+    } else {
+        (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
+        (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);
+        (void)hipMemsetAsync(Qs, 0, slot * sizeof(float), s);
+    }
+
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     for (int t = 1; t <= depth; ++t) {
         LstmFwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;
+        a.frozen = frozen;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
             a.Cprev = Cs + (size_t)(t - 1) * slot; a.Cnew = Cs + (size_t)t * slot;
@@ -466,20 +526,49 @@ extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, cons
     return GGPM_OK;
 }
 
+extern "C" int ggpm_lstm_forward(int E1, int H, int depth, const float* Xi, const float* Xo, const float* Xu,
+                                 const float* Xf, const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
+                                 const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
+                                 const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
+                                 float* Qs, float* Ss, float* Is, float* Os, float* Us, float* Fs,
+                                 float* wpack, int save_for_backward, ggpm_stream_t stream) {
+    return lstm_forward_impl(E1, H, depth, Xi, Xo, Xu, Xf, Wi_h, ld_wi, Wo_h, ld_wo, Wu_h, ld_wu, Wf_h, ld_wf, pred_rowptr,
+                             pred_col, Hs, Cs, Qs, Ss, Is, Os, Us, Fs, wpack, save_for_backward, nullptr, nullptr,
+                             nullptr, stream);
+}
+
+extern "C" int ggpm_lstm_sparse_forward(int E1, int H, int depth, const float* h_in, const float* c_in,
+                                        const unsigned char* frozen, const float* Xi, const float* Xo,
+                                        const float* Xu, const float* Xf, const float* Wi_h, int ld_wi,
+                                        const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu,
+                                        const float* Wf_h, int ld_wf, const int32_t* pred_rowptr,
+                                        const int32_t* pred_col, float* Hs, float* Cs, float* Qs, float* Ss,
+                                        float* Is, float* Os, float* Us, float* Fs, float* wpack,
+                                        int save_for_backward, ggpm_stream_t stream) {
+    if (!h_in || !c_in || !frozen) return GGPM_ERR_ARG;
+    return lstm_forward_impl(E1, H, depth, Xi, Xo, Xu, Xf, Wi_h, ld_wi, Wo_h, ld_wo, Wu_h, ld_wu, Wf_h, ld_wf, pred_rowptr,
+                             pred_col, Hs, Cs, Qs, Ss, Is, Os, Us, Fs, wpack, save_for_backward, h_in, c_in, frozen,
+                             stream);
+}
+
 extern "C" size_t ggpm_lstm_backward_workspace_bytes(int E1, int H, int depth) {
     const size_t Hp = (size_t)ggpm_padded_hidden(H);
     const size_t slot = (size_t)E1 * Hp;
     size_t f = 0;
     f += 3 * (size_t)depth * slot;                     // DI, DO, DU
-    f += (size_t)(depth > 1 ? depth - 1 : 1) * slot;   // DQ
-    f += 4 * slot;                                     // dS / dFC double buffers
+    f += (size_t)depth * slot;                         // DQ (slot t = dqf^t; slot 0 only used by sparse_forward)
+    f += 6 * slot;                                     // dS / dFC double buffers + dh / dc carries
     f += 4 * Hp * Hp;                                  // packed transposes
     size_t bytes = f * sizeof(float);
     bytes += ggpm_gemm_workspace_bytes(H, H, depth * E1);
     return bytes + 256;
 }
 
-extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
+static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
+                                  size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h,
+                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, ggpm_stream_t stream);
+
+static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
                                   const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
                                   int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col,
                                   const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
@@ -488,7 +577,8 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
                                   float* dXo,
                                   float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                                   float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
-                                  size_t work_bytes, int weight_grads, ggpm_stream_t stream) {
+                                  size_t work_bytes, int weight_grads, const unsigned char* frozen,
+                                  const float* dCD, float* dHin, float* dCin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Cs || !Qs || !Ss || !Is || !Os || !Us || !Fs || !dHD || !dXi || !dXo || !dXu ||
@@ -504,9 +594,10 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
-    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
+    float* DQ = w; w += (size_t)depth * slot;
     float* dSb[2]; float* dFb[2];
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dFb[0] = w; w += slot; dFb[1] = w; w += slot;
+    float* carry_h = w; w += slot; float* carry_c = w; w += slot;
     float* pWiT = w; w += HH; float* pWoT = w; w += HH; float* pWuT = w; w += HH; float* pWfT = w; w += HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
@@ -522,6 +613,10 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
     (void)hipMemsetAsync(dXo, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXu, 0, slot * sizeof(float), s);
     (void)hipMemsetAsync(dXf, 0, slot * sizeof(float), s);
+    if (frozen) {
+        (void)hipMemsetAsync(carry_h, 0, slot * sizeof(float), s);
+        (void)hipMemsetAsync(carry_c, 0, slot * sizeof(float), s);
+    }
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
@@ -536,24 +631,70 @@ extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, con
         a.dHD = dHD;
         a.dSin = dSb[(t + 1) & 1]; a.dFCin = dFb[(t + 1) & 1];
         a.dSout = dSb[t & 1]; a.dFCout = dFb[t & 1];
-        a.DQ = (t < depth) ? DQ + (size_t)(t - 1) * slot : nullptr;
+        a.DQ = (t < depth) ? DQ + (size_t)t * slot : nullptr;
+        a.frozen = frozen; a.dCD = dCD; a.carry_h = carry_h; a.carry_c = carry_c; a.final_pass = 0;
+        a.dHin = nullptr; a.dCin = nullptr;
         a.DI = DI + (size_t)(t - 1) * slot; a.DO = DO + (size_t)(t - 1) * slot; a.DU = DU + (size_t)(t - 1) * slot;
         a.dXi = dXi; a.dXo = dXo; a.dXu = dXu; a.dXf = dXf;
         a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT;
         a.srowptr = succ_rowptr; a.scol = succ_col;
-        launch_bwd(a, t > 1, flops1, s);
+        launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
+    if (frozen) {      // gradient of the incoming (h, c): one more gather + dqf.Wf_h launch at t = 0
+        LstmBwdArgs a = {};
+        a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = 0; a.final_pass = 1;
+        a.Xf = Xf; a.Ccur = Cs; a.Qcur = Qs;
+        a.dSin = dSb[1]; a.dFCin = dFb[1];          // written by the launches of depth 1
+        a.DQ = DQ; a.WfT = pWfT; a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.frozen = frozen; a.carry_h = carry_h; a.carry_c = carry_c; a.dHin = dHin; a.dCin = dCin;
+        launch_bwd(a, false, flops1, s);
+        GGPM_CHECK_LAUNCH();
+    }
 
     if (!weight_grads) return GGPM_OK;
-    return ggpm_lstm_weight_grads(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
-                                  dWf_h, ld_dwf, stream);
+    return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
+                                  dWf_h, ld_dwf, frozen != nullptr, stream);
+}
+
+extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
+                                  const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
+                                  int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col,
+                                  const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
+                                  const float* Cs, const float* Qs, const float* Ss, const float* Is,
+                                  const float* Os, const float* Us, const float* Fs, const float* dHD, float* dXi,
+                                  float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h,
+                                  int ld_dwo, float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
+                                  size_t work_bytes, int weight_grads, ggpm_stream_t stream) {
+    return lstm_backward_impl(E1, H, depth, Xf, Wi_h, ld_wi, Wo_h, ld_wo, Wu_h, ld_wu, Wf_h, ld_wf, pred_rowptr, pred_col,
+                              succ_rowptr, succ_col, Hs, Cs, Qs, Ss, Is, Os, Us, Fs, dHD, dXi, dXo, dXu, dXf, dWi_h, ld_dwi,
+                              dWo_h, ld_dwo, dWu_h, ld_dwu, dWf_h, ld_dwf, work, work_bytes, weight_grads, nullptr, nullptr,
+                              nullptr, nullptr, stream);
+}
+
+// sparse_forward backward: takes dL/dh_D and dL/dc_D, additionally returns dHin / dCin (zero on the recomputed rows)
+extern "C" int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* frozen, const float* Xf,
+                                         const float* Wi_h, int ld_wi, const float* Wo_h, int ld_wo,
+                                         const float* Wu_h, int ld_wu, const float* Wf_h, int ld_wf,
+                                         const int32_t* pred_rowptr, const int32_t* pred_col,
+                                         const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
+                                         const float* Cs, const float* Qs, const float* Ss, const float* Is,
+                                         const float* Os, const float* Us, const float* Fs, const float* dHD,
+                                         const float* dCD, float* dHin, float* dCin, float* dXi, float* dXo,
+                                         float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                                         float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
+                                         size_t work_bytes, ggpm_stream_t stream) {
+    if (!frozen || !dHin || !dCin) return GGPM_ERR_ARG;
+    return lstm_backward_impl(E1, H, depth, Xf, Wi_h, ld_wi, Wo_h, ld_wo, Wu_h, ld_wu, Wf_h, ld_wf, pred_rowptr, pred_col,
+                              succ_rowptr, succ_col, Hs, Cs, Qs, Ss, Is, Os, Us, Fs, dHD, dXi, dXo, dXu, dXf, dWi_h, ld_dwi,
+                              dWo_h, ld_dwo, dWu_h, ld_dwu, dWf_h, ld_dwf, work, work_bytes, 1, frozen, dCD, dHin, dCin,
+                              stream);
 }
 
 // Weight gradients of the LSTM message function from the stashes ggpm_lstm_backward left in `work`.
-extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
-                                      size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
-                                      float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, ggpm_stream_t stream) {
+static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
+                                  size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h,
+                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !work || !dWi_h || !dWo_h || !dWu_h || !dWf_h)
         return GGPM_ERR_ARG;
@@ -565,8 +706,8 @@ extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs,
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
-    float* DQ = w; w += (size_t)(depth > 1 ? depth - 1 : 1) * slot;
-    w += 4 * slot + 4 * HH;
+    float* DQ = w; w += (size_t)depth * slot;
+    w += 6 * slot + 4 * HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = depth * E1;
@@ -577,13 +718,21 @@ extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs,
     if (rc) return rc;
     rc = ggpm_gemm(1, 0, H, H, KD, DU, Hp, Ss, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
     if (rc) return rc;
-    if (depth > 1) {
-        const int KQ = (depth - 1) * E1;
-        rc = ggpm_gemm(1, 0, H, H, KQ, DQ, Hp, Hs + slot, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
+    if (depth > 1 || with_slot0) {
+        const int first_slot = with_slot0 ? 0 : 1;     // dqf^t pairs with h^t; slot 0 exists for sparse_forward only
+        const int KQ = (depth - first_slot) * E1;
+        rc = ggpm_gemm(1, 0, H, H, KQ, DQ + (size_t)first_slot * slot, Hp, Hs + (size_t)first_slot * slot, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
         if (rc) return rc;
     } else {
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
+                                      size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                                      float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, ggpm_stream_t stream) {
+    return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
+                                  dWf_h, ld_dwf, false, stream);
 }

@@ -445,6 +445,216 @@ def gru_level(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred: CSR, depth: int, I: in
     return _GruLevel.apply(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H)
 
 
+def _as_padded_state(h: torch.Tensor, H: int, Hp: int) -> torch.Tensor:
+    """[E, H] public state -> [E, Hp] buffer with zero pad columns (no copy when it already is a view of one)."""
+    if h.dim() == 2 and h.shape[1] == H and h.stride(1) == 1 and h.stride(0) == Hp and Hp != H \
+            and h.storage_offset() % Hp == 0:
+        return h.as_strided((h.shape[0], Hp), (Hp, 1), h.storage_offset())     # our own earlier output
+    if Hp == H:
+        return h.contiguous()
+    out = torch.zeros(h.shape[0], Hp, dtype=h.dtype, device=h.device)
+    out[:, :H] = h
+    return out
+
+
+def _scatter_rows(full_rows: int, sub: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """zeros([full_rows, ...]) with rows `index` := sub (the subset tensors of get_sub_tensor back in place)."""
+    out = torch.zeros((full_rows,) + tuple(sub.shape[1:]), dtype=sub.dtype, device=sub.device)
+    out.index_copy_(0, index, sub)
+    return out
+
+
+class _GruSparse(torch.autograd.Function):
+    """GRU.sparse_forward (ggpm/rnn.py:52-59): recompute the rows `submess` of the message state `depth` times."""
+
+    @staticmethod
+    def forward(ctx, h_in, x_sub, submess, bgraph_sub, W_z, b_z, W_r, U_r, b_u, W_h, b_h, depth, I, H):
+        _need_gpu(h_in, x_sub, submess, bgraph_sub, W_z)
+        lib = _lib.load()
+        E1, Hp, ms = h_in.shape[0], padded_hidden(H), submess.numel()
+        f32 = dict(dtype=torch.float32, device=h_in.device)
+        save = any(ctx.needs_input_grad)
+        hp = _as_padded_state(h_in, H, Hp)
+        frozen = torch.ones(E1, dtype=torch.uint8, device=h_in.device)
+        frozen.index_fill_(0, submess, 0)
+        pred = csr_from_padded(_scatter_rows(E1, bgraph_sub, submess), ncols=E1)
+        Wz_x, Wz_h = _split_cols(W_z, I)
+        Wh_x, Wh_h = _split_cols(W_h, I)
+        ldx = _ld(x_sub)
+        Xs = torch.empty(3, ms, Hp, **f32)
+        gemm(0, 1, ms, H, I, x_sub, ldx, Wz_x, W_z.stride(0), Xs[0], Hp, Hp, bias=b_z)
+        gemm(0, 1, ms, H, I, x_sub, ldx, W_r, W_r.stride(0), Xs[1], Hp, Hp)
+        gemm(0, 1, ms, H, I, x_sub, ldx, Wh_x, W_h.stride(0), Xs[2], Hp, Hp, bias=b_h)
+        X = torch.zeros(3, E1, Hp, **f32)
+        X.index_copy_(1, submess, Xs)
+        wpack = torch.empty(int(lib.ggpm_gru_pack_floats(H)), **f32)
+        if save:
+            Hs = torch.empty(depth + 1, E1, Hp, **f32)
+            Qs = torch.empty(depth, E1, Hp, **f32)
+            St = torch.empty(5, depth, E1, Hp, **f32)
+            Ss, Gs, Zs, Ms, Rs = St[0], St[1], St[2], St[3], St[4]
+        else:
+            Hs = torch.empty(2, E1, Hp, **f32)
+            Qs = torch.empty(2, E1, Hp, **f32)
+            Ss = Gs = Zs = Ms = Rs = None
+        _lib.check(lib.ggpm_gru_sparse_forward(E1, H, depth, _p(hp), _p(frozen), _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h),
+                                               W_z.stride(0), _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0),
+                                               _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs),
+                                               _p(Ms), _p(Rs), _p(wpack), int(save), _stream()), "gru_sparse_forward")
+        out = Hs[depth] if save else Hs[depth & 1]
+        if save:
+            ctx.save_for_backward(x_sub, submess, W_z, W_r, U_r, W_h)
+            ctx.stash = (X[1], frozen, pred, Hs, Qs, Ss, Gs, Zs, Ms, Rs)
+            ctx.meta = (depth, I, H)
+        return out[:, :H]
+
+    @staticmethod
+    def backward(ctx, dH):
+        x_sub, submess, W_z, W_r, U_r, W_h = ctx.saved_tensors
+        Xr, frozen, pred, Hs, Qs, Ss, Gs, Zs, Ms, Rs = ctx.stash
+        depth, I, H = ctx.meta
+        lib = _lib.load()
+        E1, Hp, ms = Hs.shape[1], padded_hidden(H), submess.numel()
+        f32 = dict(dtype=torch.float32, device=x_sub.device)
+        succ = pred.T
+        dHD = torch.zeros(E1, Hp, **f32)
+        dHD[:, :H] = dH
+        dHin = torch.empty(E1, Hp, **f32)
+        dX = torch.empty(3, E1, Hp, **f32)
+        dW_z, dW_r, dU_r, dW_h = (torch.empty(W_z.shape, **f32), torch.empty(W_r.shape, **f32),
+                                  torch.empty(H, H, **f32), torch.empty(W_h.shape, **f32))
+        db_u = torch.empty(H, **f32)
+        Wz_x, Wz_h = _split_cols(W_z, I)
+        Wh_x, Wh_h = _split_cols(W_h, I)
+        dWz_x, dWz_h = _split_cols(dW_z, I)
+        dWh_x, dWh_h = _split_cols(dW_h, I)
+        wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        _lib.check(lib.ggpm_gru_sparse_backward(E1, H, depth, _p(frozen), _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r),
+                                                U_r.stride(0), _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col),
+                                                _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs),
+                                                _p(Ms), _p(Rs), _p(dHD), _p(dHin), _p(dX[0]), _p(dX[1]), _p(dX[2]),
+                                                _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),
+                                                dW_h.stride(0), _p(work), work.numel() * 4, _stream()),
+                   "gru_sparse_backward")
+        ctx.stash = None
+        dXs = dX.index_select(1, submess)             # [3, ms, Hp]: only the recomputed rows carry input gradients
+        ldx = _ld(x_sub)
+        gemm(1, 0, H, I, ms, dXs[0], Hp, x_sub, ldx, dWz_x, dW_z.stride(0), I, splitk=True)
+        gemm(1, 0, H, I, ms, dXs[1], Hp, x_sub, ldx, dW_r, dW_r.stride(0), I, splitk=True)
+        gemm(1, 0, H, I, ms, dXs[2], Hp, x_sub, ldx, dWh_x, dW_h.stride(0), I, splitk=True)
+        db_z, db_h = colsum(dXs[0], ms, H), colsum(dXs[2], ms, H)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x_sub)
+            gemm(0, 0, ms, I, H, dXs[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x_sub.shape[1])
+            gemm(0, 0, ms, I, H, dXs[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
+            gemm(0, 0, ms, I, H, dXs[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
+        return (dHin[:, :H], dx, None, None, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None)
+
+
+def gru_sparse(h_in, x_sub, submess, bgraph_sub, W_z, b_z, W_r, U_r, b_u, W_h, b_h, depth: int, I: int, H: int):
+    return _GruSparse.apply(h_in, x_sub, submess, bgraph_sub, W_z, b_z, W_r, U_r, b_u, W_h, b_h, depth, I, H)
+
+
+class _LstmSparse(torch.autograd.Function):
+    """LSTM.sparse_forward (ggpm/rnn.py:110-121): recompute rows `submess` of the (h, c) state `depth` times."""
+
+    @staticmethod
+    def forward(ctx, h_in, c_in, x_sub, submess, bgraph_sub, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, depth, I, H):
+        _need_gpu(h_in, c_in, x_sub, submess, bgraph_sub, W_i)
+        lib = _lib.load()
+        E1, Hp, ms = h_in.shape[0], padded_hidden(H), submess.numel()
+        f32 = dict(dtype=torch.float32, device=h_in.device)
+        save = any(ctx.needs_input_grad)
+        hp, cp = _as_padded_state(h_in, H, Hp), _as_padded_state(c_in, H, Hp)
+        frozen = torch.ones(E1, dtype=torch.uint8, device=h_in.device)
+        frozen.index_fill_(0, submess, 0)
+        pred = csr_from_padded(_scatter_rows(E1, bgraph_sub, submess), ncols=E1)
+        Ws, bs = (W_i, W_o, W_u, W_f), (b_i, b_o, b_u, b_f)
+        ldx = _ld(x_sub)
+        Xs = torch.empty(4, ms, Hp, **f32)
+        for k in range(4):
+            gemm(0, 1, ms, H, I, x_sub, ldx, Ws[k][:, :I], Ws[k].stride(0), Xs[k], Hp, Hp, bias=bs[k])
+        X = torch.zeros(4, E1, Hp, **f32)
+        X.index_copy_(1, submess, Xs)
+        wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H)), **f32)
+        if save:
+            Hs = torch.empty(depth + 1, E1, Hp, **f32)
+            Cs = torch.empty(depth + 1, E1, Hp, **f32)
+            Qs = torch.empty(depth, E1, Hp, **f32)
+            St = torch.empty(5, depth, E1, Hp, **f32)
+            Ss, Is, Os, Us, Fs = St[0], St[1], St[2], St[3], St[4]
+        else:
+            Hs = torch.empty(2, E1, Hp, **f32)
+            Cs = torch.empty(2, E1, Hp, **f32)
+            Qs = torch.empty(2, E1, Hp, **f32)
+            Ss = Is = Os = Us = Fs = None
+        Wh = [w[:, I:] for w in Ws]
+        _lib.check(lib.ggpm_lstm_sparse_forward(E1, H, depth, _p(hp), _p(cp), _p(frozen), _p(X[0]), _p(X[1]), _p(X[2]),
+                                                _p(X[3]), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0), _p(Wh[2]),
+                                                W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr), _p(pred.col),
+                                                _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os), _p(Us), _p(Fs), _p(wpack),
+                                                int(save), _stream()), "lstm_sparse_forward")
+        k = depth if save else depth & 1
+        if save:
+            ctx.save_for_backward(x_sub, submess, W_i, W_o, W_u, W_f)
+            ctx.stash = (X[3], frozen, pred, Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
+            ctx.meta = (depth, I, H)
+        return Hs[k][:, :H], Cs[k][:, :H]
+
+    @staticmethod
+    def backward(ctx, dH, dC):
+        x_sub, submess, W_i, W_o, W_u, W_f = ctx.saved_tensors
+        Xf, frozen, pred, Hs, Cs, Qs, Ss, Is, Os, Us, Fs = ctx.stash
+        depth, I, H = ctx.meta
+        lib = _lib.load()
+        E1, Hp, ms = Hs.shape[1], padded_hidden(H), submess.numel()
+        f32 = dict(dtype=torch.float32, device=x_sub.device)
+        succ = pred.T
+        dHD = torch.zeros(E1, Hp, **f32)
+        dCD = torch.zeros(E1, Hp, **f32)
+        if dH is not None:
+            dHD[:, :H] = dH
+        if dC is not None:
+            dCD[:, :H] = dC
+        dHin, dCin = torch.empty(E1, Hp, **f32), torch.empty(E1, Hp, **f32)
+        Ws = (W_i, W_o, W_u, W_f)
+        dX = torch.empty(4, E1, Hp, **f32)
+        dWs = [torch.empty(w.shape, **f32) for w in Ws]
+        Wh = [w[:, I:] for w in Ws]
+        dWh = [w[:, I:] for w in dWs]
+        wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        _lib.check(lib.ggpm_lstm_sparse_backward(E1, H, depth, _p(frozen), _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]),
+                                                 W_o.stride(0), _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0),
+                                                 _p(pred.rowptr), _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs),
+                                                 _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD),
+                                                 _p(dCD), _p(dHin), _p(dCin), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dX[3]),
+                                                 _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0), _p(dWh[2]),
+                                                 dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0), _p(work),
+                                                 work.numel() * 4, _stream()), "lstm_sparse_backward")
+        ctx.stash = None
+        dXs = dX.index_select(1, submess)
+        ldx = _ld(x_sub)
+        dbs = []
+        for k in range(4):
+            gemm(1, 0, H, I, ms, dXs[k], Hp, x_sub, ldx, dWs[k][:, :I], dWs[k].stride(0), I, splitk=True)
+            dbs.append(colsum(dXs[k], ms, H))
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = torch.empty_like(x_sub)
+            for k in range(4):
+                gemm(0, 0, ms, I, H, dXs[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx,
+                     x_sub.shape[1] if k == 0 else I, accumulate=k > 0)
+        return (dHin[:, :H], dCin[:, :H], dx, None, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3],
+                dbs[3], None, None, None)
+
+
+def lstm_sparse(h_in, c_in, x_sub, submess, bgraph_sub, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, depth, I, H):
+    return _LstmSparse.apply(h_in, c_in, x_sub, submess, bgraph_sub, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, depth, I, H)
+
+
 class _LstmLevel(torch.autograd.Function):
     """LSTM.forward (ggpm/rnn.py:96-108) for one level; returns (h_D, c_D) as [E1, Hp] tensors."""
 

@@ -49,6 +49,13 @@ class GRU(nn.Module):
     def forward(self, fmess, bgraph):
         return self.forward_padded(fmess, bgraph)[:, :self.hidden_size]
 
+    def sparse_forward(self, h, fmess, submess, bgraph):
+        """reference ggpm/rnn.py:52-59: recompute rows ``submess`` of the state ``h`` (``fmess``/``bgraph`` are the
+        sub-tensors of those rows, ``bgraph`` holding GLOBAL predecessor ids)."""
+        return F_.gru_sparse(h, fmess, submess.long(), bgraph.long(), self.W_z.weight, self.W_z.bias, self.W_r.weight,
+                             self.U_r.weight, self.U_r.bias, self.W_h.weight, self.W_h.bias, self.depth,
+                             self.input_size, self.hidden_size)
+
 
 class LSTM(nn.Module):
     """reference ggpm/rnn.py:61-121"""
@@ -84,3 +91,10 @@ class LSTM(nn.Module):
     def forward(self, fmess, bgraph):
         h, c = self.forward_padded(fmess, bgraph)
         return h[:, :self.hidden_size], c[:, :self.hidden_size]
+
+    def sparse_forward(self, h, fmess, submess, bgraph):
+        """reference ggpm/rnn.py:110-121: ``h`` is the (h, c) pair; returns the updated pair."""
+        h, c = h
+        i, o, u, f = self.W_i[0], self.W_o[0], self.W[0], self.W_f[0]
+        return F_.lstm_sparse(h, c, fmess, submess.long(), bgraph.long(), i.weight, i.bias, o.weight, o.bias,
+                              u.weight, u.bias, f.weight, f.bias, self.depth, self.input_size, self.hidden_size)

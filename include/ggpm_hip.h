@@ -142,6 +142,24 @@ int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float
                           size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
                           float* dWh_h, int ld_dwh, ggpm_stream_t stream);
 
+/* GRU.sparse_forward (ggpm/rnn.py:52-59) -- the incremental form the decoder uses (IncMPNEncoder, ggpm/encoder.py:160-179):
+ * rows with frozen[row] != 0 keep their state for the whole loop, the other rows (the `submess` subset) start from 0 and
+ * are recomputed `depth` times from the current states of their predecessors.  Same kernels as the dense level:
+ * frozen rows have empty predecessor lists, copy their state in the epilogue and pass their gradient through a carry
+ * buffer; Hs[0] = masked h_in, Qs[0] = U_r Hs[0] + b_u.  The backward also returns dHin [E1][Hp] (zero on recomputed rows). */
+int ggpm_gru_sparse_forward(int E1, int H, int depth, const float* h_in, const unsigned char* frozen, const float* Xz,
+                            const float* Xr, const float* Xh, const float* Wz_h, int ld_wz, const float* Ur, int ld_ur,
+                            const float* bu, const float* Wh_h, int ld_wh, const int32_t* pred_rowptr,
+                            const int32_t* pred_col, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms,
+                            float* Rs, float* wpack, int save_for_backward, ggpm_stream_t stream);
+int ggpm_gru_sparse_backward(int E1, int H, int depth, const unsigned char* frozen, const float* Xr, const float* Wz_h,
+                             int ld_wz, const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                             const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* succ_rowptr,
+                             const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss, const float* Gs,
+                             const float* Zs, const float* Ms, const float* Rs, const float* dHD, float* dHin,
+                             float* dXz, float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
+                             float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes, ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ LSTM message function
  * LSTM.forward (ggpm/rnn.py:96-108) with LSTM.LSTM (ggpm/rnn.py:85-94), same restatement:
  *     Xi/Xo/Xu/Xf = x W_*[:, :I]^T + b_*  (hoisted),   qf_p = Wf_h h_p,
@@ -170,6 +188,24 @@ int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* W
 int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work, size_t work_bytes,
                            float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu,
                            float* dWf_h, int ld_dwf, ggpm_stream_t stream);
+
+/* LSTM.sparse_forward (ggpm/rnn.py:110-121): as ggpm_gru_sparse_forward, with the cell state carried too.  The backward
+ * takes dL/dh_D and dL/dc_D (the decoder keeps both) and returns dHin / dCin. */
+int ggpm_lstm_sparse_forward(int E1, int H, int depth, const float* h_in, const float* c_in, const unsigned char* frozen,
+                             const float* Xi, const float* Xo, const float* Xu, const float* Xf, const float* Wi_h,
+                             int ld_wi, const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
+                             int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col, float* Hs, float* Cs,
+                             float* Qs, float* Ss, float* Is, float* Os, float* Us, float* Fs, float* wpack,
+                             int save_for_backward, ggpm_stream_t stream);
+int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* frozen, const float* Xf, const float* Wi_h,
+                              int ld_wi, const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
+                              int ld_wf, const int32_t* pred_rowptr, const int32_t* pred_col,
+                              const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs, const float* Cs,
+                              const float* Qs, const float* Ss, const float* Is, const float* Os, const float* Us,
+                              const float* Fs, const float* dHD, const float* dCD, float* dHin, float* dCin, float* dXi,
+                              float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
+                              float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
+                              ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ instrumentation
  * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own

@@ -113,6 +113,42 @@ def rnn_forward(p: Params, pre: str, rnn_type: str, fmess: Tensor, bgraph: Tenso
     raise ValueError("unsupported rnn cell type " + rnn_type)
 
 
+# ---------------------------------------------------------------- incremental form (decoder side)
+def index_scatter(sub: Tensor, full: Tensor, index: Tensor) -> Tensor:
+    """index_scatter -- ggpm/nnutils.py:124-128: rows `index` of `full` replaced by `sub`."""
+    mask = torch.ones(full.shape[0], dtype=full.dtype, device=full.device)
+    mask[index] = 0
+    buf = torch.zeros_like(full)
+    buf = buf.index_copy(0, index, sub)
+    return full * mask.unsqueeze(-1) + buf
+
+
+def gru_sparse_forward(p: Params, pre: str, h: Tensor, fmess: Tensor, submess: Tensor, bgraph: Tensor,
+                       depth: int) -> Tensor:
+    """GRU.sparse_forward -- ggpm/rnn.py:52-59."""
+    mask = torch.ones(h.shape[0], dtype=h.dtype, device=h.device)
+    mask[submess] = 0
+    h = h * mask.unsqueeze(1)
+    for _ in range(depth):
+        sub_h = gru_cell(p, pre, fmess, gather_rows(h, bgraph))
+        h = index_scatter(sub_h, h, submess)
+    return h
+
+
+def lstm_sparse_forward(p: Params, pre: str, h: Tensor, c: Tensor, fmess: Tensor, submess: Tensor, bgraph: Tensor,
+                        depth: int) -> Tuple[Tensor, Tensor]:
+    """LSTM.sparse_forward -- ggpm/rnn.py:110-121."""
+    mask = torch.ones(h.shape[0], dtype=h.dtype, device=h.device)
+    mask[submess] = 0
+    h = h * mask.unsqueeze(1)
+    c = c * mask.unsqueeze(1)
+    for _ in range(depth):
+        sub_h, sub_c = lstm_cell(p, pre, fmess, gather_rows(h, bgraph), gather_rows(c, bgraph))
+        h = index_scatter(sub_h, h, submess)
+        c = index_scatter(sub_c, c, submess)
+    return h, c
+
+
 # ---------------------------------------------------------------- MPNEncoder (ggpm/encoder.py:8-38)
 def mpn_forward(p: Params, pre: str, rnn_type: str, depth: int, fnode: Tensor, fmess: Tensor,
                 agraph: Tensor, bgraph: Tensor, trace: list | None = None) -> Tuple[Tensor, Tensor]:

@@ -31,6 +31,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.dont_write_bytecode = True
 
 REF = "/root/reference"
@@ -299,9 +300,59 @@ def main_motif():
                                                              os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+SPARSE_CASES = [
+    # name, rnn, E1, I, H, depth, ms, K, seed
+    ("sparse_gru_s5", "GRU", 60, 13, 24, 3, 17, 4, 5),
+    ("sparse_lstm_s6", "LSTM", 60, 13, 24, 3, 17, 4, 6),
+    ("sparse_gru_s7", "GRU", 300, 62, 100, 5, 80, 5, 7),
+    ("sparse_lstm_s8", "LSTM", 300, 62, 100, 5, 80, 5, 8),
+]
+
+
+def main_sparse():
+    """GRU/LSTM.sparse_forward (ggpm/rnn.py:52-59, 110-121) on seeded states/subsets: outputs and all gradients."""
+    from ggpm.rnn import GRU, LSTM
+    from ggpm_amd.params import rnn_param_shapes
+    from golden_utils import sparse_inputs
+    for (name, rnn, E1, I, H, depth, ms, K, seed) in SPARSE_CASES:
+        torch.set_default_dtype(torch.float32)
+        h, c, submess, x, bg, coef = sparse_inputs(E1, I, H, ms, K, seed)
+        sd = seeded_state_dict(rnn_param_shapes(rnn, I, H), seed)
+        mod = (GRU if rnn == "GRU" else LSTM)(I, H, depth)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        ht = torch.from_numpy(h).requires_grad_(True)
+        ct = torch.from_numpy(c).requires_grad_(True)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        if rnn == "GRU":
+            ho = mod.sparse_forward(ht, xt, torch.from_numpy(submess), torch.from_numpy(bg))
+            loss = (torch.from_numpy(coef[0]) * ho).sum()
+            co = None
+        else:
+            ho, co = mod.sparse_forward((ht, ct), xt, torch.from_numpy(submess), torch.from_numpy(bg))
+            loss = (torch.from_numpy(coef[0]) * ho).sum() + (torch.from_numpy(coef[1]) * co).sum()
+        loss.backward()
+        out = {"h_out": ho.detach().numpy(), "dh_in": ht.grad.numpy(), "dx": xt.grad.numpy(), "loss": loss.detach().numpy()}
+        if co is not None:
+            out["c_out"] = co.detach().numpy()
+            out["dc_in"] = ct.grad.numpy()
+        for pname, prm in mod.named_parameters():
+            out["grad/" + pname] = prm.grad.numpy()
+        out["meta"] = np.array([E1, I, H, depth, ms, K, seed], dtype=np.int64)
+        out["rnn"] = np.array(rnn)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-14s loss=%.6f -> %s (%.1f KB)" % (name, float(out["loss"]), os.path.basename(path),
+                                                   os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
+    if "--sparse-only" in sys.argv:
+        import_reference()
+        main_sparse()
+        sys.exit(0)
     if "--motif-only" not in sys.argv:
         main()
     else:
         import_reference()
     main_motif()
+    main_sparse()

@@ -15,6 +15,7 @@ N_PROBE = 64
 def case_names(prefix="", motif=False):
     """HierMPNEncoder fixtures by default; ``motif=True`` lists the MotifEncoder fixtures instead."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    names = [n for n in names if not n.startswith("sparse_")]      # sparse_forward fixtures have their own tests
     return [n for n in names if n.startswith("motif_") == motif]
 
 
@@ -97,3 +98,21 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def sparse_inputs(E1, I, H, ms, K, seed):
+    """Seeded inputs of a sparse_forward call (shared with the tests): state, subset, its inputs and predecessors."""
+    rs = np.random.RandomState(seed)
+    h = (0.5 * rs.standard_normal((E1, H))).astype(np.float32)
+    c = (0.5 * rs.standard_normal((E1, H))).astype(np.float32)
+    h[0] = 0; c[0] = 0
+    submess = rs.choice(np.arange(1, E1), size=ms, replace=False).astype(np.int64)
+    x = rs.standard_normal((ms, I)).astype(np.float32)
+    bg = np.zeros((ms, K + 1), dtype=np.int64)
+    for i in range(ms):
+        k = rs.randint(0, K + 1)
+        bg[i, :k] = rs.choice(np.arange(1, E1), size=k, replace=False)     # inside AND outside the subset
+    coef = rs.standard_normal((2, E1, H)).astype(np.float32)
+    return h, c, submess, x, bg, coef
+
+

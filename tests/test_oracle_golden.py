@@ -5,7 +5,9 @@ import torch
 
 from ggpm_amd import synth
 from oracle import ref_encoder as ref
-from golden_utils import Golden, case_names, rel_err
+import os
+
+from golden_utils import GOLDEN_DIR, Golden, case_names, rel_err, sparse_inputs
 
 CASES = case_names()
 
@@ -86,3 +88,35 @@ def test_oracle_motif_encoder_matches_reference(name):
     assert rel_err(node.detach().numpy(), g.z["node"]) <= 2e-5
     for k, v in p.items():
         g.check_grad(k, v.grad.numpy(), rel=5e-5)
+
+
+def _sparse_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    E1, I, H, depth, ms, K, seed = [int(v) for v in z["meta"]]
+    return z, str(z["rnn"]), (E1, I, H, depth, ms, K, seed)
+
+
+@pytest.mark.parametrize("name", ["sparse_gru_s5", "sparse_lstm_s6", "sparse_gru_s7", "sparse_lstm_s8"])
+def test_oracle_sparse_forward_matches_reference(name):
+    """GRU/LSTM.sparse_forward restatement vs the reference's outputs and gradients."""
+    from ggpm_amd.params import rnn_param_shapes, seeded_state_dict
+    z, rnn, (E1, I, H, depth, ms, K, seed) = _sparse_case(name)
+    h, c, submess, x, bg, coef = sparse_inputs(E1, I, H, ms, K, seed)
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in seeded_state_dict(rnn_param_shapes(rnn, I, H), seed).items()}
+    ht, ct, xt = (torch.from_numpy(a).requires_grad_(True) for a in (h, c, x))
+    sm, bgt = torch.from_numpy(submess), torch.from_numpy(bg)
+    if rnn == "GRU":
+        ho = ref.gru_sparse_forward(p, "", ht, xt, sm, bgt, depth)
+        loss = (torch.from_numpy(coef[0]) * ho).sum()
+    else:
+        ho, co = ref.lstm_sparse_forward(p, "", ht, ct, xt, sm, bgt, depth)
+        loss = (torch.from_numpy(coef[0]) * ho).sum() + (torch.from_numpy(coef[1]) * co).sum()
+        assert rel_err(co.detach().numpy(), z["c_out"]) <= 2e-5
+    loss.backward()
+    assert rel_err(ho.detach().numpy(), z["h_out"]) <= 2e-5
+    assert rel_err(ht.grad.numpy(), z["dh_in"]) <= 5e-5
+    assert rel_err(xt.grad.numpy(), z["dx"]) <= 5e-5
+    if rnn == "LSTM":
+        assert rel_err(ct.grad.numpy(), z["dc_in"]) <= 5e-5
+    for k, v in p.items():
+        assert rel_err(v.grad.numpy(), z["grad/" + k]) <= 5e-5, k
