@@ -3,7 +3,8 @@
 Host side: Python mirror of the reference's classes (rnn.GRU/LSTM, encoder.MPNEncoder/HierMPNEncoder);
 device side: hand-written HIP kernels behind the C ABI in include/ggpm_hip.h (ggpm_amd/libggpm_hip.so).
 """
-__all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "HierEncoderVAE", "rsample", "make_cuda"]
+__all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "IncMPNEncoder", "IncHierMPNEncoder",
+           "IncEncoder", "HierEncoderVAE", "rsample", "make_cuda"]
 
 
 def __getattr__(name):
@@ -14,6 +15,9 @@ def __getattr__(name):
     if name in ("MPNEncoder", "HierMPNEncoder", "MotifEncoder", "PreparedBatch"):
         from . import encoder
         return getattr(encoder, name)
+    if name in ("IncMPNEncoder", "IncHierMPNEncoder", "IncEncoder", "HTuple"):
+        from . import inc_encoder
+        return getattr(inc_encoder, name)
     if name in ("HierEncoderVAE", "rsample"):
         from . import property_vae
         return getattr(property_vae, name)

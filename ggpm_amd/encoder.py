@@ -154,6 +154,12 @@ class HierMPNEncoder(nn.Module):
         fnode, fmess = graph_tensors[0], graph_tensors[1]
         return F_.embed_graph(fnode, fmess, self.atom_size, NUM_BOND_TYPES, MAX_POS)
 
+    def embed_graph(self, graph_tensors):
+        """reference ggpm/encoder.py:119-126: (one-hot atoms, [atom | bond type | position] messages, agraph, bgraph)."""
+        hnode, hmess = self.embed_graph_padded(graph_tensors)
+        return (hnode[:, :self.atom_size], hmess[:, :self.atom_size + self.bond_size], graph_tensors[2],
+                graph_tensors[3])
+
     def embed_inter_padded(self, prep: PreparedBatch, hatom):
         H, He = self.hidden_size, self.embed_size
         emb = self.E_i[0].weight

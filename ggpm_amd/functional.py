@@ -197,7 +197,7 @@ class _SegmentSum(torch.autograd.Function):
         if _ld(src) > width:
             out[:, width:].zero_()
         _segment_sum_raw(src, csr, width, out)
-        ctx.csr, ctx.width, ctx.src_rows = csr, width, src.shape[0]
+        ctx.csr, ctx.width, ctx.src_rows, ctx.src_cols = csr, width, src.shape[0], src.shape[1]
         return out
 
     @staticmethod
@@ -209,7 +209,7 @@ class _SegmentSum(torch.autograd.Function):
         if _ld(dout) > ctx.width:
             dsrc[:, ctx.width:].zero_()
         _segment_sum_raw(dout, csrT, ctx.width, dsrc)
-        return dsrc, None, None
+        return dsrc[:, :ctx.src_cols], None, None     # src may have been a [rows, H] view of a padded buffer
 
 
 def segment_sum(src: torch.Tensor, csr: CSR, width: int) -> torch.Tensor:

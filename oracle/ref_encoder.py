@@ -236,6 +236,170 @@ def motif_encoder_forward(p: Params, rnn_type: str, depthT: int, tree_tensors):
     return root, node
 
 
+# ---------------------------------------------------------------- incremental encoders (ggpm/encoder.py:160-249, 343-394)
+class IncState:
+    """HTuple -- ggpm/decoder.py:13-16."""
+
+    def __init__(self, node=None, mess=None, vmask=None, emask=None):
+        self.node, self.mess, self.vmask, self.emask = node, mess, vmask, emask
+
+
+def _hidden(rnn_type: str, h):
+    return h if rnn_type == "GRU" else h[0]
+
+
+def rnn_init_state(rnn_type: str, n_mess: int, H: int, like: Tensor, init_state: Tensor | None = None):
+    """GRU/LSTM.get_init_state -- ggpm/rnn.py:18-20, 74-80 (root vectors appended as extra message rows)."""
+    h = torch.zeros(n_mess, H, dtype=like.dtype, device=like.device)
+    c = torch.zeros(n_mess, H, dtype=like.dtype, device=like.device)
+    if init_state is not None:
+        h = torch.cat([h, init_state], dim=0)
+        c = torch.cat([c, torch.zeros_like(init_state)], dim=0)
+    return h if rnn_type == "GRU" else (h, c)
+
+
+def apply_tree_mask(tensors, cur: IncState, prev: IncState):
+    """HierMPNDecoder.apply_tree_mask -- ggpm/decoder.py:72-77."""
+    fnode, fmess, agraph, bgraph, cgraph, scope = tensors
+    return (fnode, fmess, agraph * cur.emask[agraph], bgraph * cur.emask[bgraph], cgraph * prev.vmask[cgraph], scope)
+
+
+def apply_graph_mask(tensors, hgraph: IncState):
+    """HierMPNDecoder.apply_graph_mask -- ggpm/decoder.py:79-83."""
+    fnode, fmess, agraph, bgraph, scope = tensors
+    return fnode, fmess, agraph * hgraph.emask[agraph], bgraph * hgraph.emask[bgraph], scope
+
+
+def init_decoder_tensors(tree_tensors, batch: int):
+    """agraph/bgraph edits of init_decoder_state -- ggpm/decoder.py:103-118 (root vector i lives in row num_mess+i)."""
+    fmess, agraph, bgraph = tree_tensors[1], tree_tensors[2].clone(), tree_tensors[3].clone()
+    num_mess = fmess.shape[0]
+    for i, (root, _) in enumerate(tree_tensors[-1]):
+        agraph[root, -1] = num_mess + i
+        for m in range(1, num_mess):
+            if int(fmess[m, 0]) == root:
+                bgraph[m, -1] = num_mess + i
+    return list(tree_tensors[:2]) + [agraph, bgraph] + list(tree_tensors[4:])
+
+
+def inc_mpn_forward(p: Params, pre: str, rnn_type: str, depth: int, tensors, h, num_nodes: int, subset):
+    """IncMPNEncoder.forward -- ggpm/encoder.py:165-179 (no pad-row mask on this path)."""
+    fnode, fmess, agraph, bgraph = tensors
+    subnode, submess = subset
+    if len(submess) > 0:
+        if rnn_type == "GRU":
+            h = gru_sparse_forward(p, pre + "rnn.", h, fmess, submess, bgraph, depth)
+        else:
+            h = lstm_sparse_forward(p, pre + "rnn.", h[0], h[1], fmess, submess, bgraph, depth)
+    nei = gather_rows(_hidden(rnn_type, h), agraph).sum(dim=1)
+    node = torch.relu(_affine(p, pre + "W_o.0", torch.cat([fnode, nei], dim=1)))
+    buf = torch.zeros(num_nodes, node.shape[1], dtype=node.dtype, device=node.device)
+    return index_scatter(node, buf, subnode), h
+
+
+def _sub_tensor(tensors, subset):
+    """get_sub_tensor -- ggpm/encoder.py:195-206."""
+    subnode, submess = subset
+    out = [tensors[0].index_select(0, subnode), tensors[1].index_select(0, submess),
+           tensors[2].index_select(0, subnode), tensors[3].index_select(0, submess)]
+    if len(tensors) == 6:
+        out.append(tensors[4].index_select(0, subnode))
+    return out
+
+
+def _sub_messages(hnode: Tensor, subnode: Tensor, fmess: Tensor, num_nodes: int):
+    buf = torch.zeros(num_nodes, hnode.shape[1], dtype=hnode.dtype, device=hnode.device)
+    buf = index_scatter(hnode, buf, subnode)
+    return torch.cat([buf.index_select(0, fmess[:, 0]), _eye(MAX_POS, hnode).index_select(0, fmess[:, 2])], dim=-1)
+
+
+def embed_sub_tree(p: Params, tree_tensors, hinput: Tensor, subtree, is_inter_layer: bool):
+    """IncHierMPNEncoder.embed_sub_tree -- ggpm/encoder.py:208-230."""
+    subnode, submess = subtree
+    fnode, fmess, agraph, bgraph, cgraph = _sub_tensor(tree_tensors, subtree)
+    if is_inter_layer:
+        finput = p["E_i.0.weight"].index_select(0, fnode[:, 1])
+        pooled = gather_rows(hinput, cgraph).sum(dim=1)
+        hnode = torch.relu(_affine(p, "W_i.0", torch.cat([finput, pooled], dim=-1)))
+    else:
+        finput = p["E_c.0.weight"].index_select(0, fnode[:, 0])
+        hnode = torch.relu(_affine(p, "W_c.0", torch.cat([finput, hinput.index_select(0, subnode)], dim=-1)))
+    hmess = fmess if len(submess) == 0 else _sub_messages(hnode, subnode, fmess, tree_tensors[0].shape[0])
+    return hnode, hmess, agraph, bgraph
+
+
+def inc_hier_forward(p: Params, rnn_type: str, depthT: int, depthG: int, tree_tensors, inter_tensors, graph_tensors,
+                     htree: IncState, hinter: IncState, hgraph: IncState, subtree, subgraph):
+    """IncHierMPNEncoder.forward -- ggpm/encoder.py:232-249 (``graph_tensors`` already embedded)."""
+    n_tree, n_graph = tree_tensors[0].shape[0], graph_tensors[0].shape[0]
+    if len(subgraph[0]) + len(subgraph[1]) > 0:
+        sub = _sub_tensor(graph_tensors[:4], subgraph)
+        hgraph.node, hgraph.mess = inc_mpn_forward(p, "graph_encoder.", rnn_type, depthG, sub, hgraph.mess, n_graph,
+                                                   subgraph)
+    if len(subtree[0]) + len(subtree[1]) > 0:
+        sub = embed_sub_tree(p, inter_tensors, hgraph.node, subtree, True)
+        hinter.node, hinter.mess = inc_mpn_forward(p, "inter_encoder.", rnn_type, depthT, sub, hinter.mess, n_tree,
+                                                   subtree)
+        sub = embed_sub_tree(p, tree_tensors, hinter.node, subtree, False)
+        htree.node, htree.mess = inc_mpn_forward(p, "tree_encoder.", rnn_type, depthT, sub, htree.mess, n_tree, subtree)
+    return htree, hinter, hgraph
+
+
+def inc_tree_forward(p: Params, rnn_type: str, depthT: int, tree_tensors, htree: IncState, subtree):
+    """IncEncoder.embed_sub_tree / forward -- ggpm/encoder.py:364-394."""
+    if len(subtree[0]) + len(subtree[1]) > 0:
+        subnode, submess = subtree
+        fnode, fmess, agraph, bgraph, _ = _sub_tensor(tree_tensors, subtree)
+        hnode = p["E_c.0.weight"].index_select(0, fnode[:, 0])
+        hmess = fmess if len(submess) == 0 else _sub_messages(hnode, subnode, fmess, tree_tensors[0].shape[0])
+        htree.node, htree.mess = inc_mpn_forward(p, "tree_encoder.", rnn_type, depthT, (hnode, hmess, agraph, bgraph),
+                                                 htree.mess, tree_tensors[0].shape[0], subtree)
+    return htree
+
+
+def inc_teacher_forced(p: Params, kind: str, rnn_type: str, depthT: int, depthG: int, tree_tensors, graph_tensors,
+                       init_vecs: Tensor, schedule, atom_size: int = 38):
+    """The state handling of the teacher-forced decoder loop around the incremental encoder --
+    ggpm/decoder.py:165-222 (hier) / 640-683 (tree-only).  ``schedule`` is a list of steps
+    ``(subnode, submess, new_atoms, new_bonds)`` (int64 tensors); returns the vectors the decoder reads after every
+    step (``htree.node[xid]``, hidden ``htree.mess[mess_idx]``) and the final states."""
+    B, H = init_vecs.shape
+    dev = init_vecs.device
+    n_mess_t, n_mess_g = tree_tensors[1].shape[0], graph_tensors[1].shape[0]
+    inter_tensors = tree_tensors
+    dec_tensors = init_decoder_tensors(tree_tensors, B)
+    z = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
+    htree = IncState(mess=rnn_init_state(rnn_type, n_mess_t, H, init_vecs, init_vecs),
+                     emask=torch.cat([z(n_mess_t), torch.ones(B, dtype=torch.long, device=dev)]))
+    hinter = IncState(mess=rnn_init_state(rnn_type, n_mess_t, H, init_vecs), emask=z(n_mess_t))
+    hgraph = IncState(mess=rnn_init_state(rnn_type, n_mess_g, H, init_vecs), vmask=z(graph_tensors[0].shape[0]),
+                      emask=z(n_mess_g))
+    if kind == "hier":
+        graph_emb = tuple(embed_graph(p, graph_tensors, atom_size, init_vecs.dtype)) + (graph_tensors[-1],)
+    topo, cls = [], []
+    for subnode, submess, atoms, bonds in schedule:
+        hgraph.vmask[atoms] = 1                              # update_graph_mask, ggpm/decoder.py:85-101
+        hgraph.emask[bonds] = 1
+        htree.emask[submess] = 1
+        cur_tree = apply_tree_mask(dec_tensors, htree, hgraph)
+        if kind == "hier":
+            hinter.emask[submess] = 1
+            cur_inter = apply_tree_mask(inter_tensors, hinter, hgraph)
+            cur_graph = apply_graph_mask(graph_emb, hgraph)
+            htree, hinter, hgraph = inc_hier_forward(p, rnn_type, depthT, depthG, cur_tree, cur_inter, cur_graph,
+                                                     htree, hinter, hgraph, (subnode, submess), (atoms, bonds))
+        else:
+            htree = inc_tree_forward(p, rnn_type, depthT, cur_tree, htree, (subnode, submess))
+        topo.append(htree.node.index_select(0, subnode))
+        if len(submess) > 0:
+            cls.append(_hidden(rnn_type, htree.mess).index_select(0, submess))
+    out = {"topo": torch.cat(topo), "cls": torch.cat(cls), "tree_mess": _hidden(rnn_type, htree.mess)}
+    if kind == "hier":
+        out.update(inter_mess=_hidden(rnn_type, hinter.mess), graph_mess=_hidden(rnn_type, hgraph.mess),
+                   graph_node=hgraph.node, inter_node=hinter.node)
+    return out, dec_tensors
+
+
 # ---------------------------------------------------------------- KL (ggpm/property_vae.py:26-33)
 def rsample_kl(p: Params, hroot: Tensor, pre_mean: str = "R_mean", pre_var: str = "R_var",
                eps: Tensor | None = None) -> Tuple[Tensor, Tensor]:

@@ -15,7 +15,7 @@ N_PROBE = 64
 def case_names(prefix="", motif=False):
     """HierMPNEncoder fixtures by default; ``motif=True`` lists the MotifEncoder fixtures instead."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    names = [n for n in names if not n.startswith("sparse_")]      # sparse_forward fixtures have their own tests
+    names = [n for n in names if not n.startswith(("sparse_", "inc_"))]   # those fixtures have their own tests
     return [n for n in names if n.startswith("motif_") == motif]
 
 
@@ -116,3 +116,43 @@ def sparse_inputs(E1, I, H, ms, K, seed):
     return h, c, submess, x, bg, coef
 
 
+
+
+def inc_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "inc_*.npz")))
+
+
+class IncGolden(Golden):
+    """Teacher-forced incremental-encoder fixtures (tests/golden/make_golden_inc.py)."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.kind = str(self.z["kind"])
+
+    def params(self, dtype=torch.float32, device="cpu", requires_grad=False):
+        shapes = (encoder_param_shapes if self.kind == "hier" else motif_encoder_param_shapes)(
+            self.rnn, self.H, self.n_motif, self.n_attach)
+        out = {}
+        for k, v in seeded_state_dict(shapes, self.seed).items():
+            if k.startswith("W_root"):
+                continue
+            t = torch.from_numpy(v).to(dtype).to(device)
+            out[k] = t.requires_grad_(True) if requires_grad else t
+        return out
+
+    def schedule(self, device="cpu"):
+        z = self.z
+        cols = []
+        for k in ("subnode", "submess", "atoms", "bonds"):
+            flat, off = z["sched_" + k].astype(np.int64), z["sched_" + k + "_off"]
+            cols.append([torch.from_numpy(flat[off[i]:off[i + 1]]).to(device) for i in range(len(off) - 1)])
+        return list(zip(*cols))
+
+    def init_vecs(self, device="cpu", dtype=torch.float32):
+        return torch.from_numpy(self.z["init_vecs"]).to(dtype).to(device).requires_grad_(True)
+
+    def output_keys(self):
+        keys = ["topo", "cls", "tree_mess"]
+        if self.kind == "hier":
+            keys += ["inter_mess", "graph_mess", "graph_node", "inter_node"]
+        return keys

@@ -7,7 +7,7 @@ from ggpm_amd import synth
 from oracle import ref_encoder as ref
 import os
 
-from golden_utils import GOLDEN_DIR, Golden, case_names, rel_err, sparse_inputs
+from golden_utils import GOLDEN_DIR, Golden, IncGolden, case_names, inc_case_names, rel_err, sparse_inputs
 
 CASES = case_names()
 
@@ -120,3 +120,27 @@ def test_oracle_sparse_forward_matches_reference(name):
         assert rel_err(ct.grad.numpy(), z["dc_in"]) <= 5e-5
     for k, v in p.items():
         assert rel_err(v.grad.numpy(), z["grad/" + k]) <= 5e-5, k
+
+
+# ---------------------------------------------------------------- incremental encoders
+@pytest.mark.parametrize("name", inc_case_names())
+def test_oracle_incremental_encoder_matches_reference(name):
+    g = IncGolden(name)
+    dtype = torch.float64
+    p = g.params(dtype=dtype, requires_grad=True)
+    tree, graph = g.tensors()
+    init = g.init_vecs(dtype=dtype)
+    outs, dec_tensors = ref.inc_teacher_forced(p, g.kind, g.rnn, g.depthT, g.depthG, tree, graph, init, g.schedule())
+    assert (dec_tensors[2].numpy() == g.z["dec_agraph"]).all() and (dec_tensors[3].numpy() == g.z["dec_bgraph"]).all()
+    keys = g.output_keys()
+    coeffs = g.loss_coeffs([tuple(outs[k].shape) for k in keys])
+    loss = sum((torch.from_numpy(c).to(dtype) * outs[k]).sum() for c, k in zip(coeffs, keys))
+    loss.backward()
+    for k in keys:
+        assert rel_err(outs[k].detach().numpy(), g.z[k]) < 2e-5, k
+    assert abs(float(loss.detach()) - float(g.z["loss"])) < 2e-4 * max(1.0, abs(float(g.z["loss"])))
+    assert rel_err(init.grad.numpy(), g.z["d_init_vecs"]) < 1e-4
+    for k, t in p.items():
+        want = g.z["grad/" + k]
+        got = t.grad.numpy() if t.grad is not None else np.zeros_like(want)
+        assert rel_err(got, want) < 1e-4, k
