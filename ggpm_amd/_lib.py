@@ -37,6 +37,8 @@ SIGNATURES = {
     "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_gru_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               P, I, P, I, P, P, I, P, c_size_t, I, P]),
+    "ggpm_gru_backward_overlapped": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                         P, I, P, I, P, P, I, P, c_size_t, P, P]),
     "ggpm_gru_weight_grads": (I, [I, I, I, P, P, P, P, c_size_t, P, I, P, I, P, P, I, P]),
     "ggpm_gru_sparse_forward": (I, [I, I, I, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
@@ -51,6 +53,14 @@ SIGNATURES = {
                                      P, I, P]),
     "ggpm_lstm_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                       P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_build_clusters": (I, [P, P, I, I, P, P, P]),
+    "ggpm_gru_persistent_supported": (I, [I]),
+    "ggpm_gru_persistent_ncg": (I, [I]),
+    "ggpm_gru_persistent_target_rows": (I, [I, I]),
+    "ggpm_gru_persistent_workspace_floats": (c_size_t, [I, I]),
+    "ggpm_gru_forward_persistent": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, I, P, P, P, P, P, P, P, P, P,
+                                        P, P]),
+    "ggpm_persistent_timeout": (I, [P, P]),
     "ggpm_timing_enable": (I, [I]),
     "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
 }

@@ -582,6 +582,16 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
                                  float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
                                  float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, ggpm_stream_t stream);
 
+// depths per chunk of the overlapped weight-gradient contractions, and a small pool of re-recordable events
+constexpr int GGPM_WGRAD_CHUNK = 5;
+hipEvent_t ggpm_wgrad_event(int i) {
+    static thread_local hipEvent_t pool[64] = {};
+    i &= 63;
+    if (!pool[i] && hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    return pool[i];
+}
+static inline hipEvent_t wgrad_event(int i) { return ggpm_wgrad_event(i); }
+
 static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
                                  const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
                                  const int32_t* pred_rowptr, const int32_t* pred_col,
@@ -590,7 +600,8 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr, float* dXh,
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, int weight_grads,
-                                 const unsigned char* frozen, float* dHin, ggpm_stream_t stream) {
+                                 const unsigned char* frozen, float* dHin, ggpm_stream_t stream,
+                                 ggpm_stream_t side_stream = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
@@ -628,6 +639,8 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
+    int chunk_hi = depth, n_ev = 0;
+    bool first_chunk = true, dur_started = false;
     for (int t = depth; t >= 1; --t) {
         GruBwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
@@ -646,8 +659,53 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
         a.srowptr = succ_rowptr; a.scol = succ_col;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
+        if (side_stream && !frozen) {
+            // Overlapped weight gradients: the stash slots of the depths finished so far are final, so their share of
+            // the three tall contractions runs on the second stream beside the rest of this (latency-bound) loop.
+            const int done = depth - t + 1;
+            const bool last = (t == 1);
+            if (done % GGPM_WGRAD_CHUNK == 0 || last) {
+                const int t_hi = chunk_hi;                 // depths (t_hi .. t] finished since the last chunk
+                chunk_hi = t - 1;
+                hipEvent_t ev = wgrad_event(n_ev++);
+                if (!ev) return GGPM_ERR_LAUNCH;
+                (void)hipEventRecord(ev, s);
+                (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+                const int acc = first_chunk ? 0 : 1;
+                const int nsl = t_hi - t + 1;              // slots t-1 .. t_hi-1 of DMP/DZP/S/G
+                const int K1 = nsl * E1;
+                int rc = ggpm_gemm(1, 0, H, H, K1, DMP + (size_t)(t - 1) * slot, Hp, Gs + (size_t)(t - 1) * slot, Hp, dWh_h,
+                                   ld_dwh, H, nullptr, acc, GGPM_ACT_NONE, 0, skws, skbytes, side_stream);
+                if (rc) return rc;
+                rc = ggpm_gemm(1, 0, H, H, K1, DZP + (size_t)(t - 1) * slot, Hp, Ss + (size_t)(t - 1) * slot, Hp, dWz_h,
+                               ld_dwz, H, nullptr, acc, GGPM_ACT_NONE, 0, skws, skbytes, side_stream);
+                if (rc) return rc;
+                // dq^u pairs with h^u for u in [max(t,1), min(t_hi, depth-1)]
+                const int u_lo = t, u_hi = t_hi < depth ? t_hi : depth - 1;
+                if (u_hi >= u_lo) {
+                    rc = ggpm_gemm(1, 0, H, H, (u_hi - u_lo + 1) * E1, DQ + (size_t)u_lo * slot, Hp, Hs + (size_t)u_lo * slot,
+                                   Hp, dUr, ld_dur, H, nullptr, dur_started ? 1 : 0, GGPM_ACT_NONE, 0, skws, skbytes,
+                                   side_stream);
+                    if (rc) return rc;
+                    dur_started = true;
+                }
+                first_chunk = false;
+            }
+        }
     }
     GGPM_CHECK_LAUNCH();
+    if (side_stream && !frozen) {
+        hipStream_t ss = (hipStream_t)side_stream;
+        if (depth > 1) {
+            int rc = ggpm_colsum(DQ + slot, Hp, (depth - 1) * E1, H, dbu, csws, side_stream);
+            if (rc) return rc;
+        } else {
+            for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), ss);
+            (void)hipMemsetAsync(dbu, 0, H * sizeof(float), ss);
+        }
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
 
     if (frozen) {      // gradient of the incoming state: one more gather + dq.U_r launch at t = 0
         GruBwdArgs a = {};
@@ -676,6 +734,23 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
                              succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
                              dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream);
+}
+
+// As ggpm_gru_backward with weight_grads = 0, but the h-half weight gradients (dWz_h, dUr, dbu, dWh_h) are issued on
+// `side_stream` in chunks of depths WHILE the depth loop still runs on `stream` (event-ordered), instead of after it.
+extern "C" int ggpm_gru_backward_overlapped(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+                                            const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                                            const int32_t* pred_rowptr, const int32_t* pred_col,
+                                            const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
+                                            const float* Qs, const float* Ss, const float* Gs, const float* Zs,
+                                            const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr,
+                                            float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
+                                            float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
+                                            ggpm_stream_t stream, ggpm_stream_t side_stream) {
+    if (!side_stream) return GGPM_ERR_ARG;
+    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
+                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
+                             dWh_h, ld_dwh, work, work_bytes, 0, nullptr, nullptr, stream, side_stream);
 }
 
 // sparse_forward backward: additionally returns dHin (gradient of the incoming state; zero on the recomputed rows)

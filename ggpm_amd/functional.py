@@ -10,6 +10,7 @@ columns are zero.  Index tensors are int32 (CSR) unless stated.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -20,7 +21,9 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
 
 def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Python
+    # Stream object: ~9 us per call, and a step makes ~1000 of them)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -50,6 +53,20 @@ class CSR:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, rows: int, ncols: int):
         self.rowptr, self.col, self.rows, self.ncols = rowptr, col, rows, ncols
         self._T: Optional["CSR"] = None
+        self._clusters = {}
+
+    def clusters(self, target: int) -> torch.Tensor:
+        """Closed row ranges of >= ``target`` rows (molecule clusters) for the persistent depth-loop kernels:
+        int32 [n, bound_0 = 0, ..., bound_n = rows], built on the device (no host sync)."""
+        tab = self._clusters.get(target)
+        if tab is None:
+            dev = self.col.device
+            tab = torch.empty(self.rows + 4, dtype=torch.int32, device=dev)
+            scratch = torch.empty(3 * self.rows, dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().ggpm_build_clusters(_p(self.rowptr), _p(self.col), self.rows, target, _p(tab),
+                                                       _p(scratch), _stream()), "build_clusters")
+            self._clusters[target] = tab
+        return tab
 
     @property
     def T(self) -> "CSR":
@@ -145,6 +162,7 @@ class _Linear(torch.autograd.Function):
             off += K
         ctx.save_for_backward(weight, y, *xs)
         ctx.meta = (act, zero_row0, Ks, bias is not None)
+        ctx.weight_ref, ctx.bias_ref = weight, bias       # the Parameter objects themselves (their .grad is assigned)
         return y
 
     @staticmethod
@@ -162,13 +180,9 @@ class _Linear(torch.autograd.Function):
                        "act_backward")
         else:
             dpre = dy
-        dW = torch.empty_like(weight) if ctx.needs_input_grad[0] else None
-        db = colsum(dpre, M, N) if (has_bias and ctx.needs_input_grad[1]) else None
         dxs: List[Optional[torch.Tensor]] = []
         off = 0
-        for i, (x, K) in enumerate(zip(xs, Ks)):
-            if dW is not None:
-                gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW[:, off:], dW.stride(0), K, splitk=True)
+        for i, (x, K) in enumerate(zip(xs, Ks)):     # input gradients are needed upstream right away: main stream
             if ctx.needs_input_grad[6 + i]:
                 dx = torch.empty_like(x)
                 gemm(0, 0, M, K, N, dpre, _ld(dpre), weight[:, off:], weight.stride(0), dx, _ld(dx), x.shape[1])
@@ -176,6 +190,34 @@ class _Linear(torch.autograd.Function):
             else:
                 dxs.append(None)
             off += K
+
+        def param_grads():
+            dW_ = torch.empty_like(weight) if ctx.needs_input_grad[0] else None
+            o = 0
+            for x, K in zip(xs, Ks):
+                if dW_ is not None:
+                    gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW_[:, o:], dW_.stride(0), K, splitk=True)
+                o += K
+            db_ = colsum(dpre, M, N) if (has_bias and ctx.needs_input_grad[1]) else None
+            return dW_, db_
+
+        wref, bias = ctx.weight_ref, ctx.bias_ref
+        use_side = (side_stream_enabled() and ctx.needs_input_grad[0] and getattr(wref, "is_leaf", False)
+                    and (bias is None or getattr(bias, "is_leaf", False)))
+        if use_side:      # weight / bias gradients: second stream, straight into param.grad (as the level functions do)
+            main = torch.cuda.current_stream()
+            side = _side_stream(weight.device)
+            side.wait_stream(main)
+            for tns in (dpre, *xs):
+                tns.record_stream(side)
+            with torch.cuda.stream(side):
+                dW, db = param_grads()
+                _accumulate_grad(wref, dW, main)
+                if db is not None:
+                    _accumulate_grad(bias, db, main)
+            _join_later(main, side)
+            return (None, None, None, None, None, None, *dxs)
+        dW, db = param_grads()
         return (dW, db, None, None, None, None, *dxs)
 
 
@@ -302,6 +344,12 @@ def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_t
 _SIDE = {}
 
 
+def wgrad_overlap_enabled() -> bool:
+    """GGPM_WGRAD_OVERLAP=1 (opt-in): weight-gradient contractions start while the level's backward depth loop still
+    runs.  Off by default: the contractions already hide behind the NEXT level's loop and the extra events cost host time."""
+    return os.environ.get("GGPM_WGRAD_OVERLAP", "0") != "0"
+
+
 def side_stream_enabled() -> bool:
     import os
     return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
@@ -325,6 +373,29 @@ def _accumulate_grad(param: torch.Tensor, g: torch.Tensor, main: torch.cuda.Stre
 
 def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
     torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+
+
+# ----------------------------------------------------------------------------- persistent depth loops
+# GGPM_PERSISTENT=1 (opt-in, experimental): one launch per level runs all forward depth steps (molecule clusters,
+# csrc/mpn_gru_persist.hip); the default keeps the two-launches-per-depth kernels of csrc/mpn_gru.hip, which
+# measured faster end to end on MI355X ("persistent depth loop").
+_PERSIST = {"sync": None}
+
+
+def persistent_enabled() -> bool:
+    return os.environ.get("GGPM_PERSISTENT", "0") != "0"
+
+
+def persistent_max_rows() -> int:
+    return int(os.environ.get("GGPM_PERSISTENT_MAX_ROWS", "32"))
+
+
+def persistent_timeout() -> int:
+    """Timeout word of the most recent persistent launch (synchronises; 0 = all cluster waits completed)."""
+    sync = _PERSIST["sync"]
+    if sync is None:
+        return 0
+    return int(_lib.load().ggpm_persistent_timeout(_p(sync), _stream()))
 
 
 def _split_cols(W: torch.Tensor, I: int):
@@ -364,10 +435,23 @@ class _GruLevel(torch.autograd.Function):
             Hs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
             Ss = Gs = Zs = Ms = Rs = None
-        _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0), _p(U_r),
-                                        U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col),
-                                        _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack),
-                                        int(save), _stream()), "gru_forward")
+        target = int(lib.ggpm_gru_persistent_target_rows(E1, H)) if save and persistent_enabled() else 0
+        # the one-launch cluster kernel wins where the level is latency bound (few rows per molecule cluster); big
+        # levels are MFMA / L2 bound either way and keep the two-launches-per-depth kernels
+        if target and target <= persistent_max_rows() and lib.ggpm_gru_persistent_supported(H):
+            table = pred.clusters(target)
+            xwork = torch.empty(int(lib.ggpm_gru_persistent_workspace_floats(E1, H)), **f32)
+            sync = torch.empty(8 + E1 // target + 4, dtype=torch.int32, device=x.device)
+            _lib.check(lib.ggpm_gru_forward_persistent(
+                E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0), _p(b_u),
+                _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(table), target, _p(Hs), _p(Qs), _p(Ss),
+                _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack), _p(xwork), _p(sync), _stream()), "gru_forward_persistent")
+            _PERSIST["sync"] = sync
+        else:
+            _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0),
+                                            _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr),
+                                            _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                            _p(wpack), int(save), _stream()), "gru_forward")
         if save:
             ctx.save_for_backward(x, W_z, W_r, U_r, W_h)
             ctx.stash = (X[1], Hs, Qs, Ss, Gs, Zs, Ms, Rs)
@@ -397,12 +481,28 @@ class _GruLevel(torch.autograd.Function):
         wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         use_side = side_stream_enabled() and all(getattr(p, "is_leaf", False) for p in ctx.params)
-        _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
-                                         _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
-                                         _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(dHD),
-                                         _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0), _p(dU_r), H,
-                                         _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4,
-                                         0 if use_side else 1, _stream()), "gru_backward")
+        overlapped = use_side and wgrad_overlap_enabled()
+        if overlapped:
+            # the h-half weight gradients run on the second stream in chunks of depths WHILE this level's depth
+            # loop is still going (the loop is latency bound and leaves most of the chip idle)
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            for tns in (work, Hs, Ss, dW_z, dU_r, dW_h, db_u):
+                tns.record_stream(side)
+            _lib.check(lib.ggpm_gru_backward_overlapped(
+                E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0), _p(Wh_h), W_h.stride(0),
+                _p(pred.rowptr), _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs),
+                _p(Ms), _p(Rs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0), _p(dU_r), H,
+                _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4, _stream(),
+                ctypes.c_void_p(side.cuda_stream)), "gru_backward_overlapped")
+        else:
+            _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
+                                             _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
+                                             _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                             _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0),
+                                             _p(dU_r), H, _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work),
+                                             work.numel() * 4, 0 if use_side else 1, _stream()), "gru_backward")
         ctx.stash = None
         ldx = _ld(x)
         dx = None
@@ -413,7 +513,7 @@ class _GruLevel(torch.autograd.Function):
             gemm(0, 0, E1, I, H, dX[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
 
         def weight_grads():
-            if use_side:
+            if use_side and not overlapped:
                 _lib.check(lib.ggpm_gru_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(Gs), _p(work), work.numel() * 4,
                                                      _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),
                                                      dW_h.stride(0), _stream()), "gru_weight_grads")

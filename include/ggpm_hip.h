@@ -138,6 +138,16 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
                       int weight_grads, ggpm_stream_t stream);
 /* The weight-gradient tail of ggpm_gru_backward (called with weight_grads = 0) as its own entry point, so the
  * host may enqueue it on a second stream beside the next level's depth loop. Same `work` buffer. */
+/* ggpm_gru_backward (weight_grads = 0) with the h-half weight gradients issued on `side_stream` in chunks of depths
+ * while the depth loop still runs on `stream` (event-ordered); afterwards `side_stream` holds dWz_h, dUr, dbu, dWh_h. */
+int ggpm_gru_backward_overlapped(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+                                 const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                                 const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* succ_rowptr,
+                                 const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss,
+                                 const float* Gs, const float* Zs, const float* Ms, const float* Rs, const float* dHD,
+                                 float* dXz, float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
+                                 float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
+                                 ggpm_stream_t stream, ggpm_stream_t side_stream);
 int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs, float* work,
                           size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
                           float* dWh_h, int ld_dwh, ggpm_stream_t stream);
@@ -206,6 +216,28 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
                               float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                               float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
                               ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ persistent depth loop (molecule clusters)
+ * The message recurrence of ggpm/rnn.py:41-50 only couples messages of one molecule.  ggpm_build_clusters cuts the
+ * level's rows into closed ranges of >= target_rows rows (table: int32[E1+4], scratch: int32[3*E1]); the persistent
+ * forward runs ALL depth steps in one launch, each cluster owned by ggpm_gru_persistent_ncg(H) workgroups that keep
+ * their gate-weight slices in registers and synchronise per cluster only.  Same outputs and stashes as ggpm_gru_forward
+ * with save_for_backward = 1 (Qs has `depth` slots).  xwork: ggpm_gru_persistent_workspace_floats floats; sync:
+ * 8 + E1/target_rows uint32 words (zeroed by the call).  ggpm_persistent_timeout synchronises the stream and returns
+ * the launch's timeout word (0 = every cluster wait completed). */
+int ggpm_build_clusters(const int32_t* pred_rowptr, const int32_t* pred_col, int E1, int target_rows, int32_t* table,
+                        int32_t* scratch, ggpm_stream_t stream);
+int ggpm_gru_persistent_supported(int H);
+int ggpm_gru_persistent_ncg(int H);
+int ggpm_gru_persistent_target_rows(int E1, int H);
+size_t ggpm_gru_persistent_workspace_floats(int E1, int H);
+int ggpm_gru_forward_persistent(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
+                                const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
+                                const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
+                                const int32_t* clusters, int target_rows, float* Hs, float* Qs, float* Ss, float* Gs,
+                                float* Zs, float* Ms, float* Rs, float* wpack, float* xwork, uint32_t* sync,
+                                ggpm_stream_t stream);
+int ggpm_persistent_timeout(uint32_t* sync, ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ instrumentation
  * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own

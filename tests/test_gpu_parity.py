@@ -394,3 +394,39 @@ def test_incremental_encoder_teacher_forced_matches_reference_golden(name):
         grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
         e = rel_err(grad, g.z["grad/" + k]) if np.abs(g.z["grad/" + k]).max() > 0 else float(np.abs(grad).max())
         assert e < TOL, "%s grad %s rel err %.3e" % (name, k, e)
+
+
+# ------------------------------------------------------------------------------------------ persistent depth loop
+@pytest.mark.parametrize("rnn,H,depth,motifs,B", [("GRU", 16, 3, (2, 4), 3), ("GRU", 24, 4, (1, 5), 5),
+                                                  ("GRU", 100, 5, (4, 7), 6), ("GRU", 300, 20, (8, 12), 32),
+                                                  ("GRU", 250, 6, (30, 40), 2)])
+def test_persistent_depth_loop_matches_stepwise_kernels(rnn, H, depth, motifs, B, monkeypatch):
+    """The one-launch-per-level cluster kernels (csrc/mpn_gru_persist.hip) against the two-launches-per-depth
+    kernels on the same level: final state, every stash the backward reads, and the gradients; no cluster wait
+    may have timed out."""
+    from ggpm_amd import synth, rnn as R, functional as F_
+    dev = _dev()
+    specs = synth.random_batch(H + depth, B, motifs=motifs, n_motif_vocab=11, n_attach_vocab=33)
+    tree, graph = synth.tensorize(specs)
+    for tens, I in ((graph, 62), (tree, H + 20)):
+        bg = torch.from_numpy(tens[3].astype(np.int64)).to(dev)
+        E1 = bg.shape[0]
+        torch.manual_seed(E1)
+        x = torch.randn(E1, I, device=dev)
+        x[0] = 0
+        mod = (R.GRU if rnn == "GRU" else R.LSTM)(I, H, depth).to(dev)
+        coef = torch.randn(E1, H, device=dev)
+        res = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("GGPM_PERSISTENT", flag)
+            monkeypatch.setenv("GGPM_PERSISTENT_MAX_ROWS", "100000")
+            mod.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            h = mod(xg, bg)
+            (h * coef).sum().backward()
+            assert F_.persistent_timeout() == 0
+            res.append([h.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in mod.parameters()])
+        assert F_._PERSIST["sync"] is not None          # the persistent path did run
+        for a, b in zip(*res):
+            scale = max(float(a.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) <= 2e-5 * scale
