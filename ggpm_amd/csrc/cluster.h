@@ -42,13 +42,6 @@ __device__ __forceinline__ void ggpm_xst_l2(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ggpm_u32x4, v), r, byte_off, 0, 0);
 }
 
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global stores / loads
-// (__syncthreads() also drains vmcnt, which puts every store's acknowledgement on the critical path).  A wave
-// that published data by LDS-DMA waits for vmcnt itself before calling this.
-__device__ __forceinline__ void ggpm_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // All waves of the workgroup call this after their exchange stores; returns false on timeout (uniform).
 __device__ __forceinline__ bool ggpm_cluster_sync(unsigned* cnt, unsigned target, unsigned* tmo, int* lds_ok) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have landed

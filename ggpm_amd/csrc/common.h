@@ -38,6 +38,13 @@ __device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
 }
 __device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global stores / loads
+// (__syncthreads() also drains vmcnt, which puts every store's acknowledgement on the critical path).  A wave
+// that published data by LDS-DMA waits for vmcnt itself before calling this.
+__device__ __forceinline__ void ggpm_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
 void ggpm_timing_begin(int which, hipStream_t s, double flops);
 void ggpm_timing_end(int which, hipStream_t s);

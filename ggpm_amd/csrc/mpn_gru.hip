@@ -60,6 +60,7 @@ struct GruFwdArgs {
     const int32_t *rowptr, *col;
     int ablate;                    // timing experiments only (GGPM_ABLATE): 1 no gather, 2 no GEMM
     const unsigned char* frozen;   // sparse_forward only: rows with frozen[row] != 0 keep their state (h' = h)
+    int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
 };
 
 __global__ void gru_init_state(float* __restrict__ H0, float* __restrict__ Q0, const float* __restrict__ bu,
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         }
     }
 
-    __syncthreads();
+    ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
     // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
     const int lr = lane & 15, row = r0 + lr;
@@ -170,8 +171,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             const float* const wps[2] = {a.Wz, a.Wh};
             ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        if (row >= a.E1) continue;
         float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
+        if (row >= a.E1) {
+            if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, h);
+            continue;
+        }
         if (a.frozen && a.frozen[row]) {
             h = ggpm_ld4(a.Hprev + o);             // z = m = 0 in the stash => the backward passes dh through
         } else if (row != 0 || a.frozen) {
@@ -183,10 +187,26 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                             (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
         }
         ggpm_st4(a.Hnew + o, h);
+        if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, h);
         if (STASH) {
             ggpm_st4(a.Z + o, z);
             ggpm_st4(a.M + o, m);
         }
+    }
+    if (!a.fuse_b) return;
+
+    // ---- P3 (single column group only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
+    ggpm_lds_barrier();
+    const float* Th = lds + 2 * ROWS * LD;
+    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const float4 b = ggpm_ld4(a.bu + c);
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        const float* const tiles[1] = {Th};
+        const float* const wps[1] = {a.Ur};
+        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
     }
 }
 
@@ -238,6 +258,7 @@ struct GruBwdArgs {
     float* carry;                  // [E1,Hp] running dh of frozen rows (zeroed by the driver)
     int final_pass;                // t == 0: P1 + dq.U_r only, result to dHin
     float* dHin;                   // [E1,Hp]
+    int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
@@ -310,12 +331,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         }
     }
 
-    if (!a.first) __syncthreads();
+    if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dq stash stores finish under the GEMM
 
     // ---- P2: dh = partial + dq . U_r ; gate derivatives, for this wave's tiles
     const int lr = lane & 15, row = r0 + lr;
     const int t_end = min(NT, (grp + 1) * a.tg);
-    for (int tt = t; tt < t_end; tt += GGPM_NWA) {
+    float4 dsd_keep[2] = {ggpm_zero4(), ggpm_zero4()};      // fused P3: ds_dir of this wave's (at most two) tiles
+    int it = 0;
+    for (int tt = t; tt < t_end; tt += GGPM_NWA, ++it) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
         float4 s = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4(), oxz = ggpm_zero4(), oxh = ggpm_zero4();
@@ -331,7 +354,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             const float* const wps[1] = {a.UrT};
             ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        if (row >= a.E1) continue;
+        if (row >= a.E1) {
+            if (a.fuse_b) {
+                ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, ggpm_zero4());
+                ggpm_st4(lds + 3 * ROWS * LD + lr * LD + c, ggpm_zero4());
+            }
+            continue;
+        }
         const bool frz = a.frozen && a.frozen[row];
         if (a.final_pass) {        // gradient of the incoming state: frozen rows only (active rows started from 0)
             float4 dh0 = ggpm_zero4();
@@ -360,11 +389,41 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
             dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
         }
-        ggpm_st4(a.DSD + o, dsdir);
         ggpm_st4(a.DZP + o, dzp);
         ggpm_st4(a.DMP + o, dmp);
         ggpm_st4(a.dXz + o, oxz + dzp);
         ggpm_st4(a.dXh + o, oxh + dmp);
+        if (a.fuse_b) {
+            ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, dzp);
+            ggpm_st4(lds + 3 * ROWS * LD + lr * LD + c, dmp);
+            if (it == 0) dsd_keep[0] = dsdir; else dsd_keep[1] = dsdir;
+        } else {
+            ggpm_st4(a.DSD + o, dsdir);
+        }
+    }
+    if (!a.fuse_b) return;
+
+    // ---- P3 (single column group only): the workgroup holds the complete dz_pre / dm_pre rows ->
+    // dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h ; dXr += dG * R   (the body of kernel B)
+    ggpm_lds_barrier();
+    it = 0;
+    for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
+        const int c = 16 * tt + 4 * (lane >> 4);
+        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+        const float4 dsd = it == 0 ? dsd_keep[0] : dsd_keep[1];
+        const float4 rco = ggpm_ld4(a.R + o), oxr = ggpm_ld4(a.dXr + o);
+        f32x4 acc[2][RT];
+        ggpm_zero_acc<2, RT>(acc);
+        {
+            const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
+            const float* const wps[2] = {a.WhT, a.WzT};
+            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        if (row >= a.E1) continue;
+        const float4 dg = ggpm_f4(acc[0][0]);
+        ggpm_st4(a.dGout + o, dg);
+        ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
+        ggpm_st4(a.dXr + o, oxr + dg * rco);
     }
 }
 
@@ -421,11 +480,14 @@ inline int pick_tg(int E1, int NT) {
     return ggpm_tiles_per_group(E1, NT);
 }
 
-void launch_fwd(const GruFwdArgs& a, bool stash, bool with_b, double flops1, hipStream_t s) {
+void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    const size_t lds_a = (size_t)2 * ROWS * (Hp + 4) * sizeof(float), lds_b = lds_a / 2;
-    ggpm_timing_begin(0, s, 2 * flops1);
+    const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
+    a.fuse_b = (with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    if (a.fuse_b) with_b = false;
+    const size_t lds_a = (a.fuse_b ? 3 : 2) * lds_b;
+    ggpm_timing_begin(0, s, (a.fuse_b ? 3 : 2) * flops1);
     if (stash) {
         set_lds(gru_fwd_a<true>, lds_a);
         gru_fwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
@@ -442,13 +504,17 @@ void launch_fwd(const GruFwdArgs& a, bool stash, bool with_b, double flops1, hip
     }
 }
 
-void launch_bwd(const GruBwdArgs& a, bool with_b, double flops1, hipStream_t s) {
+void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t lds = (size_t)2 * ROWS * (Hp + 4) * sizeof(float);
-    set_lds(gru_bwd_a, lds);
-    ggpm_timing_begin(1, s, 1 * flops1);
-    gru_bwd_a<<<grid_a, GGPM_NWA * 64, lds, s>>>(a);
+    a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && 2 * lds <= 160 * 1024 &&
+                !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    if (a.fuse_b) with_b = false;
+    const size_t lds_a = a.fuse_b ? 2 * lds : lds;
+    set_lds(gru_bwd_a, lds_a);
+    ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
+    gru_bwd_a<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     ggpm_timing_end(1, s);
     if (with_b) {
         set_lds(gru_bwd_b, lds);

@@ -39,6 +39,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("enqueue %.3f ms/step, total %.3f ms/step" % (1e3 * (t1 - t0) / N, 1e3 * (t2 - t0) / N))
+torch.autograd.set_multithreading_enabled(False)      # run the backward functions in this thread so cProfile sees them
 pr = cProfile.Profile()
 pr.enable()
 for i in range(N):
@@ -46,5 +47,5 @@ for i in range(N):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(60)
 print(s.getvalue())
