@@ -28,9 +28,9 @@ SIGNATURES = {
     "ggpm_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, I, P, I, I, I, P, c_size_t, P]),
     "ggpm_colsum": (I, [P, I, I, I, P, P, P]),
     "ggpm_act_backward": (I, [P, P, I, I, I, I, I, P, P]),
-    "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, P]),
-    "ggpm_gather_rows": (I, [P, I, P, I, I, P, I, I, P]),
-    "ggpm_onehot": (I, [P, I, I, P, I, I, P]),
+    "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, I, P]),
+    "ggpm_gather_rows": (I, [P, I, P, I, I, P, I, I, I, P]),
+    "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
     "ggpm_gru_pack_floats": (c_size_t, [I]),
     "ggpm_gru_forward": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
@@ -53,6 +53,10 @@ SIGNATURES = {
                                      P, I, P]),
     "ggpm_lstm_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                       P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_encoder_saved_bytes": (c_size_t, [P]),
+    "ggpm_encoder_work_bytes": (c_size_t, [P]),
+    "ggpm_encoder_forward": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
+    "ggpm_encoder_backward": (I, [P, P, P, P, P, c_size_t, P, P, P, P, P, P, P, P, P, c_size_t, P, P]),
     "ggpm_build_clusters": (I, [P, P, I, I, P, P, P]),
     "ggpm_gru_persistent_supported": (I, [I]),
     "ggpm_gru_persistent_ncg": (I, [I]),

@@ -1,0 +1,508 @@
+// Whole-encoder drivers: HierMPNEncoder.forward / its backward (reference ggpm/encoder.py:96-157) as ONE C call each.
+//
+// The per-op entry points of this library are what the Python host composes op by op (functional.py); at MI355X
+// speeds that composition costs more host time than the GPU needs for the step (~150 ctypes calls, ~140
+// allocations, 21 autograd nodes per step).  These two drivers issue exactly the same kernels in the same order
+// from C++, carve every intermediate out of two caller-provided arenas (`saved`: forward -> backward, `work`:
+// backward temporaries), accumulate gradient contributions in place (GEMM / segmented-sum `accumulate` flags instead
+// of separate add kernels), build the transposed CSRs beside the forward on the second stream and run all weight
+// gradient contractions there, event-ordered.  GRU message function, dropout 0 (the host keeps the op-by-op path
+// for everything else).
+#include "common.h"
+#include <cstring>
+#include <cstdlib>
+
+hipEvent_t ggpm_wgrad_event(int i);          // small pool of re-recordable events (mpn_gru.hip)
+
+namespace {
+
+struct Arena {
+    char* base;
+    size_t off;
+    bool overflow;
+    size_t cap;
+    template <typename T>
+    T* take(size_t n) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        if (base && off > cap) overflow = true;
+        return p;
+    }
+};
+
+struct Csr {
+    int32_t *rowptr, *col;
+    int rows, ncols, cap;
+    int32_t *rowptrT, *colT, *cursor;
+};
+
+struct LevelSaved {
+    float *X, *Hs, *Qs, *St, *wpack, *nei;
+};
+
+struct Saved {          // layout of the `saved` arena (pointers are re-derived by replaying the same takes)
+    Csr gpred, gagr, tpred, tagr, tcgr, tsrc, root, motif, attach;
+    int32_t *src, *attr0, *motif_id, *attach_id, *iota;
+    float *hnode_a, *hmess_a;
+    LevelSaved lv[3];          // 0 tree, 1 inter, 2 graph
+    float *finput_i, *pooled, *hnode_i, *hmess_i, *finput_t, *hnode_t, *hmess_t, *f, *n;
+};
+
+struct Dims {
+    int H, Hp, He, Hep, depthT, depthG, atom, n_motif, n_attach;
+    int N1g, E1g, Kga, Kgb, N1t, E1t, Kta, Ktb, Ktc, B;
+    int ld_n, ld_m, ld_t, Ig, It;
+};
+
+Dims make_dims(const ggpm_enc_dims* d) {
+    Dims x;
+    x.H = d->H; x.Hp = ggpm_padded_hidden(d->H); x.He = d->He; x.Hep = ggpm_padded_hidden(d->He);
+    x.depthT = d->depthT; x.depthG = d->depthG; x.atom = d->atom_size; x.n_motif = d->n_motif; x.n_attach = d->n_attach;
+    x.N1g = d->N1g; x.E1g = d->E1g; x.Kga = d->Kg_a; x.Kgb = d->Kg_b;
+    x.N1t = d->N1t; x.E1t = d->E1t; x.Kta = d->Kt_a; x.Ktb = d->Kt_b; x.Ktc = d->Kt_c; x.B = d->B;
+    x.ld_n = ggpm_round_up(x.atom, 4);
+    x.Ig = x.atom + 4 + 20; x.ld_m = ggpm_round_up(x.Ig, 4);
+    x.It = x.H + 20; x.ld_t = ggpm_round_up(x.It, 4);
+    return x;
+}
+
+void take_csr(Arena& A, Csr& c, int rows, int ncols, int cap) {
+    c.rows = rows; c.ncols = ncols; c.cap = cap < 1 ? 1 : cap;
+    c.rowptr = A.take<int32_t>(rows + 1);
+    c.col = A.take<int32_t>(c.cap);
+    c.rowptrT = A.take<int32_t>(ncols + 1);
+    c.colT = A.take<int32_t>(c.cap);
+    c.cursor = A.take<int32_t>(ncols);
+}
+
+void take_level(Arena& A, LevelSaved& L, int E1, int N1, int Hp, int H, int depth) {
+    const size_t slot = (size_t)E1 * Hp;
+    L.X = A.take<float>(3 * slot);
+    L.Hs = A.take<float>((size_t)(depth + 1) * slot);
+    L.Qs = A.take<float>((size_t)depth * slot);
+    L.St = A.take<float>((size_t)5 * depth * slot);
+    L.wpack = A.take<float>(ggpm_gru_pack_floats(H));
+    L.nei = A.take<float>((size_t)N1 * Hp);
+}
+
+void layout_saved(Arena& A, const Dims& d, Saved& s) {
+    take_csr(A, s.gpred, d.E1g, d.E1g, d.E1g * d.Kgb);
+    take_csr(A, s.gagr, d.N1g, d.E1g, d.N1g * d.Kga);
+    take_csr(A, s.tpred, d.E1t, d.E1t, d.E1t * d.Ktb);
+    take_csr(A, s.tagr, d.N1t, d.E1t, d.N1t * d.Kta);
+    take_csr(A, s.tcgr, d.N1t, d.N1g, d.N1t * d.Ktc);
+    s.src = A.take<int32_t>(d.E1t); s.attr0 = A.take<int32_t>(d.E1t);
+    s.motif_id = A.take<int32_t>(d.N1t); s.attach_id = A.take<int32_t>(d.N1t);
+    const int nio = (d.E1t > d.N1t ? d.E1t : d.N1t) + 1;
+    s.iota = A.take<int32_t>(nio > d.B + 1 ? nio : d.B + 1);
+    // index "CSRs" (one entry per row): rowptr = iota, col = the index array; only their transposes are stored
+    auto take_index = [&](Csr& c, int rows, int ncols) {
+        c.rows = rows; c.ncols = ncols; c.cap = rows;
+        c.rowptr = s.iota; c.col = nullptr;
+        c.rowptrT = A.take<int32_t>(ncols + 1); c.colT = A.take<int32_t>(rows); c.cursor = A.take<int32_t>(ncols);
+    };
+    take_index(s.tsrc, d.E1t, d.N1t);
+    take_index(s.root, d.B, d.N1t);
+    take_index(s.motif, d.N1t, d.n_motif);
+    take_index(s.attach, d.N1t, d.n_attach);
+    s.hnode_a = A.take<float>((size_t)d.N1g * d.ld_n);
+    s.hmess_a = A.take<float>((size_t)d.E1g * d.ld_m);
+    take_level(A, s.lv[0], d.E1t, d.N1t, d.Hp, d.H, d.depthT);
+    take_level(A, s.lv[1], d.E1t, d.N1t, d.Hp, d.H, d.depthT);
+    take_level(A, s.lv[2], d.E1g, d.N1g, d.Hp, d.H, d.depthG);
+    s.finput_i = A.take<float>((size_t)d.N1t * d.Hep); s.pooled = A.take<float>((size_t)d.N1t * d.Hp);
+    s.hnode_i = A.take<float>((size_t)d.N1t * d.Hp); s.hmess_i = A.take<float>((size_t)d.E1t * d.ld_t);
+    s.finput_t = A.take<float>((size_t)d.N1t * d.Hep);
+    s.hnode_t = A.take<float>((size_t)d.N1t * d.Hp); s.hmess_t = A.take<float>((size_t)d.E1t * d.ld_t);
+    s.f = A.take<float>((size_t)d.B * d.Hp); s.n = A.take<float>((size_t)d.B * d.Hp);
+}
+
+__global__ void iota_k(int32_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// parameter slots
+enum { P_EC = 0, P_EI, P_WC, P_BC, P_WI, P_BI, P_WROOT, P_BROOT, P_LEVEL0 };
+enum { L_WO = 0, L_BO, L_WZ, L_BZ, L_WR, L_UR, L_BU, L_WH, L_BH, L_COUNT };
+inline int lp(int level, int which) { return P_LEVEL0 + level * L_COUNT + which; }
+
+#define CK(expr)                    \
+    do {                            \
+        const int rc__ = (expr);    \
+        if (rc__) return rc__;      \
+    } while (0)
+
+// y[:, :N] = act(sum_i x_i W[:, off_i : off_i + K_i]^T + b), pad columns zero (functional._Linear.forward)
+int linear2(int M, int N, const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const float* W,
+            const float* b, int act, int zero_row0, float* y, int ldy, ggpm_stream_t s) {
+    const int ldw = K1 + K2;
+    CK(ggpm_gemm(0, 1, M, N, K1, x1, ld1, W, ldw, y, ldy, ldy, b, 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
+    CK(ggpm_gemm(0, 1, M, N, K2, x2, ld2, W + K1, ldw, y, ldy, ldy, nullptr, 1, act, zero_row0, nullptr, 0, s));
+    return GGPM_OK;
+}
+
+int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* x, int ldx, float* const* P, int level,
+                  const Csr& pred, const Csr& agr, LevelSaved& L, ggpm_stream_t s) {
+    const int H = d.H, Hp = d.Hp;
+    const size_t slot = (size_t)E1 * Hp;
+    const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
+    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wz, I + H, L.X, Hp, Hp, P[lp(level, L_BZ)], 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
+    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wr, I, L.X + slot, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
+    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wh, I + H, L.X + 2 * slot, Hp, Hp, P[lp(level, L_BH)], 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, s));
+    const size_t ds = (size_t)depth * slot;
+    CK(ggpm_gru_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
+                        P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, L.Hs, L.Qs, L.St, L.St + ds,
+                        L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
+    CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
+    return GGPM_OK;
+}
+
+int transpose(const Csr& c, const int32_t* col, ggpm_stream_t s) {
+    return ggpm_csr_transpose(c.rowptr, col ? col : c.col, c.rows, c.ncols, c.rowptrT, c.colT, c.cursor, s);
+}
+
+}  // namespace
+
+extern "C" size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims) {
+    if (!dims) return 0;
+    const Dims d = make_dims(dims);
+    Arena A = {nullptr, 0, false, 0};
+    Saved s;
+    layout_saved(A, d, s);
+    return A.off;
+}
+
+extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* params, const int64_t* tfnode,
+                                    const int64_t* tfmess, const int64_t* tagraph, const int64_t* tbgraph,
+                                    const int64_t* tcgraph, const int64_t* gfnode, const int64_t* gfmess,
+                                    const int64_t* gagraph, const int64_t* gbgraph, const int32_t* roots, void* saved,
+                                    size_t saved_bytes, float* hroot, float* hnode, float* hinter, float* hatom,
+                                    ggpm_stream_t stream, ggpm_stream_t side_stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!dims || !params || !tfnode || !tfmess || !tagraph || !tbgraph || !tcgraph || !gfnode || !gfmess || !gagraph ||
+        !gbgraph || !roots || !saved || !hroot || !hnode || !hinter || !hatom)
+        return GGPM_ERR_ARG;
+    const Dims d = make_dims(dims);
+    Arena A = {reinterpret_cast<char*>(saved), 0, false, saved_bytes};
+    Saved S;
+    layout_saved(A, d, S);
+    if (A.overflow) return GGPM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* const* P = params;
+    const int H = d.H, Hp = d.Hp, He = d.He;
+
+    // ---- graph layout
+    CK(ggpm_padded_to_csr(gbgraph, d.E1g, d.Kgb, S.gpred.rowptr, S.gpred.col, stream));
+    CK(ggpm_padded_to_csr(gagraph, d.N1g, d.Kga, S.gagr.rowptr, S.gagr.col, stream));
+    CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, stream));
+    CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, stream));
+    CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, stream));
+    CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, stream));
+    CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, stream));
+    CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, stream));
+    CK(ggpm_extract_column(tfnode, d.N1t, 2, 1, S.attach_id, stream));
+    {
+        const int nio = (d.E1t > d.N1t ? d.E1t : d.N1t) + 1;
+        const int n = nio > d.B + 1 ? nio : d.B + 1;
+        iota_k<<<ggpm_ceil_div(n, 256), 256, 0, s>>>(S.iota, n);
+    }
+    if (side_stream) {      // transposes are only read by the backward: build them beside the forward
+        hipEvent_t ev = ggpm_wgrad_event(60);
+        if (!ev) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev, s);
+        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+    }
+    {
+        ggpm_stream_t ts = side_stream ? side_stream : stream;
+        CK(transpose(S.gpred, nullptr, ts));
+        CK(transpose(S.gagr, nullptr, ts));
+        CK(transpose(S.tpred, nullptr, ts));
+        CK(transpose(S.tagr, nullptr, ts));
+        CK(transpose(S.tcgr, nullptr, ts));
+        CK(transpose(S.tsrc, S.src, ts));
+        CK(transpose(S.root, roots, ts));
+        CK(transpose(S.motif, S.motif_id, ts));
+        CK(transpose(S.attach, S.attach_id, ts));
+    }
+
+    // ---- atom level (embed_graph, graph_encoder)
+    CK(ggpm_embed_graph(gfnode, d.N1g, gfmess, d.E1g, d.atom, 4, 20, S.hnode_a, d.ld_n, S.hmess_a, d.ld_m, stream));
+    CK(level_forward(d, d.E1g, d.N1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, 2, S.gpred, S.gagr, S.lv[2], stream));
+    CK(linear2(d.N1g, H, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, P[lp(2, L_WO)], P[lp(2, L_BO)], GGPM_ACT_RELU, 1,
+               hatom, Hp, stream));
+
+    // ---- attachment level (embed_inter, inter_encoder)
+    CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, stream));
+    CK(ggpm_segment_sum(hatom, Hp, S.tcgr.rowptr, S.tcgr.col, d.N1t, H, S.pooled, Hp, 0, Hp, stream));
+    CK(linear2(d.N1t, H, S.finput_i, d.Hep, He, S.pooled, Hp, H, P[P_WI], P[P_BI], GGPM_ACT_RELU, 0, S.hnode_i, Hp,
+               stream));
+    CK(ggpm_gather_rows(S.hnode_i, Hp, S.src, d.E1t, H, S.hmess_i, d.ld_t, 0, 0, stream));
+    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, stream));
+    CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, 1, S.tpred, S.tagr, S.lv[1], stream));
+    CK(linear2(d.N1t, H, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, P[lp(1, L_WO)], P[lp(1, L_BO)], GGPM_ACT_RELU, 1, hinter, Hp,
+               stream));
+
+    // ---- motif level (embed_tree, tree_encoder)
+    CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, stream));
+    CK(linear2(d.N1t, H, S.finput_t, d.Hep, He, hinter, Hp, H, P[P_WC], P[P_BC], GGPM_ACT_RELU, 0, S.hnode_t, Hp, stream));
+    CK(ggpm_gather_rows(S.hnode_t, Hp, S.src, d.E1t, H, S.hmess_t, d.ld_t, 0, 0, stream));
+    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, stream));
+    CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, 0, S.tpred, S.tagr, S.lv[0], stream));
+    CK(linear2(d.N1t, H, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, P[lp(0, L_WO)], P[lp(0, L_BO)], GGPM_ACT_RELU, 1, hnode, Hp,
+               stream));
+
+    // ---- root readout (embed_root)
+    CK(ggpm_gather_rows(S.hnode_t, Hp, roots, d.B, H, S.f, Hp, 0, Hp, stream));
+    CK(ggpm_gather_rows(S.lv[0].nei, Hp, roots, d.B, H, S.n, Hp, 0, Hp, stream));
+    CK(linear2(d.B, H, S.f, Hp, H, S.n, Hp, H, P[P_WROOT], P[P_BROOT], GGPM_ACT_TANH, 0, hroot, Hp, stream));
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+namespace {
+
+struct BwdWork {
+    float *dpre_root, *df, *dn, *d_hnode_t, *d_nei_t, *dpre, *d_h, *dX, *dx_mess, *d_finput, *d_hinter, *d_hnode_i,
+        *d_nei_i, *d_pooled, *d_hatom, *d_nei_g, *level_work, *skws, *csws;
+    size_t level_work_bytes, skws_bytes;
+};
+
+void layout_work(Arena& A, const Dims& d, BwdWork& w) {
+    const int Hp = d.Hp;
+    const int Nmax = d.N1g > d.N1t ? d.N1g : d.N1t, Emax = d.E1g > d.E1t ? d.E1g : d.E1t;
+    w.dpre_root = A.take<float>((size_t)d.B * Hp); w.df = A.take<float>((size_t)d.B * Hp);
+    w.dn = A.take<float>((size_t)d.B * Hp);
+    w.d_hnode_t = A.take<float>((size_t)d.N1t * Hp); w.d_nei_t = A.take<float>((size_t)d.N1t * Hp);
+    // dpre of the five linear layers: the weight-gradient stream still reads one while the main stream writes the
+    // next, so each gets its own buffer
+    w.dpre = A.take<float>((size_t)5 * Nmax * Hp);
+    w.d_h = A.take<float>((size_t)Emax * Hp);
+    w.dX = A.take<float>((size_t)3 * 3 * Emax * Hp);          // per level (read by the second stream afterwards)
+    w.dx_mess = A.take<float>((size_t)d.E1t * d.ld_t);
+    w.d_finput = A.take<float>((size_t)2 * d.N1t * d.Hep);
+    w.d_hinter = A.take<float>((size_t)d.N1t * Hp);
+    w.d_hnode_i = A.take<float>((size_t)d.N1t * Hp); w.d_nei_i = A.take<float>((size_t)d.N1t * Hp);
+    w.d_pooled = A.take<float>((size_t)d.N1t * Hp);
+    w.d_hatom = A.take<float>((size_t)d.N1g * Hp); w.d_nei_g = A.take<float>((size_t)d.N1g * Hp);
+    size_t lw = ggpm_gru_backward_workspace_bytes(d.E1g, d.H, d.depthG);
+    const size_t lwt = ggpm_gru_backward_workspace_bytes(d.E1t, d.H, d.depthT);
+    w.level_work_bytes = lw > lwt ? lw : lwt;
+    w.level_work = A.take<float>(3 * (w.level_work_bytes / 4 + 64));      // one per level (stashes read by stream 2)
+    size_t sk = 0;
+    const int Imax = d.It > d.Ig ? d.It : d.Ig;
+    const size_t cand[] = {ggpm_gemm_workspace_bytes(d.H, Imax, Emax), ggpm_gemm_workspace_bytes(d.H, d.Hp, Nmax),
+                           ggpm_gemm_workspace_bytes(d.H, d.Hp, d.B)};
+    for (size_t c : cand) sk = c > sk ? c : sk;
+    w.skws_bytes = sk + 1024;
+    w.skws = A.take<float>(w.skws_bytes / 4);
+    w.csws = A.take<float>((size_t)256 * (Hp > d.ld_t ? Hp : d.ld_t));
+}
+
+struct Streams {
+    ggpm_stream_t main, side;
+    int n_ev;
+    // order the second stream behind everything issued on the main stream so far
+    int side_after_main() {
+        if (!side) return GGPM_OK;
+        hipEvent_t ev = ggpm_wgrad_event(n_ev++ & 31);
+        if (!ev) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev, (hipStream_t)main);
+        (void)hipStreamWaitEvent((hipStream_t)side, ev, 0);
+        return GGPM_OK;
+    }
+    ggpm_stream_t w() const { return side ? side : main; }      // where weight gradients go
+};
+
+// weight / bias gradients of y = act(x1 W1^T + x2 W2^T + b): dW[:, :K1] = dpre^T x1, dW[:, K1:] = dpre^T x2, db = colsum
+int linear2_wgrad(int M, int N, const float* dpre, int ldp, const float* x1, int ld1, int K1, const float* x2, int ld2,
+                  int K2, float* dW, float* db, BwdWork& w, Streams& st) {
+    CK(st.side_after_main());
+    const int ldw = K1 + K2;
+    CK(ggpm_gemm(1, 0, N, K1, M, dpre, ldp, x1, ld1, dW, ldw, K1, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
+    CK(ggpm_gemm(1, 0, N, K2, M, dpre, ldp, x2, ld2, dW + K1, ldw, K2, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
+                 st.w()));
+    if (db) CK(ggpm_colsum(dpre, ldp, M, N, db, w.csws, st.w()));
+    return GGPM_OK;
+}
+
+// backward of one level given dHD = d(h_D); dx (the gradient of the level's message inputs) is optional
+int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int ldx, float* const* P, float* const* G,
+                   int level, const Csr& pred, const LevelSaved& L, const float* dHD, float* dX, float* level_work,
+                   float* dx, int lddx, BwdWork& w, Streams& st, bool overlap_wgrads = false) {
+    const int H = d.H, Hp = d.Hp;
+    const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
+    const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
+    float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
+    // The last level of the backward (the atom level) has nothing behind it to hide its weight-gradient contractions:
+    // issue them in chunks of depths on the second stream WHILE its own depth loop still runs.
+    const bool overlap = overlap_wgrads && st.side != nullptr;
+    if (overlap) {
+        CK(st.side_after_main());
+        CK(ggpm_gru_backward_overlapped(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
+                                        pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds,
+                                        L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot,
+                                        dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
+                                        w.level_work_bytes, st.main, st.side));
+    } else {
+        CK(ggpm_gru_backward(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H, pred.rowptr,
+                             pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds,
+                             L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dWz + I, I + H, dUr, H,
+                             G[lp(level, L_BU)], dWh + I, I + H, level_work, w.level_work_bytes, 0, st.main));
+    }
+    if (dx) {       // needed upstream right away: main stream
+        CK(ggpm_gemm(0, 0, E1, I, H, dX, Hp, Wz, I + H, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, st.main));
+        CK(ggpm_gemm(0, 0, E1, I, H, dX + slot, Hp, Wr, I, dx, lddx, I, nullptr, 1, GGPM_ACT_NONE, 0, nullptr, 0, st.main));
+        CK(ggpm_gemm(0, 0, E1, I, H, dX + 2 * slot, Hp, Wh, I + H, dx, lddx, I, nullptr, 1, GGPM_ACT_NONE, 0, nullptr, 0,
+                     st.main));
+    }
+    CK(st.side_after_main());
+    if (!overlap)
+        CK(ggpm_gru_weight_grads(E1, H, depth, L.Hs, L.St, L.St + ds, level_work, w.level_work_bytes, dWz + I, I + H, dUr,
+                                 H, G[lp(level, L_BU)], dWh + I, I + H, st.w()));
+    CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
+    CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
+                 st.w()));
+    CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
+                 w.skws_bytes, st.w()));
+    CK(ggpm_colsum(dX, Hp, E1, H, G[lp(level, L_BZ)], w.csws, st.w()));
+    CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, G[lp(level, L_BH)], w.csws, st.w()));
+    return GGPM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims) {
+    if (!dims) return 0;
+    const Dims d = make_dims(dims);
+    Arena A = {nullptr, 0, false, 0};
+    BwdWork w;
+    layout_work(A, d, w);
+    return A.off;
+}
+
+// grads: one buffer per parameter slot (same shapes as the parameters, every element written).  d_* may be null
+// (no gradient arrives for that output).  On return the main stream is ordered behind the second stream.
+extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* params, float* const* grads,
+                                     const int32_t* roots, void* saved, size_t saved_bytes, const float* hroot,
+                                     const float* hnode, const float* hinter, const float* hatom, const float* d_hroot,
+                                     const float* d_hnode, const float* d_hinter, const float* d_hatom, void* work,
+                                     size_t work_bytes, ggpm_stream_t stream, ggpm_stream_t side_stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!dims || !params || !grads || !roots || !saved || !work || !hroot || !hnode || !hinter || !hatom)
+        return GGPM_ERR_ARG;
+    const Dims d = make_dims(dims);
+    Arena A = {reinterpret_cast<char*>(saved), 0, false, saved_bytes};
+    Saved S;
+    layout_saved(A, d, S);
+    Arena B = {reinterpret_cast<char*>(work), 0, false, work_bytes};
+    BwdWork w;
+    layout_work(B, d, w);
+    if (A.overflow || B.overflow) return GGPM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* const* P = params;
+    float* const* G = grads;
+    const int H = d.H, Hp = d.Hp, He = d.He;
+    Streams st = {stream, side_stream, 0};
+    const int Nmax = d.N1g > d.N1t ? d.N1g : d.N1t, Emax = d.E1g > d.E1t ? d.E1g : d.E1t;
+    float* dpre[5];
+    for (int i = 0; i < 5; ++i) dpre[i] = w.dpre + (size_t)i * Nmax * Hp;
+    float* dXl[3];
+    for (int i = 0; i < 3; ++i) dXl[i] = w.dX + (size_t)i * 3 * Emax * Hp;
+    float* lwork[3];
+    for (int i = 0; i < 3; ++i) lwork[i] = w.level_work + (size_t)i * (w.level_work_bytes / 4 + 64);
+    const size_t nt = (size_t)d.N1t * Hp * sizeof(float), ng = (size_t)d.N1g * Hp * sizeof(float);
+
+    if (side_stream) {      // the transposed CSRs were built on the second stream during the forward
+        hipEvent_t ev = ggpm_wgrad_event(61);
+        if (!ev) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev, (hipStream_t)side_stream);
+        (void)hipStreamWaitEvent(s, ev, 0);
+    }
+
+    // ---- root readout
+    if (d_hroot) {
+        CK(ggpm_act_backward(d_hroot, hroot, d.B, H, Hp, GGPM_ACT_TANH, 0, w.dpre_root, stream));
+        CK(ggpm_gemm(0, 0, d.B, H, H, w.dpre_root, Hp, P[P_WROOT], 2 * H, w.df, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0, nullptr,
+                     0, stream));
+        CK(ggpm_gemm(0, 0, d.B, H, H, w.dpre_root, Hp, P[P_WROOT] + H, 2 * H, w.dn, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+                     nullptr, 0, stream));
+        CK(ggpm_segment_sum(w.df, Hp, S.root.rowptrT, S.root.colT, d.N1t, H, w.d_hnode_t, Hp, 0, Hp, stream));
+        CK(ggpm_segment_sum(w.dn, Hp, S.root.rowptrT, S.root.colT, d.N1t, H, w.d_nei_t, Hp, 0, Hp, stream));
+        CK(linear2_wgrad(d.B, H, w.dpre_root, Hp, S.f, Hp, H, S.n, Hp, H, G[P_WROOT], G[P_BROOT], w, st));
+    } else {
+        (void)hipMemsetAsync(w.d_hnode_t, 0, nt, s);
+        (void)hipMemsetAsync(w.d_nei_t, 0, nt, s);
+        (void)hipMemsetAsync(G[P_WROOT], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
+        (void)hipMemsetAsync(G[P_BROOT], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
+    }
+
+    // ---- motif level: W_o, message function, W_c / E_c
+    if (d_hnode) {
+        CK(ggpm_act_backward(d_hnode, hnode, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[0], stream));
+        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lp(0, L_WO)], 2 * H, w.d_hnode_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE, 0,
+                     nullptr, 0, stream));
+        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lp(0, L_WO)] + H, 2 * H, w.d_nei_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE,
+                     0, nullptr, 0, stream));
+        CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lp(0, L_WO)], G[lp(0, L_BO)], w, st));
+    } else {
+        (void)hipMemsetAsync(G[lp(0, L_WO)], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
+        (void)hipMemsetAsync(G[lp(0, L_BO)], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
+    }
+    CK(ggpm_segment_sum(w.d_nei_t, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
+    CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, G, 0, S.tpred, S.lv[0], w.d_h, dXl[0], lwork[0],
+                      w.dx_mess, d.ld_t, w, st));
+    CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_t, Hp, 1, 0, stream));
+    CK(ggpm_act_backward(w.d_hnode_t, S.hnode_t, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[1], stream));
+    CK(ggpm_gemm(0, 0, d.N1t, He, H, dpre[1], Hp, P[P_WC], He + H, w.d_finput, d.Hep, d.Hep, nullptr, 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, stream));
+    if (d_hinter) (void)hipMemcpyAsync(w.d_hinter, d_hinter, nt, hipMemcpyDeviceToDevice, s);
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[1], Hp, P[P_WC] + He, He + H, w.d_hinter, Hp, Hp, nullptr, d_hinter ? 1 : 0,
+                 GGPM_ACT_NONE, 0, nullptr, 0, stream));
+    CK(linear2_wgrad(d.N1t, H, dpre[1], Hp, S.finput_t, d.Hep, He, hinter, Hp, H, G[P_WC], G[P_BC], w, st));
+    CK(ggpm_segment_sum(w.d_finput, d.Hep, S.motif.rowptrT, S.motif.colT, d.n_motif, He, G[P_EC], He, 0, He, st.w()));
+
+    // ---- attachment level: W_o, message function, W_i / E_i, pooling over atoms
+    CK(ggpm_act_backward(w.d_hinter, hinter, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[2], stream));
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lp(1, L_WO)], 2 * H, w.d_hnode_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, stream));
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lp(1, L_WO)] + H, 2 * H, w.d_nei_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, stream));
+    CK(linear2_wgrad(d.N1t, H, dpre[2], Hp, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, G[lp(1, L_WO)], G[lp(1, L_BO)], w, st));
+    CK(ggpm_segment_sum(w.d_nei_i, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
+    CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, G, 1, S.tpred, S.lv[1], w.d_h, dXl[1], lwork[1],
+                      w.dx_mess, d.ld_t, w, st));
+    CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_i, Hp, 1, 0, stream));
+    CK(ggpm_act_backward(w.d_hnode_i, S.hnode_i, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[3], stream));
+    float* d_finput_i = w.d_finput + (size_t)d.N1t * d.Hep;
+    CK(ggpm_gemm(0, 0, d.N1t, He, H, dpre[3], Hp, P[P_WI], He + H, d_finput_i, d.Hep, d.Hep, nullptr, 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, stream));
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[3], Hp, P[P_WI] + He, He + H, w.d_pooled, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+                 nullptr, 0, stream));
+    CK(linear2_wgrad(d.N1t, H, dpre[3], Hp, S.finput_i, d.Hep, He, S.pooled, Hp, H, G[P_WI], G[P_BI], w, st));
+    CK(ggpm_segment_sum(d_finput_i, d.Hep, S.attach.rowptrT, S.attach.colT, d.n_attach, He, G[P_EI], He, 0, He, st.w()));
+    if (d_hatom) (void)hipMemcpyAsync(w.d_hatom, d_hatom, ng, hipMemcpyDeviceToDevice, s);
+    CK(ggpm_segment_sum(w.d_pooled, Hp, S.tcgr.rowptrT, S.tcgr.colT, d.N1g, H, w.d_hatom, Hp, d_hatom ? 1 : 0,
+                        d_hatom ? 0 : Hp, stream));
+
+    // ---- atom level: W_o, message function (its inputs are constants)
+    CK(ggpm_act_backward(w.d_hatom, hatom, d.N1g, H, Hp, GGPM_ACT_RELU, 1, dpre[4], stream));
+    CK(ggpm_gemm(0, 0, d.N1g, H, H, dpre[4], Hp, P[lp(2, L_WO)] + d.atom, d.atom + H, w.d_nei_g, Hp, Hp, nullptr, 0,
+                 GGPM_ACT_NONE, 0, nullptr, 0, stream));
+    CK(linear2_wgrad(d.N1g, H, dpre[4], Hp, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, G[lp(2, L_WO)], G[lp(2, L_BO)], w,
+                     st));
+    CK(ggpm_segment_sum(w.d_nei_g, Hp, S.gagr.rowptrT, S.gagr.colT, d.E1g, H, w.d_h, Hp, 0, Hp, stream));
+    CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],
+                      nullptr, 0, w, st, getenv("GGPM_WGRAD_OVERLAP") != nullptr && atoi(getenv("GGPM_WGRAD_OVERLAP")) != 0));
+
+    if (side_stream) {      // every gradient buffer is complete once the main stream has passed this point
+        hipEvent_t ev = ggpm_wgrad_event(62);
+        if (!ev) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev, (hipStream_t)side_stream);
+        (void)hipStreamWaitEvent(s, ev, 0);
+    }
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

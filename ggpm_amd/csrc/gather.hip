@@ -9,12 +9,13 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) segment_sum_k(const float* __restrict__ src, int ld_src,
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, int rows, int width,
-                                                     float* __restrict__ out, int ld_out, int accumulate) {
+                                                     float* __restrict__ out, int ld_out, int accumulate, int zero_to) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lo = rowptr[r], hi = rowptr[r + 1];
     float* dst = out + (size_t)r * ld_out;
+    for (int c = width + lane; c < zero_to; c += 64) dst[c] = 0.f;      // pad columns of the row
     if (VEC) {
         for (int c = lane * 4; c < width; c += 256) {
             float4 acc = accumulate ? ggpm_ld4(dst + c) : ggpm_zero4();
@@ -32,12 +33,13 @@ __global__ void __launch_bounds__(256) segment_sum_k(const float* __restrict__ s
 
 __global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ table, int ld_table,
                                                      const int32_t* __restrict__ idx, int rows, int width,
-                                                     float* __restrict__ out, int ld_out, int col_off) {
+                                                     float* __restrict__ out, int ld_out, int col_off, int zero_to) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int id = idx[r];
     float* dst = out + (size_t)r * ld_out + col_off;
+    for (int c = width + lane; c < zero_to - col_off; c += 64) dst[c] = 0.f;
     if (id < 0) {
         for (int c = lane; c < width; c += 64) dst[c] = 0.f;
     } else {
@@ -47,11 +49,11 @@ __global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ t
 }
 
 __global__ void onehot_k(const int32_t* __restrict__ idx, int rows, int classes, float* __restrict__ out,
-                         int ld_out, int col_off) {
+                         int ld_out, int col_off, int zero_to) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
-    if (c >= classes) return;
-    out[(size_t)r * ld_out + col_off + c] = (idx[r] == c) ? 1.f : 0.f;
+    if (col_off + c >= (zero_to > col_off + classes ? zero_to : col_off + classes)) return;
+    out[(size_t)r * ld_out + col_off + c] = (c < classes && idx[r] == c) ? 1.f : 0.f;
 }
 
 __global__ void embed_graph_k(const int64_t* __restrict__ fnode, int N1, const int64_t* __restrict__ fmess,
@@ -78,7 +80,7 @@ __global__ void embed_graph_k(const int64_t* __restrict__ fnode, int N1, const i
 }  // namespace
 
 extern "C" int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const int32_t* col,
-                                int rows, int width, float* out, int ld_out, int accumulate,
+                                int rows, int width, float* out, int ld_out, int accumulate, int zero_to,
                                 ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (!src || !rowptr || !col || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
@@ -86,28 +88,30 @@ extern "C" int ggpm_segment_sum(const float* src, int ld_src, const int32_t* row
     const bool vec = (width % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) &&
                      (((uintptr_t)src & 15) == 0) && (((uintptr_t)out & 15) == 0);
     const int grid = ggpm_ceil_div(rows, 4);
-    if (vec) segment_sum_k<true><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate);
-    else segment_sum_k<false><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate);
+    if (vec) segment_sum_k<true><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate,
+                                                           zero_to);
+    else segment_sum_k<false><<<grid, 256, 0, s>>>(src, ld_src, rowptr, col, rows, width, out, ld_out, accumulate, zero_to);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
 
 extern "C" int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
-                                float* out, int ld_out, int col_off, ggpm_stream_t stream) {
+                                float* out, int ld_out, int col_off, int zero_to, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (!table || !idx || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
     gather_rows_k<<<ggpm_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(table, ld_table, idx, rows, width, out,
-                                                                          ld_out, col_off);
+                                                                          ld_out, col_off, zero_to);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
 
-extern "C" int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off,
+extern "C" int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off, int zero_to,
                            ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (!idx || !out || rows <= 0 || classes <= 0) return GGPM_ERR_ARG;
-    dim3 grid(ggpm_ceil_div(classes, 64), rows);
-    onehot_k<<<grid, 64, 0, (hipStream_t)stream>>>(idx, rows, classes, out, ld_out, col_off);
+    const int span = (zero_to > col_off + classes ? zero_to - col_off : classes);
+    dim3 grid(ggpm_ceil_div(span, 64), rows);
+    onehot_k<<<grid, 64, 0, (hipStream_t)stream>>>(idx, rows, classes, out, ld_out, col_off, zero_to);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

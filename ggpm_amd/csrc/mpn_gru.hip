@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         float4 s = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4(), oxz = ggpm_zero4(), oxh = ggpm_zero4();
         if (!a.final_pass) {
             s = ggpm_ld4(a.S + o); z = ggpm_ld4(a.Z + o); m = ggpm_ld4(a.M + o);
-            oxz = ggpm_ld4(a.dXz + o); oxh = ggpm_ld4(a.dXh + o);
+            if (!a.first) { oxz = ggpm_ld4(a.dXz + o); oxh = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
         }
         const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
         f32x4 acc[1][RT];
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
         const float4 dsd = it == 0 ? dsd_keep[0] : dsd_keep[1];
-        const float4 rco = ggpm_ld4(a.R + o), oxr = ggpm_ld4(a.dXr + o);
+        const float4 rco = ggpm_ld4(a.R + o), oxr = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
         f32x4 acc[2][RT];
         ggpm_zero_acc<2, RT>(acc);
         {
@@ -446,7 +446,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
-        const float4 dsd = ggpm_ld4(a.DSD + o), rco = ggpm_ld4(a.R + o), oxr = ggpm_ld4(a.dXr + o);
+        const float4 dsd = ggpm_ld4(a.DSD + o), rco = ggpm_ld4(a.R + o);
+        const float4 oxr = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
         f32x4 acc[2][RT];
         ggpm_zero_acc<2, RT>(acc);
         {
@@ -698,9 +699,8 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWzT; pk.bias = nullptr; pk.bias_out = nullptr;
         ggpm_launch_pack(pk, 3, s);
     }
-    (void)hipMemsetAsync(dXz, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(dXh, 0, slot * sizeof(float), s);
+    // dXz / dXh are started (not accumulated) by the first backward depth; so is dXr when that depth has a dS/dG product
+    if (depth == 1 && !frozen) (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
     if (frozen) (void)hipMemsetAsync(carry, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);

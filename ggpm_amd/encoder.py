@@ -72,8 +72,14 @@ class PreparedBatch:
         self.tree = LevelGraph(tfmess, tagraph, tbgraph, tcgraph, n_lower=gfnode.shape[0])
         self.motif_id = F_.extract_column(tfnode, 0)
         self.attach_id = F_.extract_column(tfnode, 1)
-        # roots may be handed in as a device tensor (hipGraph capture: no host list inside the captured region)
         self.roots = roots if roots is not None else _RING.upload([st for st, _ in tscope], tfnode.device)
+        self.root_csr = F_.csr_from_index(self.roots, ncols=tfnode.shape[0])
+        self.motif_csr = self.attach_csr = None      # set by the encoder (they need the vocabulary sizes)
+
+    def prefetch_backward_structures(self):
+        """Transposed CSRs are only read by the backward: build them beside the forward, off the critical path."""
+        F_.prefetch_transposes([self.graph.pred, self.graph.agr, self.tree.pred, self.tree.agr, self.tree.src_csr,
+                                self.tree.cgr, self.root_csr, self.motif_csr, self.attach_csr])
 
 
 class MPNEncoder(nn.Module):
@@ -164,7 +170,7 @@ class HierMPNEncoder(nn.Module):
         H, He = self.hidden_size, self.embed_size
         emb = self.E_i[0].weight
         ids = prep.attach_id
-        finput = F_.gather_rows(emb, ids, F_.csr_from_index(ids, ncols=emb.shape[0]), He, F_.padded_hidden(He))
+        finput = F_.gather_rows(emb, ids, prep.attach_csr, He, F_.padded_hidden(He))
         finput = self.E_i[1](finput)
         pooled = F_.segment_sum(hatom, prep.tree.cgr, H)
         hnode = F_.linear([finput, pooled], [He, H], self.W_i[0].weight, self.W_i[0].bias, act=F_.ACT_RELU)
@@ -175,7 +181,7 @@ class HierMPNEncoder(nn.Module):
         H, He = self.hidden_size, self.embed_size
         emb = self.E_c[0].weight
         ids = prep.motif_id
-        finput = F_.gather_rows(emb, ids, F_.csr_from_index(ids, ncols=emb.shape[0]), He, F_.padded_hidden(He))
+        finput = F_.gather_rows(emb, ids, prep.motif_csr, He, F_.padded_hidden(He))
         finput = self.E_c[1](finput)
         hnode = F_.linear([finput, hinter], [He, H], self.W_c[0].weight, self.W_c[0].bias, act=F_.ACT_RELU)
         hnode = self.W_c[2](hnode)
@@ -185,16 +191,42 @@ class HierMPNEncoder(nn.Module):
         """tanh(W_root [hnode_in[root], sum hmess[agraph[root]]]) -- reference ggpm/encoder.py:128-138."""
         H = self.hidden_size
         roots = prep.roots
-        rcsr = F_.csr_from_index(roots, ncols=hnode_in.shape[0])
+        rcsr = prep.root_csr
         f = F_.gather_rows(hnode_in, roots, rcsr, H, F_.padded_hidden(H))
         n = F_.gather_rows(nei, roots, rcsr, H, F_.padded_hidden(H))
         return F_.linear([f, n], [H, H], self.W_root[0].weight, self.W_root[0].bias, act=F_.ACT_TANH)
 
     # ------------------------------------------------------------------ forward
+    def _fused_ok(self, tree_tensors, graph_tensors) -> bool:
+        """The one-call C++ driver covers the GRU message function without dropout on int64 device tensors."""
+        from . import fused
+        if not fused.enabled() or not isinstance(self.graph_encoder.rnn, GRU):
+            return False
+        if self.training and self.dropout > 0:
+            return False
+        if type(self.tree_encoder) is not MPNEncoder or self.atom_size + 24 > 252:
+            return False
+        ts = list(tree_tensors[:5]) + list(graph_tensors[:4])
+        return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 for t in ts)
+
+    def _fused_check(self):
+        """The tensors whose identity invalidates the cached parameter list (tie_embedding / load into new modules)."""
+        return (self.E_c[0].weight, self.E_i[0].weight)
+
     def forward_padded(self, tree_tensors, graph_tensors, prep: Optional[PreparedBatch] = None,
                        roots: Optional[torch.Tensor] = None):
+        if prep is None and self._fused_ok(tree_tensors, graph_tensors):
+            from . import fused
+            if roots is None:
+                roots = _RING.upload([st for st, _ in tree_tensors[-1]], tree_tensors[0].device)
+            return fused.hier_encoder(self, tree_tensors, graph_tensors, roots)
         if prep is None:
             prep = PreparedBatch(tree_tensors, graph_tensors, roots)
+        if prep.motif_csr is None:
+            prep.motif_csr = F_.csr_from_index(prep.motif_id, ncols=self.E_c[0].weight.shape[0])
+            prep.attach_csr = F_.csr_from_index(prep.attach_id, ncols=self.E_i[0].weight.shape[0])
+        if torch.is_grad_enabled():
+            prep.prefetch_backward_structures()
         hnode_a, hmess_a = self.embed_graph_padded(graph_tensors)
         hatom, _, _ = self.graph_encoder.forward_padded(hnode_a, hmess_a, prep.graph.agr, prep.graph.pred)
 

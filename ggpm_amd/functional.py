@@ -53,6 +53,8 @@ class CSR:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, rows: int, ncols: int):
         self.rowptr, self.col, self.rows, self.ncols = rowptr, col, rows, ncols
         self._T: Optional["CSR"] = None
+        self._T_event = None
+        self._keep = None
         self._clusters = {}
 
     def clusters(self, target: int) -> torch.Tensor:
@@ -68,19 +70,50 @@ class CSR:
             self._clusters[target] = tab
         return tab
 
+    def _build_T(self) -> "CSR":
+        lib = _lib.load()
+        dev = self.col.device
+        rowptrT = torch.empty(self.ncols + 1, dtype=torch.int32, device=dev)
+        colT = torch.empty(max(self.col.numel(), 1), dtype=torch.int32, device=dev)
+        cursor = torch.empty(self.ncols, dtype=torch.int32, device=dev)
+        _lib.check(lib.ggpm_csr_transpose(_p(self.rowptr), _p(self.col), self.rows, self.ncols, _p(rowptrT),
+                                          _p(colT), _p(cursor), _stream()), "csr_transpose")
+        t = CSR(rowptrT, colT, self.ncols, self.rows)
+        t._T = self
+        t._keep = cursor
+        return t
+
     @property
     def T(self) -> "CSR":
         if self._T is None:
-            lib = _lib.load()
-            dev = self.col.device
-            rowptrT = torch.empty(self.ncols + 1, dtype=torch.int32, device=dev)
-            colT = torch.empty(max(self.col.numel(), 1), dtype=torch.int32, device=dev)
-            cursor = torch.empty(self.ncols, dtype=torch.int32, device=dev)
-            _lib.check(lib.ggpm_csr_transpose(_p(self.rowptr), _p(self.col), self.rows, self.ncols, _p(rowptrT),
-                                              _p(colT), _p(cursor), _stream()), "csr_transpose")
-            self._T = CSR(rowptrT, colT, self.ncols, self.rows)
-            self._T._T = self
+            self._T = self._build_T()
+        ev = self._T_event
+        if ev is not None:          # built ahead of time on the second stream: order this stream behind it once
+            torch.cuda.current_stream().wait_event(ev)
+            self._T_event = None
         return self._T
+
+
+def prefetch_transposes(csrs: Sequence["CSR"]) -> None:
+    """Build the transposes the BACKWARD will need on the second stream while the forward runs (each is a
+    single-workgroup integer kernel of ~10 us that would otherwise sit on the backward's critical path)."""
+    todo = [c for c in csrs if c is not None and c._T is None]
+    if not todo or not side_stream_enabled():
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(todo[0].col.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for c in todo:
+            c._T = c._build_T()
+            for t in (c.rowptr, c.col):
+                t.record_stream(side)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for c in todo:
+        for t in (c._T.rowptr, c._T.col, c._T._keep):
+            t.record_stream(main)
+        c._T_event = ev
 
 
 def csr_from_padded(padded: torch.Tensor, ncols: int) -> CSR:
@@ -137,8 +170,9 @@ def colsum(A: torch.Tensor, M: int, N: int) -> torch.Tensor:
 
 
 def _segment_sum_raw(src: torch.Tensor, csr: CSR, width: int, out: torch.Tensor) -> None:
+    """out[:, :width] = segmented sums; the kernel also zeroes the pad columns [width, out.shape[1])."""
     _lib.check(_lib.load().ggpm_segment_sum(_p(src), _ld(src), _p(csr.rowptr), _p(csr.col), csr.rows, width,
-                                            _p(out), _ld(out), 0, _stream()), "segment_sum")
+                                            _p(out), _ld(out), 0, out.shape[1], _stream()), "segment_sum")
 
 
 # ----------------------------------------------------------------------------- autograd functions
@@ -236,8 +270,6 @@ class _SegmentSum(torch.autograd.Function):
     def forward(ctx, src, csr, width):
         _need_gpu(src)
         out = torch.empty(csr.rows, _ld(src), dtype=torch.float32, device=src.device)
-        if _ld(src) > width:
-            out[:, width:].zero_()
         _segment_sum_raw(src, csr, width, out)
         ctx.csr, ctx.width, ctx.src_rows, ctx.src_cols = csr, width, src.shape[0], src.shape[1]
         return out
@@ -248,8 +280,6 @@ class _SegmentSum(torch.autograd.Function):
         csrT = ctx.csr.T
         assert csrT.rows == ctx.src_rows
         dsrc = torch.empty(ctx.src_rows, _ld(dout), dtype=torch.float32, device=dout.device)
-        if _ld(dout) > ctx.width:
-            dsrc[:, ctx.width:].zero_()
         _segment_sum_raw(dout, csrT, ctx.width, dsrc)
         return dsrc[:, :ctx.src_cols], None, None     # src may have been a [rows, H] view of a padded buffer
 
@@ -266,10 +296,8 @@ class _GatherRows(torch.autograd.Function):
         _need_gpu(table, idx)
         rows = idx.numel()
         out = torch.empty(rows, ld_out, dtype=torch.float32, device=table.device)
-        if ld_out > width:
-            out[:, width:].zero_()
         _lib.check(_lib.load().ggpm_gather_rows(_p(table), _ld(table), _p(idx), rows, width, _p(out), ld_out, 0,
-                                                _stream()), "gather_rows")
+                                                ld_out, _stream()), "gather_rows")
         ctx.idx_csr, ctx.width, ctx.tshape, ctx.tld = idx_csr, width, table.shape, _ld(table)
         return out
 
@@ -278,8 +306,6 @@ class _GatherRows(torch.autograd.Function):
         dout = dout.contiguous() if dout.stride(1) != 1 else dout
         csrT = ctx.idx_csr.T
         dtable = torch.empty(ctx.tshape, dtype=torch.float32, device=dout.device)
-        if ctx.tshape[1] > ctx.width:
-            dtable[:, ctx.width:].zero_()
         _segment_sum_raw(dout, csrT, ctx.width, dtable)
         return dtable, None, None, None, None
 
@@ -297,11 +323,9 @@ class _TreeMessInput(torch.autograd.Function):
         lib = _lib.load()
         rows = src.numel()
         out = torch.empty(rows, ld_out, dtype=torch.float32, device=hnode.device)
-        if ld_out > H + n_pos:
-            out[:, H + n_pos:].zero_()
-        _lib.check(lib.ggpm_gather_rows(_p(hnode), _ld(hnode), _p(src), rows, H, _p(out), ld_out, 0, _stream()),
+        _lib.check(lib.ggpm_gather_rows(_p(hnode), _ld(hnode), _p(src), rows, H, _p(out), ld_out, 0, 0, _stream()),
                    "gather_rows")
-        _lib.check(lib.ggpm_onehot(_p(pos), rows, n_pos, _p(out), ld_out, H, _stream()), "onehot")
+        _lib.check(lib.ggpm_onehot(_p(pos), rows, n_pos, _p(out), ld_out, H, ld_out, _stream()), "onehot")
         ctx.src_csr, ctx.H, ctx.nshape = src_csr, H, hnode.shape
         return out
 
@@ -310,8 +334,6 @@ class _TreeMessInput(torch.autograd.Function):
         dout = dout.contiguous() if dout.stride(1) != 1 else dout
         csrT = ctx.src_csr.T
         dh = torch.empty(ctx.nshape, dtype=torch.float32, device=dout.device)
-        if ctx.nshape[1] > ctx.H:
-            dh[:, ctx.H:].zero_()
         _segment_sum_raw(dout, csrT, ctx.H, dh)
         return dh, None, None, None, None, None, None
 

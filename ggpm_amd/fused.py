@@ -1,0 +1,119 @@
+"""Whole-encoder autograd node on the C++ drivers of csrc/encoder.hip (ggpm_encoder_forward / _backward).
+
+One ctypes call per direction instead of ~150: at MI355X speeds the op-by-op host path (functional.py) needs about as
+long to ENQUEUE a step as the GPU needs to run it.  Same kernels, same order, same results; used by
+``HierMPNEncoder.forward_padded`` for the GRU message function with dropout 0 (anything else keeps the op-by-op
+path).  GGPM_FUSED_ENCODER=0 switches it off.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List
+
+import torch
+
+from . import _lib
+from . import functional as F_
+
+PARAM_ORDER = (["E_c.0.weight", "E_i.0.weight", "W_c.0.weight", "W_c.0.bias", "W_i.0.weight", "W_i.0.bias",
+                "W_root.0.weight", "W_root.0.bias"] +
+               [lvl + "." + k for lvl in ("tree_encoder", "inter_encoder", "graph_encoder")
+                for k in ("W_o.0.weight", "W_o.0.bias", "rnn.W_z.weight", "rnn.W_z.bias", "rnn.W_r.weight",
+                          "rnn.U_r.weight", "rnn.U_r.bias", "rnn.W_h.weight", "rnn.W_h.bias")])
+
+
+class EncDims(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int) for k in ("H", "He", "depthT", "depthG", "atom_size", "n_motif", "n_attach", "N1g",
+                                            "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B")]
+
+
+def enabled() -> bool:
+    return os.environ.get("GGPM_FUSED_ENCODER", "1") != "0"
+
+
+def _ptr_array(tensors) -> ctypes.Array:
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _side_ptr(device):
+    if not F_.side_stream_enabled():
+        return None, ctypes.c_void_p(0)
+    side = F_._side_stream(device)
+    return side, ctypes.c_void_p(side.cuda_stream)
+
+
+class _HierEncoder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dims: EncDims, tree_tensors, graph_tensors, roots, *params):
+        lib = _lib.load()
+        dev = params[0].device
+        tfnode, tfmess, tagraph, tbgraph, tcgraph = [t.contiguous() for t in tree_tensors[:5]]
+        gfnode, gfmess, gagraph, gbgraph = [t.contiguous() for t in graph_tensors[:4]]
+        Hp = F_.padded_hidden(dims.H)
+        f32 = dict(dtype=torch.float32, device=dev)
+        saved_bytes = int(lib.ggpm_encoder_saved_bytes(ctypes.byref(dims)))
+        saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+        hroot = torch.empty(dims.B, Hp, **f32)
+        hnode = torch.empty(dims.N1t, Hp, **f32)
+        hinter = torch.empty(dims.N1t, Hp, **f32)
+        hatom = torch.empty(dims.N1g, Hp, **f32)
+        params = [p if p.is_contiguous() else p.contiguous() for p in params]
+        side, side_p = _side_ptr(dev)
+        if side is not None:
+            saved.record_stream(side)
+            roots.record_stream(side)
+        P = F_._p
+        _lib.check(lib.ggpm_encoder_forward(ctypes.byref(dims), _ptr_array(params), P(tfnode), P(tfmess), P(tagraph),
+                                            P(tbgraph), P(tcgraph), P(gfnode), P(gfmess), P(gagraph), P(gbgraph),
+                                            P(roots), P(saved), saved_bytes, P(hroot), P(hnode), P(hinter), P(hatom),
+                                            F_._stream(), side_p), "encoder_forward")
+        if any(ctx.needs_input_grad):
+            ctx.dims, ctx.saved_arena, ctx.roots, ctx.params = dims, saved, roots, params
+            ctx.outs = (hroot, hnode, hinter, hatom)
+        return hroot, hnode, hinter, hatom
+
+    @staticmethod
+    def backward(ctx, d_hroot, d_hnode, d_hinter, d_hatom):
+        lib = _lib.load()
+        dims, saved, roots, params = ctx.dims, ctx.saved_arena, ctx.roots, ctx.params
+        hroot, hnode, hinter, hatom = ctx.outs
+        dev = saved.device
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads: List[torch.Tensor] = []
+        off = 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        work_bytes = int(lib.ggpm_encoder_work_bytes(ctypes.byref(dims)))
+        work = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
+        side, side_p = _side_ptr(dev)
+        if side is not None:
+            for t in (flat, work):
+                t.record_stream(side)
+        douts = [None if g is None else g.contiguous() for g in (d_hroot, d_hnode, d_hinter, d_hatom)]
+        P = F_._p
+        _lib.check(lib.ggpm_encoder_backward(ctypes.byref(dims), _ptr_array(params), _ptr_array(grads), P(roots), P(saved),
+                                             saved.numel(), P(hroot), P(hnode), P(hinter), P(hatom), P(douts[0]),
+                                             P(douts[1]), P(douts[2]), P(douts[3]), P(work), work_bytes, F_._stream(),
+                                             side_p), "encoder_backward")
+        ctx.saved_arena = ctx.outs = None
+        return (None, None, None, None, *grads)
+
+
+def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
+    """-> (hroot, hnode, hinter, hatom) as [rows, Hp] tensors; ``encoder`` is a HierMPNEncoder with GRU levels."""
+    params = getattr(encoder, "_fused_params", None)
+    if params is None or any(p is not q for p, q in zip(params, encoder._fused_check())):
+        sd = dict(encoder.named_parameters())
+        params = [sd[k] for k in PARAM_ORDER]
+        encoder._fused_params = params
+    tf, gf = tree_tensors, graph_tensors
+    dims = EncDims(encoder.hidden_size, encoder.embed_size, encoder.tree_encoder.depth, encoder.graph_encoder.depth,
+                   encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
+                   gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
+                   tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel())
+    return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, *params)

@@ -87,16 +87,18 @@ int ggpm_act_backward(const float* dy, const float* y, int rows, int cols, int l
 /* ------------------------------------------------------------------ gathers / segmented sums
  * out[r, 0:width] = sum_{j in rowptr[r]..rowptr[r+1]} src[col[j], 0:width]
  * = index_select_ND(h, 0, agraph).sum(1) of ggpm/encoder.py:31-32,99,135-136 (and, through the
- * transposed CSR, every scatter-add autograd would run for their backward).  accumulate!=0 adds to out. */
+ * transposed CSR, every scatter-add autograd would run for their backward).  accumulate!=0 adds to out.
+ * zero_to (all three below): columns [end of the written block, zero_to) of every row are set to 0 as well (the pad
+ * columns of the Hp-strided matrices), 0 = leave them alone. */
 int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const int32_t* col, int rows,
-                     int width, float* out, int ld_out, int accumulate, ggpm_stream_t stream);
+                     int width, float* out, int ld_out, int accumulate, int zero_to, ggpm_stream_t stream);
 /* out[r, col_off : col_off+width] = table[idx[r], 0:width]; rows with idx<0 give zeros.
  * = nn.Embedding / index_select of ggpm/encoder.py:98,103,111,114 */
 int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
-                     float* out, int ld_out, int col_off, ggpm_stream_t stream);
+                     float* out, int ld_out, int col_off, int zero_to, ggpm_stream_t stream);
 /* out[r, col_off + idx[r]] = 1, the other `classes` columns of that block 0: the one-hot tables
  * E_a/E_b/E_apos/E_pos of ggpm/encoder.py:74-77,121-125,104-105. */
-int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off,
+int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off, int zero_to,
                 ggpm_stream_t stream);
 /* embed_graph (ggpm/encoder.py:119-126) in one launch: hnode[N1, ld_n] = onehot(fnode), hmess[E1, ld_m] =
  * [onehot(fnode[src]) | onehot(bond) | onehot(pos)] from the int64 A0 tensors. */
@@ -216,6 +218,37 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
                               float* dXo, float* dXu, float* dXf, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                               float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
                               ggpm_stream_t stream);
+
+/* ------------------------------------------------------------------ whole-encoder drivers
+ * HierMPNEncoder.forward (ggpm/encoder.py:140-157, with embed_graph/inter/tree/root :96-138) and its backward as ONE
+ * call each: the same kernels the op-by-op host path issues, sequenced from C++ (GRU message function, dropout 0).
+ * Inputs are the A0 tensors of MolGraph.tensorize() after make_cuda (int64, row-major) plus the molecules' root node
+ * ids; outputs are [rows, Hp] with zero pad columns (Hp = ggpm_padded_hidden(H)).
+ * params / grads: 35 device pointers, contiguous fp32, in this order (shapes as in the reference state_dict):
+ *   E_c.0.weight, E_i.0.weight, W_c.0.weight, W_c.0.bias, W_i.0.weight, W_i.0.bias, W_root.0.weight, W_root.0.bias,
+ *   then for tree_encoder, inter_encoder, graph_encoder: W_o.0.weight, W_o.0.bias, rnn.W_z.weight, rnn.W_z.bias,
+ *   rnn.W_r.weight, rnn.U_r.weight, rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias.
+ * saved: ggpm_encoder_saved_bytes() bytes written by the forward and read by the backward; work: backward scratch of
+ * ggpm_encoder_work_bytes().  side_stream (may be 0): transposed CSRs and all weight-gradient contractions run there,
+ * event-ordered against `stream`; on return from the backward `stream` is ordered behind it.  d_* may be null. */
+typedef struct ggpm_enc_dims {
+    int H, He, depthT, depthG, atom_size, n_motif, n_attach;
+    int N1g, E1g, Kg_a, Kg_b;            /* atom graph: nodes+1, messages+1, agraph / bgraph widths */
+    int N1t, E1t, Kt_a, Kt_b, Kt_c;      /* motif tree: nodes+1, messages+1, agraph / bgraph / cgraph widths */
+    int B;                               /* molecules */
+} ggpm_enc_dims;
+size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims);
+size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims);
+int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* params, const int64_t* tfnode, const int64_t* tfmess,
+                         const int64_t* tagraph, const int64_t* tbgraph, const int64_t* tcgraph, const int64_t* gfnode,
+                         const int64_t* gfmess, const int64_t* gagraph, const int64_t* gbgraph, const int32_t* roots,
+                         void* saved, size_t saved_bytes, float* hroot, float* hnode, float* hinter, float* hatom,
+                         ggpm_stream_t stream, ggpm_stream_t side_stream);
+int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* params, float* const* grads, const int32_t* roots,
+                          void* saved, size_t saved_bytes, const float* hroot, const float* hnode, const float* hinter,
+                          const float* hatom, const float* d_hroot, const float* d_hnode, const float* d_hinter,
+                          const float* d_hatom, void* work, size_t work_bytes, ggpm_stream_t stream,
+                          ggpm_stream_t side_stream);
 
 /* ------------------------------------------------------------------ persistent depth loop (molecule clusters)
  * The message recurrence of ggpm/rnn.py:41-50 only couples messages of one molecule.  ggpm_build_clusters cuts the
