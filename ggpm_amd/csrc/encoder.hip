@@ -331,21 +331,41 @@ int linear2_wgrad(int M, int N, const float* dpre, int ldp, const float* x1, int
 // backward of one level given dHD = d(h_D); dx (the gradient of the level's message inputs) is optional
 int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int ldx, float* const* P, float* const* G,
                    int level, const Csr& pred, const LevelSaved& L, const float* dHD, float* dX, float* level_work,
-                   float* dx, int lddx, BwdWork& w, Streams& st, bool overlap_wgrads = false) {
+                   float* dx, int lddx, BwdWork& w, Streams& st, int overlap_wgrads = 0) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
     // The last level of the backward (the atom level) has nothing behind it to hide its weight-gradient contractions:
     // issue them in chunks of depths on the second stream WHILE its own depth loop still runs.
-    const bool overlap = overlap_wgrads && st.side != nullptr;
+    const bool overlap = overlap_wgrads != 0 && st.side != nullptr;
     if (overlap) {
         CK(st.side_after_main());
+        ggpm_stream_t chunk_stream = st.side;
+        if (overlap_wgrads == 2) {          // chunks on a LOW-priority stream: they should only fill idle CUs
+            static thread_local hipStream_t lowp = nullptr;
+            if (!lowp) {
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                if (hipStreamCreateWithPriority(&lowp, hipStreamNonBlocking, least) != hipSuccess) lowp = nullptr;
+            }
+            if (lowp) {
+                hipEvent_t ev = ggpm_wgrad_event(58);
+                (void)hipEventRecord(ev, (hipStream_t)st.side);
+                (void)hipStreamWaitEvent(lowp, ev, 0);
+                chunk_stream = lowp;
+            }
+        }
         CK(ggpm_gru_backward_overlapped(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
                                         pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds,
                                         L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot,
                                         dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
-                                        w.level_work_bytes, st.main, st.side));
+                                        w.level_work_bytes, st.main, chunk_stream));
+        if (chunk_stream != st.side) {      // the rest of the second stream's work comes after the chunks
+            hipEvent_t ev = ggpm_wgrad_event(59);
+            (void)hipEventRecord(ev, (hipStream_t)chunk_stream);
+            (void)hipStreamWaitEvent((hipStream_t)st.side, ev, 0);
+        }
     } else {
         CK(ggpm_gru_backward(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H, pred.rowptr,
                              pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds,
@@ -495,7 +515,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                      st));
     CK(ggpm_segment_sum(w.d_nei_g, Hp, S.gagr.rowptrT, S.gagr.colT, d.E1g, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],
-                      nullptr, 0, w, st, getenv("GGPM_WGRAD_OVERLAP") != nullptr && atoi(getenv("GGPM_WGRAD_OVERLAP")) != 0));
+                      nullptr, 0, w, st, getenv("GGPM_WGRAD_OVERLAP") ? atoi(getenv("GGPM_WGRAD_OVERLAP")) : 0));
 
     if (side_stream) {      // every gradient buffer is complete once the main stream has passed this point
         hipEvent_t ev = ggpm_wgrad_event(62);

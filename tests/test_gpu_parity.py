@@ -430,3 +430,41 @@ def test_persistent_depth_loop_matches_stepwise_kernels(rnn, H, depth, motifs, B
         for a, b in zip(*res):
             scale = max(float(a.abs().max()), 1e-6)
             assert float((a - b).abs().max()) <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------ whole-encoder C++ drivers
+@pytest.mark.parametrize("name", ["tiny_gru_s0", "tiny_gru_s1", "cfg_gru_s1"])
+@pytest.mark.parametrize("which", ["all", "root_only", "atom_only", "node_inter"])
+def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
+    """ggpm_encoder_forward/backward (one C call per direction) against the op-by-op host composition of the same
+    kernels: identical outputs, and identical gradients for every subset of outputs that receives a gradient
+    (absent output gradients take the null-pointer branches of the backward driver)."""
+    g = Golden(name)
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GGPM_FUSED_ENCODER", flag)
+        model = _build_encoder(g)
+        z, kl, outs = model(g.numpy_tensors(), perturb_z=False)
+        hroot, hnode, hinter, hatom = outs
+        coeffs = [torch.from_numpy(c).to(_dev()) for c in g.loss_coeffs([tuple(o.shape) for o in outs])]
+        if which == "all":
+            loss = kl + sum((c * o).sum() for c, o in zip(coeffs, outs))
+        elif which == "root_only":
+            loss = kl
+        elif which == "atom_only":
+            loss = (coeffs[3] * hatom).sum()
+        else:
+            loss = (coeffs[1] * hnode).sum() + (coeffs[2] * hinter).sum()
+        loss.backward()
+        res.append(([o.detach().clone() for o in outs],
+                    {k: (v.grad.clone() if v.grad is not None else None) for k, v in model.named_parameters()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)                     # same kernels, same order: bit-identical forward
+    for k in res[0][1]:
+        ga, gb = res[0][1][k], res[1][1][k]
+        if ga is None or gb is None:                 # the fused node always returns a (zero) gradient
+            other = gb if ga is None else ga
+            assert other is None or float(other.abs().max()) == 0.0, k
+            continue
+        scale = max(float(ga.abs().max()), 1e-12)
+        assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, k
