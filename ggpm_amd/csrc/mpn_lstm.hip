@@ -26,6 +26,7 @@ struct LstmFwdArgs {
     const float *Wi, *Wo, *Wu, *Wf;  // packed
     const int32_t *rowptr, *col;
     const unsigned char* frozen;     // sparse_forward only: rows that keep their (h, c)
+    int fuse_b;                      // single column group: kernel A also forms qf' = Wf_h h' (no B launch)
 };
 
 __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w); }
@@ -108,10 +109,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         }
     }
 
-    __syncthreads();
+    ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
     const int t_end = min(NT, (grp + 1) * a.tg);
+    float* Th = lds + 2 * ROWS * LD;      // fused P3 only: the complete h' rows of this workgroup
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
@@ -123,8 +125,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
             const float* const wps[3] = {a.Wi, a.Wo, a.Wu};
             ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        if (row >= a.E1) continue;
         float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
+        if (row >= a.E1) {
+            if (a.fuse_b) ggpm_st4(Th + lr * LD + c, h);
+            continue;
+        }
         if (a.frozen && a.frozen[row]) {
             h = ggpm_ld4(a.Hprev + o);             // gates stashed as 0 => the backward passes dh, dc through
             cn = ggpm_ld4(a.Cprev + o);
@@ -141,11 +146,25 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         }
         ggpm_st4(a.Hnew + o, h);
         ggpm_st4(a.Cnew + o, cn);
+        if (a.fuse_b) ggpm_st4(Th + lr * LD + c, h);
         if (STASH) {
             ggpm_st4(a.I + o, gi);
             ggpm_st4(a.O + o, go);
             ggpm_st4(a.U + o, gu);
         }
+    }
+    if (!a.fuse_b) return;
+
+    // ---- P3 (single column group only): qf' = Wf_h h' from the rows this workgroup already holds
+    ggpm_lds_barrier();
+    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+        f32x4 acc[1][RT];
+        ggpm_zero_acc<1, RT>(acc);
+        const float* const tiles[1] = {Th};
+        const float* const wps[1] = {a.Wf};
+        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        const int c = 16 * tt + 4 * (lane >> 4);
+        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
     }
 }
 
@@ -196,6 +215,7 @@ struct LstmBwdArgs {
     float *carry_h, *carry_c;        // [E1,Hp] each, zeroed by the driver
     int final_pass;
     float *dHin, *dCin;
+    int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
 };
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
@@ -274,10 +294,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         }
     }
 
-    if (!a.first) __syncthreads();
+    if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dqf stash stores finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
     const int t_end = min(NT, (grp + 1) * a.tg);
+    float* Ta = lds + 3 * ROWS * LD;      // fused P3 only: complete di_pre / do_pre / du_pre rows
+    float* Tb = lds + 4 * ROWS * LD;
+    float* Tc = lds + 5 * ROWS * LD;
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
@@ -286,7 +309,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         if (!a.final_pass) {
             gi = ggpm_ld4(a.I + o); go = ggpm_ld4(a.O + o); gu = ggpm_ld4(a.U + o); cc = ggpm_ld4(a.Ccur + o);
             fco = ggpm_ld4(a.F + o);
-            oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o); oxf = ggpm_ld4(a.dXf + o);
+            if (!a.first) {        // depth D starts the dX sums
+                oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o);
+                oxf = ggpm_ld4(a.dXf + o);
+            }
         }
         const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
         const float4 dcd = (a.first && a.dCD) ? ggpm_ld4(a.dCD + o) : ggpm_zero4();
@@ -297,7 +323,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             const float* const wps[1] = {a.WfT};
             ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
-        if (row >= a.E1) continue;
+        if (row >= a.E1) {
+            if (a.fuse_b) {
+                ggpm_st4(Ta + lr * LD + c, ggpm_zero4());
+                ggpm_st4(Tb + lr * LD + c, ggpm_zero4());
+                ggpm_st4(Tc + lr * LD + c, ggpm_zero4());
+            }
+            continue;
+        }
         const bool frz = a.frozen && a.frozen[row];
         if (a.final_pass) {        // gradient of the incoming (h, c): frozen rows only
             float4 dh0 = ggpm_zero4(), dc0 = ggpm_zero4();
@@ -348,6 +381,27 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         ggpm_st4(a.dXo + o, oxo + dop);
         ggpm_st4(a.dXu + o, oxu + dup);
         ggpm_st4(a.dXf + o, oxf + dfc * fco);      // dXf_e += dFC_e * sum_p c_p f(1-f)
+        if (a.fuse_b) {
+            ggpm_st4(Ta + lr * LD + c, dip);
+            ggpm_st4(Tb + lr * LD + c, dop);
+            ggpm_st4(Tc + lr * LD + c, dup);
+        }
+    }
+    if (!a.fuse_b) return;
+
+    // ---- P3 (single column group only): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h from the rows held here
+    ggpm_lds_barrier();
+    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+        f32x4 acc[3][RT];
+        ggpm_zero_acc<3, RT>(acc);
+        {
+            const float* const tiles[3] = {Ta, Tb, Tc};
+            const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
+            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        }
+        const int c = 16 * tt + 4 * (lane >> 4);
+        if (row < a.E1)
+            ggpm_st4(a.dSout + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
     }
 }
 
@@ -402,11 +456,13 @@ inline int pick_tg(int E1, int NT) {
     return ggpm_tiles_per_group(E1, NT);
 }
 
-void launch_fwd(const LstmFwdArgs& a, bool stash, bool with_b, double flops1, hipStream_t s) {
+void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    const size_t la = lds_tiles(2, Hp), lb = lds_tiles(1, Hp);
-    ggpm_timing_begin(2, s, 3 * flops1);
+    a.fuse_b = (with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    if (a.fuse_b) with_b = false;
+    const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp), lb = lds_tiles(1, Hp);
+    ggpm_timing_begin(2, s, (a.fuse_b ? 4 : 3) * flops1);
     if (stash) {
         set_lds(lstm_fwd_a<true>, la);
         lstm_fwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
@@ -423,13 +479,17 @@ void launch_fwd(const LstmFwdArgs& a, bool stash, bool with_b, double flops1, hi
     }
 }
 
-void launch_bwd(const LstmBwdArgs& a, bool with_b, double flops1, hipStream_t s) {
+void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t l3 = lds_tiles(3, Hp);
-    set_lds(lstm_bwd_a, l3);
-    ggpm_timing_begin(3, s, 1 * flops1);
-    lstm_bwd_a<<<grid_a, GGPM_NWA * 64, l3, s>>>(a);
+    a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && lds_tiles(6, Hp) <= 160 * 1024 &&
+                !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    if (a.fuse_b) with_b = false;
+    const size_t la = a.fuse_b ? lds_tiles(6, Hp) : l3;
+    set_lds(lstm_bwd_a, la);
+    ggpm_timing_begin(3, s, (a.fuse_b ? 4 : 1) * flops1);
+    lstm_bwd_a<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
     ggpm_timing_end(3, s);
     if (with_b) {
         set_lds(lstm_bwd_b, l3);
@@ -609,10 +669,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWiT; pk.bias = nullptr; pk.bias_out = nullptr;
         ggpm_launch_pack(pk, 4, s);
     }
-    (void)hipMemsetAsync(dXi, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(dXo, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(dXu, 0, slot * sizeof(float), s);
-    (void)hipMemsetAsync(dXf, 0, slot * sizeof(float), s);
+    // dXi / dXo / dXu / dXf are started (not accumulated) by the first backward depth
     if (frozen) {
         (void)hipMemsetAsync(carry_h, 0, slot * sizeof(float), s);
         (void)hipMemsetAsync(carry_c, 0, slot * sizeof(float), s);
