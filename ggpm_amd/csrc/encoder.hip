@@ -38,7 +38,7 @@ struct Csr {
 };
 
 struct LevelSaved {
-    float *X, *Hs, *Qs, *St, *wpack, *nei;
+    float *X, *Hs, *Cs, *Qs, *St, *wpack, *nei;
 };
 
 struct Saved {          // layout of the `saved` arena (pointers are re-derived by replaying the same takes)
@@ -53,6 +53,7 @@ struct Dims {
     int H, Hp, He, Hep, depthT, depthG, atom, n_motif, n_attach;
     int N1g, E1g, Kga, Kgb, N1t, E1t, Kta, Ktb, Ktc, B;
     int ld_n, ld_m, ld_t, Ig, It;
+    int lstm, nX, lcount;          // cell type, hoisted-input slots per level (3 / 4), parameter slots per level (9 / 10)
 };
 
 Dims make_dims(const ggpm_enc_dims* d) {
@@ -64,6 +65,7 @@ Dims make_dims(const ggpm_enc_dims* d) {
     x.ld_n = ggpm_round_up(x.atom, 4);
     x.Ig = x.atom + 4 + 20; x.ld_m = ggpm_round_up(x.Ig, 4);
     x.It = x.H + 20; x.ld_t = ggpm_round_up(x.It, 4);
+    x.lstm = d->rnn_type == 1; x.nX = x.lstm ? 4 : 3; x.lcount = x.lstm ? 10 : 9;
     return x;
 }
 
@@ -76,13 +78,14 @@ void take_csr(Arena& A, Csr& c, int rows, int ncols, int cap) {
     c.cursor = A.take<int32_t>(ncols);
 }
 
-void take_level(Arena& A, LevelSaved& L, int E1, int N1, int Hp, int H, int depth) {
+void take_level(Arena& A, LevelSaved& L, int E1, int N1, int Hp, int H, int depth, bool lstm) {
     const size_t slot = (size_t)E1 * Hp;
-    L.X = A.take<float>(3 * slot);
+    L.X = A.take<float>((lstm ? 4 : 3) * slot);
     L.Hs = A.take<float>((size_t)(depth + 1) * slot);
+    L.Cs = lstm ? A.take<float>((size_t)(depth + 1) * slot) : nullptr;
     L.Qs = A.take<float>((size_t)depth * slot);
     L.St = A.take<float>((size_t)5 * depth * slot);
-    L.wpack = A.take<float>(ggpm_gru_pack_floats(H));
+    L.wpack = A.take<float>(lstm ? ggpm_lstm_pack_floats(H) : ggpm_gru_pack_floats(H));
     L.nei = A.take<float>((size_t)N1 * Hp);
 }
 
@@ -108,9 +111,9 @@ void layout_saved(Arena& A, const Dims& d, Saved& s) {
     take_index(s.attach, d.N1t, d.n_attach);
     s.hnode_a = A.take<float>((size_t)d.N1g * d.ld_n);
     s.hmess_a = A.take<float>((size_t)d.E1g * d.ld_m);
-    take_level(A, s.lv[0], d.E1t, d.N1t, d.Hp, d.H, d.depthT);
-    take_level(A, s.lv[1], d.E1t, d.N1t, d.Hp, d.H, d.depthT);
-    take_level(A, s.lv[2], d.E1g, d.N1g, d.Hp, d.H, d.depthG);
+    take_level(A, s.lv[0], d.E1t, d.N1t, d.Hp, d.H, d.depthT, d.lstm);
+    take_level(A, s.lv[1], d.E1t, d.N1t, d.Hp, d.H, d.depthT, d.lstm);
+    take_level(A, s.lv[2], d.E1g, d.N1g, d.Hp, d.H, d.depthG, d.lstm);
     s.finput_i = A.take<float>((size_t)d.N1t * d.Hep); s.pooled = A.take<float>((size_t)d.N1t * d.Hp);
     s.hnode_i = A.take<float>((size_t)d.N1t * d.Hp); s.hmess_i = A.take<float>((size_t)d.E1t * d.ld_t);
     s.finput_t = A.take<float>((size_t)d.N1t * d.Hep);
@@ -125,8 +128,12 @@ __global__ void iota_k(int32_t* out, int n) {
 
 // parameter slots
 enum { P_EC = 0, P_EI, P_WC, P_BC, P_WI, P_BI, P_WROOT, P_BROOT, P_LEVEL0 };
-enum { L_WO = 0, L_BO, L_WZ, L_BZ, L_WR, L_UR, L_BU, L_WH, L_BH, L_COUNT };
+enum { L_WO = 0, L_BO, L_WZ, L_BZ, L_WR, L_UR, L_BU, L_WH, L_BH, L_COUNT };               // GRU level
+enum { Q_WO = 0, Q_BO, Q_WI, Q_BI, Q_WOG, Q_BOG, Q_WU, Q_BU, Q_WF, Q_BF, Q_COUNT };      // LSTM level
 inline int lp(int level, int which) { return P_LEVEL0 + level * L_COUNT + which; }
+inline int lq(int level, int which) { return P_LEVEL0 + level * Q_COUNT + which; }
+inline int lwo(bool lstm, int level) { return lstm ? lq(level, Q_WO) : lp(level, L_WO); }
+inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level, L_BO); }
 
 #define CK(expr)                    \
     do {                            \
@@ -147,6 +154,18 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
                   const Csr& pred, const Csr& agr, LevelSaved& L, ggpm_stream_t s) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp;
+    if (d.lstm) {
+        const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
+        const float* b[4] = {P[lq(level, Q_BI)], P[lq(level, Q_BOG)], P[lq(level, Q_BU)], P[lq(level, Q_BF)]};
+        for (int k = 0; k < 4; ++k)
+            CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, W[k], I + H, L.X + k * slot, Hp, Hp, b[k], 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
+        const size_t dsl = (size_t)depth * slot;
+        CK(ggpm_lstm_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H,
+                             W[2] + I, I + H, W[3] + I, I + H, pred.rowptr, pred.col, L.Hs, L.Cs, L.Qs, L.St, L.St + dsl,
+                             L.St + 2 * dsl, L.St + 3 * dsl, L.St + 4 * dsl, L.wpack, 1, s));
+        CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
+        return GGPM_OK;
+    }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wz, I + H, L.X, Hp, Hp, P[lp(level, L_BZ)], 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
     CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wr, I, L.X + slot, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
@@ -231,7 +250,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     // ---- atom level (embed_graph, graph_encoder)
     CK(ggpm_embed_graph(gfnode, d.N1g, gfmess, d.E1g, d.atom, 4, 20, S.hnode_a, d.ld_n, S.hmess_a, d.ld_m, stream));
     CK(level_forward(d, d.E1g, d.N1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, 2, S.gpred, S.gagr, S.lv[2], stream));
-    CK(linear2(d.N1g, H, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, P[lp(2, L_WO)], P[lp(2, L_BO)], GGPM_ACT_RELU, 1,
+    CK(linear2(d.N1g, H, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, P[lwo(d.lstm, 2)], P[lbo(d.lstm, 2)], GGPM_ACT_RELU, 1,
                hatom, Hp, stream));
 
     // ---- attachment level (embed_inter, inter_encoder)
@@ -242,7 +261,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     CK(ggpm_gather_rows(S.hnode_i, Hp, S.src, d.E1t, H, S.hmess_i, d.ld_t, 0, 0, stream));
     CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, 1, S.tpred, S.tagr, S.lv[1], stream));
-    CK(linear2(d.N1t, H, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, P[lp(1, L_WO)], P[lp(1, L_BO)], GGPM_ACT_RELU, 1, hinter, Hp,
+    CK(linear2(d.N1t, H, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, P[lwo(d.lstm, 1)], P[lbo(d.lstm, 1)], GGPM_ACT_RELU, 1, hinter, Hp,
                stream));
 
     // ---- motif level (embed_tree, tree_encoder)
@@ -251,7 +270,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     CK(ggpm_gather_rows(S.hnode_t, Hp, S.src, d.E1t, H, S.hmess_t, d.ld_t, 0, 0, stream));
     CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, 0, S.tpred, S.tagr, S.lv[0], stream));
-    CK(linear2(d.N1t, H, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, P[lp(0, L_WO)], P[lp(0, L_BO)], GGPM_ACT_RELU, 1, hnode, Hp,
+    CK(linear2(d.N1t, H, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, P[lwo(d.lstm, 0)], P[lbo(d.lstm, 0)], GGPM_ACT_RELU, 1, hnode, Hp,
                stream));
 
     // ---- root readout (embed_root)
@@ -280,15 +299,17 @@ void layout_work(Arena& A, const Dims& d, BwdWork& w) {
     // next, so each gets its own buffer
     w.dpre = A.take<float>((size_t)5 * Nmax * Hp);
     w.d_h = A.take<float>((size_t)Emax * Hp);
-    w.dX = A.take<float>((size_t)3 * 3 * Emax * Hp);          // per level (read by the second stream afterwards)
+    w.dX = A.take<float>((size_t)3 * 4 * Emax * Hp);          // per level (read by the second stream afterwards)
     w.dx_mess = A.take<float>((size_t)d.E1t * d.ld_t);
     w.d_finput = A.take<float>((size_t)2 * d.N1t * d.Hep);
     w.d_hinter = A.take<float>((size_t)d.N1t * Hp);
     w.d_hnode_i = A.take<float>((size_t)d.N1t * Hp); w.d_nei_i = A.take<float>((size_t)d.N1t * Hp);
     w.d_pooled = A.take<float>((size_t)d.N1t * Hp);
     w.d_hatom = A.take<float>((size_t)d.N1g * Hp); w.d_nei_g = A.take<float>((size_t)d.N1g * Hp);
-    size_t lw = ggpm_gru_backward_workspace_bytes(d.E1g, d.H, d.depthG);
-    const size_t lwt = ggpm_gru_backward_workspace_bytes(d.E1t, d.H, d.depthT);
+    size_t lw = d.lstm ? ggpm_lstm_backward_workspace_bytes(d.E1g, d.H, d.depthG)
+                       : ggpm_gru_backward_workspace_bytes(d.E1g, d.H, d.depthG);
+    const size_t lwt = d.lstm ? ggpm_lstm_backward_workspace_bytes(d.E1t, d.H, d.depthT)
+                              : ggpm_gru_backward_workspace_bytes(d.E1t, d.H, d.depthT);
     w.level_work_bytes = lw > lwt ? lw : lwt;
     w.level_work = A.take<float>(3 * (w.level_work_bytes / 4 + 64));      // one per level (stashes read by stream 2)
     size_t sk = 0;
@@ -334,6 +355,29 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                    float* dx, int lddx, BwdWork& w, Streams& st, int overlap_wgrads = 0) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
+    if (d.lstm) {
+        const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
+        float* dW[4] = {G[lq(level, Q_WI)], G[lq(level, Q_WOG)], G[lq(level, Q_WU)], G[lq(level, Q_WF)]};
+        float* db[4] = {G[lq(level, Q_BI)], G[lq(level, Q_BOG)], G[lq(level, Q_BU)], G[lq(level, Q_BF)]};
+        CK(ggpm_lstm_backward(E1, H, depth, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H, W[2] + I, I + H, W[3] + I, I + H,
+                              pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Cs, L.Qs, L.St, L.St + ds,
+                              L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dX + 3 * slot,
+                              dW[0] + I, I + H, dW[1] + I, I + H, dW[2] + I, I + H, dW[3] + I, I + H, level_work,
+                              w.level_work_bytes, 0, st.main));
+        if (dx)
+            for (int k = 0; k < 4; ++k)
+                CK(ggpm_gemm(0, 0, E1, I, H, dX + k * slot, Hp, W[k], I + H, dx, lddx, k == 0 ? lddx : I, nullptr, k > 0,
+                             GGPM_ACT_NONE, 0, nullptr, 0, st.main));
+        CK(st.side_after_main());
+        CK(ggpm_lstm_weight_grads(E1, H, depth, L.Hs, L.St, level_work, w.level_work_bytes, dW[0] + I, I + H, dW[1] + I,
+                                  I + H, dW[2] + I, I + H, dW[3] + I, I + H, st.w()));
+        for (int k = 0; k < 4; ++k) {
+            CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
+                         w.skws_bytes, st.w()));
+            CK(ggpm_colsum(dX + k * slot, Hp, E1, H, db[k], w.csws, st.w()));
+        }
+        return GGPM_OK;
+    }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
     // The last level of the backward (the atom level) has nothing behind it to hide its weight-gradient contractions:
@@ -430,7 +474,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     float* dpre[5];
     for (int i = 0; i < 5; ++i) dpre[i] = w.dpre + (size_t)i * Nmax * Hp;
     float* dXl[3];
-    for (int i = 0; i < 3; ++i) dXl[i] = w.dX + (size_t)i * 3 * Emax * Hp;
+    for (int i = 0; i < 3; ++i) dXl[i] = w.dX + (size_t)i * 4 * Emax * Hp;
     float* lwork[3];
     for (int i = 0; i < 3; ++i) lwork[i] = w.level_work + (size_t)i * (w.level_work_bytes / 4 + 64);
     const size_t nt = (size_t)d.N1t * Hp * sizeof(float), ng = (size_t)d.N1g * Hp * sizeof(float);
@@ -462,14 +506,14 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     // ---- motif level: W_o, message function, W_c / E_c
     if (d_hnode) {
         CK(ggpm_act_backward(d_hnode, hnode, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[0], stream));
-        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lp(0, L_WO)], 2 * H, w.d_hnode_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE, 0,
+        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)], 2 * H, w.d_hnode_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE, 0,
                      nullptr, 0, stream));
-        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lp(0, L_WO)] + H, 2 * H, w.d_nei_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE,
+        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)] + H, 2 * H, w.d_nei_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE,
                      0, nullptr, 0, stream));
-        CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lp(0, L_WO)], G[lp(0, L_BO)], w, st));
+        CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lwo(d.lstm, 0)], G[lbo(d.lstm, 0)], w, st));
     } else {
-        (void)hipMemsetAsync(G[lp(0, L_WO)], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
-        (void)hipMemsetAsync(G[lp(0, L_BO)], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
+        (void)hipMemsetAsync(G[lwo(d.lstm, 0)], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
+        (void)hipMemsetAsync(G[lbo(d.lstm, 0)], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
     }
     CK(ggpm_segment_sum(w.d_nei_t, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, G, 0, S.tpred, S.lv[0], w.d_h, dXl[0], lwork[0],
@@ -486,11 +530,11 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
 
     // ---- attachment level: W_o, message function, W_i / E_i, pooling over atoms
     CK(ggpm_act_backward(w.d_hinter, hinter, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[2], stream));
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lp(1, L_WO)], 2 * H, w.d_hnode_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)], 2 * H, w.d_hnode_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
                  nullptr, 0, stream));
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lp(1, L_WO)] + H, 2 * H, w.d_nei_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
+    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)] + H, 2 * H, w.d_nei_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
                  nullptr, 0, stream));
-    CK(linear2_wgrad(d.N1t, H, dpre[2], Hp, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, G[lp(1, L_WO)], G[lp(1, L_BO)], w, st));
+    CK(linear2_wgrad(d.N1t, H, dpre[2], Hp, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, G[lwo(d.lstm, 1)], G[lbo(d.lstm, 1)], w, st));
     CK(ggpm_segment_sum(w.d_nei_i, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, G, 1, S.tpred, S.lv[1], w.d_h, dXl[1], lwork[1],
                       w.dx_mess, d.ld_t, w, st));
@@ -509,9 +553,9 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
 
     // ---- atom level: W_o, message function (its inputs are constants)
     CK(ggpm_act_backward(w.d_hatom, hatom, d.N1g, H, Hp, GGPM_ACT_RELU, 1, dpre[4], stream));
-    CK(ggpm_gemm(0, 0, d.N1g, H, H, dpre[4], Hp, P[lp(2, L_WO)] + d.atom, d.atom + H, w.d_nei_g, Hp, Hp, nullptr, 0,
+    CK(ggpm_gemm(0, 0, d.N1g, H, H, dpre[4], Hp, P[lwo(d.lstm, 2)] + d.atom, d.atom + H, w.d_nei_g, Hp, Hp, nullptr, 0,
                  GGPM_ACT_NONE, 0, nullptr, 0, stream));
-    CK(linear2_wgrad(d.N1g, H, dpre[4], Hp, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, G[lp(2, L_WO)], G[lp(2, L_BO)], w,
+    CK(linear2_wgrad(d.N1g, H, dpre[4], Hp, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, G[lwo(d.lstm, 2)], G[lbo(d.lstm, 2)], w,
                      st));
     CK(ggpm_segment_sum(w.d_nei_g, Hp, S.gagr.rowptrT, S.gagr.colT, d.E1g, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],

@@ -16,16 +16,26 @@ import torch
 from . import _lib
 from . import functional as F_
 
-PARAM_ORDER = (["E_c.0.weight", "E_i.0.weight", "W_c.0.weight", "W_c.0.bias", "W_i.0.weight", "W_i.0.bias",
-                "W_root.0.weight", "W_root.0.bias"] +
-               [lvl + "." + k for lvl in ("tree_encoder", "inter_encoder", "graph_encoder")
-                for k in ("W_o.0.weight", "W_o.0.bias", "rnn.W_z.weight", "rnn.W_z.bias", "rnn.W_r.weight",
-                          "rnn.U_r.weight", "rnn.U_r.bias", "rnn.W_h.weight", "rnn.W_h.bias")])
+_HEAD = ["E_c.0.weight", "E_i.0.weight", "W_c.0.weight", "W_c.0.bias", "W_i.0.weight", "W_i.0.bias", "W_root.0.weight",
+         "W_root.0.bias"]
+_CELL = {"GRU": ("rnn.W_z.weight", "rnn.W_z.bias", "rnn.W_r.weight", "rnn.U_r.weight", "rnn.U_r.bias", "rnn.W_h.weight",
+                 "rnn.W_h.bias"),
+         "LSTM": ("rnn.W_i.0.weight", "rnn.W_i.0.bias", "rnn.W_o.0.weight", "rnn.W_o.0.bias", "rnn.W.0.weight",
+                  "rnn.W.0.bias", "rnn.W_f.0.weight", "rnn.W_f.0.bias")}
+
+
+def param_order(cell: str):
+    """Parameter names in the slot order of include/ggpm_hip.h (ggpm_encoder_forward)."""
+    return _HEAD + [lvl + "." + k for lvl in ("tree_encoder", "inter_encoder", "graph_encoder")
+                    for k in ("W_o.0.weight", "W_o.0.bias") + _CELL[cell]]
+
+
+PARAM_ORDER = param_order("GRU")
 
 
 class EncDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("H", "He", "depthT", "depthG", "atom_size", "n_motif", "n_attach", "N1g",
-                                            "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B")]
+                                            "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B", "rnn_type")]
 
 
 def enabled() -> bool:
@@ -106,14 +116,16 @@ class _HierEncoder(torch.autograd.Function):
 
 def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
     """-> (hroot, hnode, hinter, hatom) as [rows, Hp] tensors; ``encoder`` is a HierMPNEncoder with GRU levels."""
+    from .rnn import LSTM
+    lstm = isinstance(encoder.graph_encoder.rnn, LSTM)
     params = getattr(encoder, "_fused_params", None)
     if params is None or any(p is not q for p, q in zip(params, encoder._fused_check())):
         sd = dict(encoder.named_parameters())
-        params = [sd[k] for k in PARAM_ORDER]
+        params = [sd[k] for k in param_order("LSTM" if lstm else "GRU")]
         encoder._fused_params = params
     tf, gf = tree_tensors, graph_tensors
     dims = EncDims(encoder.hidden_size, encoder.embed_size, encoder.tree_encoder.depth, encoder.graph_encoder.depth,
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
-                   tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel())
+                   tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm))
     return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, *params)

@@ -221,21 +221,25 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
 
 /* ------------------------------------------------------------------ whole-encoder drivers
  * HierMPNEncoder.forward (ggpm/encoder.py:140-157, with embed_graph/inter/tree/root :96-138) and its backward as ONE
- * call each: the same kernels the op-by-op host path issues, sequenced from C++ (GRU message function, dropout 0).
+ * call each: the same kernels the op-by-op host path issues, sequenced from C++ (GRU or LSTM message function).
  * Inputs are the A0 tensors of MolGraph.tensorize() after make_cuda (int64, row-major) plus the molecules' root node
  * ids; outputs are [rows, Hp] with zero pad columns (Hp = ggpm_padded_hidden(H)).
- * params / grads: 35 device pointers, contiguous fp32, in this order (shapes as in the reference state_dict):
- *   E_c.0.weight, E_i.0.weight, W_c.0.weight, W_c.0.bias, W_i.0.weight, W_i.0.bias, W_root.0.weight, W_root.0.bias,
- *   then for tree_encoder, inter_encoder, graph_encoder: W_o.0.weight, W_o.0.bias, rnn.W_z.weight, rnn.W_z.bias,
- *   rnn.W_r.weight, rnn.U_r.weight, rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias.
+ * params / grads: 35 (GRU) or 38 (LSTM) device pointers, contiguous fp32, in this order (shapes as in the reference
+ * state_dict): E_c.0.weight, E_i.0.weight, W_c.0.weight, W_c.0.bias, W_i.0.weight, W_i.0.bias, W_root.0.weight,
+ *   W_root.0.bias, then for tree_encoder, inter_encoder, graph_encoder: W_o.0.weight, W_o.0.bias and the cell's
+ *   GRU:  rnn.W_z.weight, rnn.W_z.bias, rnn.W_r.weight, rnn.U_r.weight, rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias
+ *   LSTM: rnn.W_i.0.weight, rnn.W_i.0.bias, rnn.W_o.0.weight, rnn.W_o.0.bias, rnn.W.0.weight, rnn.W.0.bias,
+ *         rnn.W_f.0.weight, rnn.W_f.0.bias.
  * saved: ggpm_encoder_saved_bytes() bytes written by the forward and read by the backward; work: backward scratch of
  * ggpm_encoder_work_bytes().  side_stream (may be 0): transposed CSRs and all weight-gradient contractions run there,
- * event-ordered against `stream`; on return from the backward `stream` is ordered behind it.  d_* may be null. */
+ * event-ordered against `stream`; on return from the backward `stream` is ordered behind it.  d_* may be null.
+ * Dropout 0 only (the host keeps the op-by-op path otherwise). */
 typedef struct ggpm_enc_dims {
     int H, He, depthT, depthG, atom_size, n_motif, n_attach;
     int N1g, E1g, Kg_a, Kg_b;            /* atom graph: nodes+1, messages+1, agraph / bgraph widths */
     int N1t, E1t, Kt_a, Kt_b, Kt_c;      /* motif tree: nodes+1, messages+1, agraph / bgraph / cgraph widths */
     int B;                               /* molecules */
+    int rnn_type;                        /* 0 GRU, 1 LSTM */
 } ggpm_enc_dims;
 size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims);
 size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims);
