@@ -56,7 +56,7 @@ SIGNATURES = {
     "ggpm_encoder_saved_bytes": (c_size_t, [P]),
     "ggpm_encoder_work_bytes": (c_size_t, [P]),
     "ggpm_encoder_forward": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
-    "ggpm_encoder_backward": (I, [P, P, P, P, P, c_size_t, P, P, P, P, P, P, P, P, P, c_size_t, P, P]),
+    "ggpm_encoder_backward": (I, [P, P, P, P, P, c_size_t, P, P, P, P, P, P, P, P, P, c_size_t, I, P, P]),
     "ggpm_build_clusters": (I, [P, P, I, I, P, P, P]),
     "ggpm_gru_persistent_supported": (I, [I]),
     "ggpm_gru_persistent_ncg": (I, [I]),

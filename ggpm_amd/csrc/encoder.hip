@@ -449,13 +449,17 @@ extern "C" size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims) {
 
 // grads: one buffer per parameter slot (same shapes as the parameters, every element written).  d_* may be null
 // (no gradient arrives for that output).  On return the main stream is ordered behind the second stream.
+// phase 0: the whole backward.  phase 1: everything except the atom level (whose parameters come last in the slot
+// order), phase 2: the atom level + the final join -- the caller may start reducing the gradients of slots
+// [0, first graph_encoder slot) across ranks on the second stream between the two calls.
 extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* params, float* const* grads,
                                      const int32_t* roots, void* saved, size_t saved_bytes, const float* hroot,
                                      const float* hnode, const float* hinter, const float* hatom, const float* d_hroot,
                                      const float* d_hnode, const float* d_hinter, const float* d_hatom, void* work,
-                                     size_t work_bytes, ggpm_stream_t stream, ggpm_stream_t side_stream) {
+                                     size_t work_bytes, int phase, ggpm_stream_t stream, ggpm_stream_t side_stream) {
     GGPM_CLEAR_STALE_ERROR();
-    if (!dims || !params || !grads || !roots || !saved || !work || !hroot || !hnode || !hinter || !hatom)
+    if (!dims || !params || !grads || !roots || !saved || !work || !hroot || !hnode || !hinter || !hatom || phase < 0 ||
+        phase > 2)
         return GGPM_ERR_ARG;
     const Dims d = make_dims(dims);
     Arena A = {reinterpret_cast<char*>(saved), 0, false, saved_bytes};
@@ -479,13 +483,13 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     for (int i = 0; i < 3; ++i) lwork[i] = w.level_work + (size_t)i * (w.level_work_bytes / 4 + 64);
     const size_t nt = (size_t)d.N1t * Hp * sizeof(float), ng = (size_t)d.N1g * Hp * sizeof(float);
 
-    if (side_stream) {      // the transposed CSRs were built on the second stream during the forward
+    if (side_stream && phase != 2) {      // the transposed CSRs were built on the second stream during the forward
         hipEvent_t ev = ggpm_wgrad_event(61);
         if (!ev) return GGPM_ERR_LAUNCH;
         (void)hipEventRecord(ev, (hipStream_t)side_stream);
         (void)hipStreamWaitEvent(s, ev, 0);
     }
-
+    if (phase != 2) {
     // ---- root readout
     if (d_hroot) {
         CK(ggpm_act_backward(d_hroot, hroot, d.B, H, Hp, GGPM_ACT_TANH, 0, w.dpre_root, stream));
@@ -550,6 +554,12 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     if (d_hatom) (void)hipMemcpyAsync(w.d_hatom, d_hatom, ng, hipMemcpyDeviceToDevice, s);
     CK(ggpm_segment_sum(w.d_pooled, Hp, S.tcgr.rowptrT, S.tcgr.colT, d.N1g, H, w.d_hatom, Hp, d_hatom ? 1 : 0,
                         d_hatom ? 0 : Hp, stream));
+
+    }   // phase != 2
+    if (phase == 1) {      // everything but the atom level's parameter gradients is issued (second stream: in flight)
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
 
     // ---- atom level: W_o, message function (its inputs are constants)
     CK(ggpm_act_backward(w.d_hatom, hatom, d.N1g, H, Hp, GGPM_ACT_RELU, 1, dpre[4], stream));

@@ -58,7 +58,7 @@ def _side_ptr(device):
 
 class _HierEncoder(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dims: EncDims, tree_tensors, graph_tensors, roots, *params):
+    def forward(ctx, dims: EncDims, tree_tensors, graph_tensors, roots, grad_sink, *params):
         lib = _lib.load()
         dev = params[0].device
         tfnode, tfmess, tagraph, tbgraph, tcgraph = [t.contiguous() for t in tree_tensors[:5]]
@@ -83,6 +83,7 @@ class _HierEncoder(torch.autograd.Function):
                                             F_._stream(), side_p), "encoder_forward")
         if any(ctx.needs_input_grad):
             ctx.dims, ctx.saved_arena, ctx.roots, ctx.params = dims, saved, roots, params
+            ctx.grad_sink = grad_sink
             ctx.outs = (hroot, hnode, hinter, hatom)
         return hroot, hnode, hinter, hatom
 
@@ -92,12 +93,18 @@ class _HierEncoder(torch.autograd.Function):
         dims, saved, roots, params = ctx.dims, ctx.saved_arena, ctx.roots, ctx.params
         hroot, hnode, hinter, hatom = ctx.outs
         dev = saved.device
-        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
-        grads: List[torch.Tensor] = []
-        off = 0
-        for p in params:
-            grads.append(flat[off:off + p.numel()].view(p.shape))
-            off += p.numel()
+        sink = ctx.grad_sink() if ctx.grad_sink is not None else None
+        if sink is not None and not sink.accepts(params):
+            sink = None
+        if sink is not None:            # data parallel: write straight into the flat all-reduce buffer (no pack copy)
+            flat, grads = sink.flat, sink.encoder_views
+        else:
+            flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            grads: List[torch.Tensor] = []
+            off = 0
+            for p in params:
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
         work_bytes = int(lib.ggpm_encoder_work_bytes(ctypes.byref(dims)))
         work = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
         side, side_p = _side_ptr(dev)
@@ -106,12 +113,31 @@ class _HierEncoder(torch.autograd.Function):
                 t.record_stream(side)
         douts = [None if g is None else g.contiguous() for g in (d_hroot, d_hnode, d_hinter, d_hatom)]
         P = F_._p
-        _lib.check(lib.ggpm_encoder_backward(ctypes.byref(dims), _ptr_array(params), _ptr_array(grads), P(roots), P(saved),
-                                             saved.numel(), P(hroot), P(hnode), P(hinter), P(hatom), P(douts[0]),
-                                             P(douts[1]), P(douts[2]), P(douts[3]), P(work), work_bytes, F_._stream(),
-                                             side_p), "encoder_backward")
+        parr, garr = _ptr_array(params), _ptr_array(grads)
+
+        def run(phase):
+            _lib.check(lib.ggpm_encoder_backward(ctypes.byref(dims), parr, garr, P(roots), P(saved), saved.numel(),
+                                                 P(hroot), P(hnode), P(hinter), P(hatom), P(douts[0]), P(douts[1]),
+                                                 P(douts[2]), P(douts[3]), P(work), work_bytes, phase, F_._stream(),
+                                                 side_p), "encoder_backward")
+
+        if sink is not None and side is not None and sink.wants_early_bucket():
+            run(1)                      # everything but the atom level; its gradients complete on the second stream
+            with torch.cuda.stream(side):
+                sink.reduce_early_bucket()          # all-reduce them while the atom level's depth loop runs
+            run(2)
+        else:
+            run(0)
         ctx.saved_arena = ctx.outs = None
-        return (None, None, None, None, *grads)
+        if sink is not None:
+            # hand the gradients over in place: returning the buffer's own views would make autograd clone each one
+            for p, v in zip(params, grads):
+                if p.grad is None:
+                    p.grad = v
+                elif p.grad.data_ptr() != v.data_ptr():
+                    p.grad.add_(v)
+            return (None,) * (5 + len(params))
+        return (None, None, None, None, None, *grads)
 
 
 def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
@@ -128,4 +154,4 @@ def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
                    tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm))
-    return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, *params)
+    return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, getattr(encoder, "_grad_sink", None), *params)

@@ -30,14 +30,39 @@ class FlatGradSync:
     instead of launching one accumulate kernel per parameter; ``all_reduce()`` packs them into the flat buffer
     with one multi-tensor copy, issues ONE collective and re-points every ``p.grad`` at its slice of the
     reduced buffer (no unpack copy).  With a single rank nothing is packed at all.
+
+    With ``encoder=`` (a HierMPNEncoder on the whole-encoder C++ drivers) the encoder's parameters come first in
+    the flat buffer, in the drivers' slot order, and the backward writes its gradients straight into the buffer (no
+    pack copy).  With GGPM_BUCKETED_ALLREDUCE=1 the slice in front of the atom level's parameters (the last slots,
+    whose backward is the last and longest part) is additionally all-reduced on the second stream WHILE that part
+    still runs.  Off by default: on one rank (RCCL, forced) every collective costs ~0.45 ms of fixed overhead, so two
+    collectives were slower than one (6.38 vs 5.98 ms/step) and the multi-GPU balance could not be measured here.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, encoder=None):
+        import os
+        import weakref
         seen, uniq = set(), []
         for p in params:                         # tied embeddings appear once
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 uniq.append(p)
+        self.encoder_params, self.early_numel = [], 0
+        self.bucketed = os.environ.get("GGPM_BUCKETED_ALLREDUCE", "0") != "0"
+        if encoder is not None and os.environ.get("GGPM_GRAD_SINK", "1") != "0":
+            from . import fused
+            from .rnn import LSTM
+            named = dict(encoder.named_parameters())
+            order = fused.param_order("LSTM" if isinstance(encoder.graph_encoder.rnn, LSTM) else "GRU")
+            enc = [named[k] for k in order if k in named]
+            ids = set(id(p) for p in uniq)
+            if len(enc) == len(order) and all(id(p) in ids for p in enc) and len(set(id(p) for p in enc)) == len(enc):
+                enc_ids = set(id(p) for p in enc)
+                uniq = enc + [p for p in uniq if id(p) not in enc_ids]
+                self.encoder_params = enc
+                first_graph = next(i for i, k in enumerate(order) if k.startswith("graph_encoder."))
+                self.early_numel = sum(p.numel() for p in enc[:first_graph])
+                encoder._grad_sink = weakref.ref(self)
         self.params = uniq
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -47,12 +72,35 @@ class FlatGradSync:
             n = p.numel()
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
+        self.encoder_views = self.views[:len(self.encoder_params)]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # rehearsal switch: run the pack + collective even with one rank (exercises the RCCL path on a 1-GPU box)
-        import os
         self.force = dist.is_initialized() and os.environ.get("GGPM_FORCE_ALLREDUCE") == "1"
+        self._early_work = None
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"             # RCCL averages in the collective; gloo sums, then one division
 
+    # ------------------------------------------------------------------ interface used by fused._HierEncoder.backward
+    def active(self) -> bool:
+        return self.world_size > 1 or self.force
+
+    def accepts(self, params) -> bool:
+        return (self.active() and len(params) == len(self.encoder_params)
+                and all(p is q for p, q in zip(params, self.encoder_params)))
+
+    def wants_early_bucket(self) -> bool:
+        return self.bucketed and self.early_numel > 0
+
+    def _reduce(self, t: torch.Tensor, async_op: bool):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+
+    def reduce_early_bucket(self) -> None:
+        """Called on the second stream between the two phases of the encoder backward."""
+        self._early_work = self._reduce(self.flat[:self.early_numel], async_op=True)
+
+    # ------------------------------------------------------------------ step interface
     def zero_grad(self) -> None:
         for p in self.params:
             p.grad = None
@@ -61,9 +109,9 @@ class FlatGradSync:
         """Kept for API compatibility: gradients are (re)pointed at the flat buffer by all_reduce()."""
         return None
 
-    def pack(self) -> None:
+    def pack(self, start: int = 0) -> None:
         grads, views = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[start:], self.views[start:]):
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
@@ -76,19 +124,35 @@ class FlatGradSync:
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks then divide by world size (mean of per-rank batch-mean losses)."""
-        if self.world_size == 1 and not self.force:
+        if not self.active():
             return None
-        self.pack()
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        early, self._early_work = self._early_work, None
+        if early is not None:
+            # the encoder backward wrote its gradients into the flat buffer and the front slice is already being
+            # reduced: pack what autograd produced for the remaining parameters, reduce the tail, join
+            self.pack(start=len(self.encoder_params))
+            tail = self.flat[self.early_numel:]
+            self._reduce(tail, async_op=False)
+            early.wait()
+            if not self._avg:
+                self.flat.div_(self.world_size)
+            return None
+        in_place = len(self.encoder_params) > 0 and all(
+            p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+            for p, v in zip(self.encoder_params, self.encoder_views))
+        self.pack(start=len(self.encoder_params) if in_place else 0)
+        work = self._reduce(self.flat, async_op=async_op)
         if async_op:
             return work
-        self.flat.div_(self.world_size)
+        if not self._avg:
+            self.flat.div_(self.world_size)
         return None
 
     def finish(self, work) -> None:
         if work is not None:
             work.wait()
-            self.flat.div_(self.world_size)
+            if not self._avg:
+                self.flat.div_(self.world_size)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None) -> None:

@@ -233,6 +233,8 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
  * saved: ggpm_encoder_saved_bytes() bytes written by the forward and read by the backward; work: backward scratch of
  * ggpm_encoder_work_bytes().  side_stream (may be 0): transposed CSRs and all weight-gradient contractions run there,
  * event-ordered against `stream`; on return from the backward `stream` is ordered behind it.  d_* may be null.
+ * phase: 0 = whole backward; 1 = all but the atom level, 2 = atom level + final join (same arguments, same work
+ * arena): between the two a data-parallel caller starts all-reducing the gradients of every slot before graph_encoder.
  * Dropout 0 only (the host keeps the op-by-op path otherwise). */
 typedef struct ggpm_enc_dims {
     int H, He, depthT, depthG, atom_size, n_motif, n_attach;
@@ -251,7 +253,7 @@ int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* params, const 
 int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* params, float* const* grads, const int32_t* roots,
                           void* saved, size_t saved_bytes, const float* hroot, const float* hnode, const float* hinter,
                           const float* hatom, const float* d_hroot, const float* d_hnode, const float* d_hinter,
-                          const float* d_hatom, void* work, size_t work_bytes, ggpm_stream_t stream,
+                          const float* d_hatom, void* work, size_t work_bytes, int phase, ggpm_stream_t stream,
                           ggpm_stream_t side_stream);
 
 /* ------------------------------------------------------------------ persistent depth loop (molecule clusters)
