@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--pool", type=int, default=16, help="distinct pre-tensorized batches per rank (cycled)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="diagnostic: every step takes its batch from HOST memory through ggpm_amd.dataloader."
+                         "DevicePrefetcher (pinned staging + async copy); the PCIe-inclusive rate, never `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -213,8 +216,14 @@ def main():
     sync = FlatGradSync(model.parameters(), encoder=model.encoder)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 
+    host_iter = None
+    if a.host_input:
+        import itertools
+        from ggpm_amd.dataloader import DevicePrefetcher
+        host_iter = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, depth=2))
+
     def step(i):
-        tree, graph = dev_batches[i % len(dev_batches)]
+        tree, graph = next(host_iter) if host_iter is not None else dev_batches[i % len(dev_batches)]
         sync.zero_grad()
         hroot, hnode, hinter, hatom = model.encoder.forward_padded(tree, graph)
         _, kl = rsample(hroot, model.R_mean, model.R_var, perturb=False)
@@ -258,7 +267,8 @@ def main():
         "metric": "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32) -- HierMPNEncoder fwd+bwd target row",
         "value": round(mols / elapsed, 2), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (host-resident batches, PCIe-inclusive diagnostic)" if a.host_input else ""),
         "config": {"workload": "BASELINE configs[1]: synthetic random-motif graphs, %.1f atoms/molecule, motif vocab "
                                "%d/%d, hidden=%d depth=%d batch=%d per GPU, %s cell; step = zero_grad + encoder "
                                "fwd + KL + bwd%s + Adam" % (atoms / a.batch, n_motif, n_attach, H, a.depth, a.batch,

@@ -4,7 +4,7 @@ Host side: Python mirror of the reference's classes (rnn.GRU/LSTM, encoder.MPNEn
 device side: hand-written HIP kernels behind the C ABI in include/ggpm_hip.h (ggpm_amd/libggpm_hip.so).
 """
 __all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "IncMPNEncoder", "IncHierMPNEncoder",
-           "IncEncoder", "HierEncoderVAE", "rsample", "make_cuda"]
+           "IncEncoder", "HierEncoderVAE", "rsample", "make_cuda", "DevicePrefetcher"]
 
 
 def __getattr__(name):
@@ -21,6 +21,9 @@ def __getattr__(name):
     if name in ("HierEncoderVAE", "rsample"):
         from . import property_vae
         return getattr(property_vae, name)
+    if name == "DevicePrefetcher":
+        from .dataloader import DevicePrefetcher
+        return DevicePrefetcher
     if name == "make_cuda":
         from .nnutils import make_cuda
         return make_cuda

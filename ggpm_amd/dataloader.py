@@ -1,0 +1,125 @@
+"""Host -> device input path.
+
+The reference moves every batch to the device tensor by tensor, through Python lists
+(``make_tensor``: ``ndarray -> .tolist() -> torch.tensor -> .cuda()``, ggpm/nnutils.py:201-214; nine tensors per
+batch, each its own pageable copy).  ``DevicePrefetcher`` packs the nine A0 index arrays of a batch into ONE pinned
+int64 staging buffer, uploads it with ONE asynchronous copy on its own stream while the previous step still computes,
+and hands out int64 device views in the exact ``make_cuda`` layout (``[fnode, fmess, agraph, bgraph, cgraph, scope]``,
+``[fnode, fmess, agraph, bgraph, scope]``).  The consumer's stream is ordered behind the copy by an event; the staging
+buffers rotate, and a buffer is only rewritten after the copy that read it has completed.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def _as_int64(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+def batch_layout(tensors):
+    """(tree_tensors, graph_tensors) -> (the 9 index arrays, [(offset, shape)], total int64 elements)."""
+    tree, graph = tensors
+    arrays = [x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+              for x in list(tree[:5]) + list(graph[:4])]
+    layout, off = [], 0
+    for a in arrays:
+        layout.append((off, tuple(a.shape)))
+        off += (a.size + 1) // 2 * 2            # keep every array 16-byte aligned
+    return arrays, layout, off
+
+
+def pack_into(dst: np.ndarray, arrays, layout) -> None:
+    """Write the arrays (any integer dtype) into the flat int64 destination; plain single-threaded numpy copies --
+    a torch CPU copy_ of this size fans out over every visible core and gets the process throttled on a CPU quota."""
+    for a, (o, _) in zip(arrays, layout):
+        dst[o:o + a.size] = a.reshape(-1)
+
+
+def pack_batch(tensors) -> Tuple[np.ndarray, List[Tuple[int, Tuple[int, ...]]], list, list]:
+    """(tree_tensors, graph_tensors) -> (flat int64 array, [(offset, shape)] for the 9 arrays, tree scope, graph scope)."""
+    arrays, layout, total = batch_layout(tensors)
+    flat = np.zeros(total, dtype=np.int64)
+    pack_into(flat, arrays, layout)
+    return flat, layout, tensors[0][-1], tensors[1][-1]
+
+
+def unpack_views(flat: torch.Tensor, layout, tree_scope, graph_scope):
+    views = []
+    for off, shape in layout:
+        n = int(np.prod(shape)) if len(shape) else 1
+        views.append(flat[off:off + n].view(shape))
+    return views[:5] + [tree_scope], views[5:] + [graph_scope]
+
+
+class DevicePrefetcher:
+    """Iterate over host batches, yielding device-resident ``(tree_tensors, graph_tensors)`` one batch ahead."""
+
+    def __init__(self, batches: Iterable, device=None, depth: int = 2):
+        self.batches = batches
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self.depth = max(1, depth)
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._staging: List[torch.Tensor] = []          # pinned ring
+        self._staging_events: List = []
+
+    def _stage(self, slot: int, total: int) -> torch.Tensor:
+        while len(self._staging) <= slot:
+            self._staging.append(torch.empty(0, dtype=torch.int64))
+            self._staging_events.append(None)
+        ev = self._staging_events[slot]
+        if ev is not None:
+            ev.synchronize()                             # the copy that read this buffer has finished
+        buf = self._staging[slot]
+        if buf.numel() < total:
+            buf = torch.empty(int(total * 1.25) + 64, dtype=torch.int64)
+            if self.cuda:
+                buf = buf.pin_memory()
+            self._staging[slot] = buf
+        return buf[:total]
+
+    def _upload(self, slot: int, tensors):
+        arrays, layout, total = batch_layout(tensors)
+        tscope, gscope = tensors[0][-1], tensors[1][-1]
+        host = self._stage(slot, total)
+        pack_into(host.numpy(), arrays, layout)          # straight into the (pinned) staging buffer
+        if not self.cuda:
+            return unpack_views(host.clone(), layout, tscope, gscope), None
+        with torch.cuda.stream(self.stream):
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._staging_events[slot] = ev
+        return unpack_views(dev, layout, tscope, gscope), (ev, dev)
+
+    def __iter__(self) -> Iterator:
+        pending = []
+        it = iter(self.batches)
+        slot = 0
+        nslots = self.depth + 1
+        exhausted = False
+        while True:
+            while not exhausted and len(pending) < self.depth:
+                try:
+                    b = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                pending.append(self._upload(slot % nslots, b))
+                slot += 1
+            if not pending:
+                return
+            (tree, graph), sync = pending.pop(0)
+            if sync is not None:
+                ev, dev = sync
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)                       # consumer stream ordered behind the upload
+                dev.record_stream(cur)
+            yield tree, graph

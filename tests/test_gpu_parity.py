@@ -468,3 +468,23 @@ def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
             continue
         scale = max(float(ga.abs().max()), 1e-12)
         assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, k
+
+
+def test_device_prefetcher_feeds_the_encoder():
+    """N3: one pinned staging buffer + one async copy per batch on a copy stream; same tensors as make_cuda, and the
+    encoder consumes them (results equal to the make_cuda path)."""
+    from ggpm_amd import synth
+    from ggpm_amd.dataloader import DevicePrefetcher
+    from ggpm_amd.nnutils import make_cuda
+    g = Golden("tiny_gru_s1")
+    model = _build_encoder(g)
+    host = [synth.tensorize(synth.random_batch(s, g.B, motifs=g.motifs, n_motif_vocab=g.n_motif,
+                                               n_attach_vocab=g.n_attach)) for s in range(5)]
+    got = []
+    for tree, graph in DevicePrefetcher(host, depth=2):
+        assert all(t.is_cuda and t.dtype == torch.int64 for t in tree[:5] + graph[:4])
+        got.append([o.clone() for o in model.encoder(tree, graph)])
+    for outs, hb in zip(got, host):
+        tree, graph = make_cuda(hb)
+        for a, b in zip(outs, model.encoder(tree, graph)):
+            assert torch.equal(a, b)

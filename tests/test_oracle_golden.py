@@ -144,3 +144,20 @@ def test_oracle_incremental_encoder_matches_reference(name):
         want = g.z["grad/" + k]
         got = t.grad.numpy() if t.grad is not None else np.zeros_like(want)
         assert rel_err(got, want) < 1e-4, k
+
+
+# ---------------------------------------------------------------- host -> device input path
+def test_prefetcher_layout_matches_make_cuda_on_cpu():
+    from ggpm_amd.dataloader import DevicePrefetcher, pack_batch, unpack_views
+    specs = [synth.random_batch(s, 3, motifs=(2, 5), n_motif_vocab=11, n_attach_vocab=33) for s in (1, 2, 3)]
+    host = [synth.tensorize(b) for b in specs]
+    out = list(DevicePrefetcher(host, device="cpu", depth=2))
+    assert len(out) == 3
+    for (tree, graph), (htree, hgraph) in zip(out, host):
+        for a, b in zip(tree[:5], htree[:5]):
+            assert a.dtype == torch.int64 and tuple(a.shape) == tuple(b.shape) and (a.numpy() == b).all()
+        for a, b in zip(graph[:4], hgraph[:4]):
+            assert a.dtype == torch.int64 and tuple(a.shape) == tuple(b.shape) and (a.numpy() == b).all()
+        assert tree[-1] == htree[-1] and graph[-1] == hgraph[-1]
+    flat, layout, ts, gs = pack_batch(host[0])
+    assert all(off % 2 == 0 for off, _ in layout)

@@ -17,8 +17,15 @@ sync = FlatGradSync(model.parameters())
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 
 
+host_iter = None
+if os.environ.get("HOST_INPUT"):
+    import itertools
+    from ggpm_amd.dataloader import DevicePrefetcher
+    host_iter = iter(DevicePrefetcher(itertools.cycle(pool), depth=2))
+
+
 def step(i):
-    tree, graph = dev_batches[i % len(dev_batches)]
+    tree, graph = next(host_iter) if host_iter is not None else dev_batches[i % len(dev_batches)]
     sync.zero_grad()
     hroot, hnode, hinter, hatom = model.encoder.forward_padded(tree, graph)
     _, kl = rsample(hroot, model.R_mean, model.R_var, perturb=False)
