@@ -53,6 +53,9 @@ SIGNATURES = {
                                      P, I, P]),
     "ggpm_lstm_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                       P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_softmax_ce": (I, [P, I, I, I, P, I, P, P, P, P, I, P, P, P]),
+    "ggpm_bce_logits": (I, [P, P, I, P, P, P, P]),
+    "ggpm_scale_rows": (I, [P, I, I, I, P, P]),
     "ggpm_encoder_saved_bytes": (c_size_t, [P]),
     "ggpm_encoder_work_bytes": (c_size_t, [P]),
     "ggpm_encoder_forward": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, P, P]),

@@ -1,0 +1,129 @@
+// Decoder score-head losses -- reference ggpm/decoder.py:66-69, 136-164, 262-283.
+//
+//   softmax cross entropy, reduction = sum, with the reference's additive vocabulary mask fused in:
+//       icls_scores = iclsNN(cls_vecs) + vocab.get_mask(cls_labs)     (decoder.py:143-157, vocab.py:34-41,56-58)
+//       loss = sum_m ( logsumexp_n z[m, n] - z[m, label[m]] ),   z[m, :] = logits[m, :] + mask[mask_row[m], :]
+//     One wave per prediction row walks the class dimension three times out of L2 (max, sum of exponentials, gradient);
+//     the per-row losses are reduced in a fixed order, so the loss is bitwise reproducible.  The backward gradient
+//     dz = softmax(z) - onehot(label) is written by the same launch (the loss is always differentiated in training).
+//   BCE with logits, reduction = sum (topology head): loss = sum max(x,0) - x y + log(1 + exp(-|x|)), dx = sigmoid(x) - y.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) softmax_ce_k(const float* __restrict__ logits, int ld, int M, int N,
+                                                    const float* __restrict__ mask, int ld_mask,
+                                                    const int32_t* __restrict__ mask_row,
+                                                    const int32_t* __restrict__ label, float* __restrict__ row_loss,
+                                                    float* __restrict__ dlogits, int ld_d, int32_t* __restrict__ argmax) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* z = logits + (size_t)m * ld;
+    const float* mk = (mask && mask_row) ? mask + (size_t)mask_row[m] * ld_mask : nullptr;
+    const int lab = label[m];
+    float mx = -3.0e38f;
+    int amax = 0;
+    for (int n = lane; n < N; n += 64) {
+        const float v = z[n] + (mk ? mk[n] : 0.f);
+        if (v > mx) { mx = v; amax = n; }
+    }
+    const float wmx = wave_max(mx);
+    if (argmax) {        // first index attaining the maximum (torch.max semantics)
+        int cand = (mx == wmx) ? amax : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+        if (lane == 0) argmax[m] = cand;
+    }
+    float se = 0.f;
+    for (int n = lane; n < N; n += 64) se += expf(z[n] + (mk ? mk[n] : 0.f) - wmx);
+    se = wave_sum(se);
+    const float lse = wmx + logf(se);
+    if (lane == 0) row_loss[m] = lse - (z[lab] + (mk ? mk[lab] : 0.f));
+    if (dlogits) {
+        float* d = dlogits + (size_t)m * ld_d;
+        const float inv = 1.f / se;
+        for (int n = lane; n < N; n += 64)
+            d[n] = expf(z[n] + (mk ? mk[n] : 0.f) - wmx) * inv - (n == lab ? 1.f : 0.f);
+    }
+}
+
+__global__ void bce_logits_k(const float* __restrict__ x, const float* __restrict__ y, int M,
+                             float* __restrict__ row_loss, float* __restrict__ dx) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float v = x[m], t = y[m];
+    row_loss[m] = fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+    if (dx) dx[m] = ggpm_sigmoid(v) - t;
+}
+
+// out[0] = sum_m v[m] in a fixed order (single workgroup, pairwise tree over fixed slots)
+__global__ void __launch_bounds__(256) sum_rows_k(const float* __restrict__ v, int M, float* __restrict__ out) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256) acc += v[m];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+__global__ void scale_rows_k(float* __restrict__ d, int ld, int M, int N, const float* __restrict__ scale) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n < N) d[(size_t)m * ld + n] *= scale[0];
+}
+
+}  // namespace
+
+// loss[0] = sum of the row losses; dlogits (nullable, [M][ld_d]) = d loss / d logits for an upstream gradient of 1;
+// argmax (nullable, [M]) = predicted class per row (for get_accuracy, ggpm/nnutils.py:84-87); work: M floats.
+extern "C" int ggpm_softmax_ce(const float* logits, int ld, int M, int N, const float* mask, int ld_mask,
+                               const int32_t* mask_row, const int32_t* label, float* loss, float* dlogits, int ld_d,
+                               int32_t* argmax, float* work, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!logits || !label || !loss || !work || M <= 0 || N <= 0 || ld < N || (dlogits && ld_d < N) ||
+        ((mask == nullptr) != (mask_row == nullptr)))
+        return GGPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    softmax_ce_k<<<ggpm_ceil_div(M, 4), 256, 0, s>>>(logits, ld, M, N, mask, ld_mask, mask_row, label, work, dlogits, ld_d,
+                                                    argmax);
+    sum_rows_k<<<1, 256, 0, s>>>(work, M, loss);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_bce_logits(const float* x, const float* y, int M, float* loss, float* dx, float* work,
+                               ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!x || !y || !loss || !work || M <= 0) return GGPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bce_logits_k<<<ggpm_ceil_div(M, 256), 256, 0, s>>>(x, y, M, work, dx);
+    sum_rows_k<<<1, 256, 0, s>>>(work, M, loss);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+// d[m, 0:N] *= scale[0]   (chain rule for an upstream gradient that is a device scalar)
+extern "C" int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scale, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!d || !scale || M <= 0 || N <= 0 || ld < N) return GGPM_ERR_ARG;
+    dim3 grid(ggpm_ceil_div(N, 256), M);
+    scale_rows_k<<<grid, 256, 0, (hipStream_t)stream>>>(d, ld, M, N, scale);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

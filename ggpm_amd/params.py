@@ -85,3 +85,15 @@ def seeded_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, bias_scale:
             v = std * rs.standard_normal(shape)
         out[name] = v.astype(np.float32)
     return out
+
+
+def score_head_shapes(hidden: int, latent: int, embed: int, n_motif: int, n_attach: int):
+    """topoNN / clsNN / iclsNN / matchNN / W_assm of HierMPNDecoder (reference ggpm/decoder.py:35-58)."""
+    H, L = hidden, latent
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for name, n_out in (("topoNN", 1), ("clsNN", n_motif), ("iclsNN", n_attach)):
+        s[name + ".0.weight"] = (H, H + L); s[name + ".0.bias"] = (H,)
+        s[name + ".3.weight"] = (n_out, H); s[name + ".3.bias"] = (n_out,)
+    s["matchNN.0.weight"] = (H, H + embed + MAX_POS); s["matchNN.0.bias"] = (H,)
+    s["W_assm.weight"] = (L, H); s["W_assm.bias"] = (L,)
+    return s

@@ -219,6 +219,19 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
                               float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
                               ggpm_stream_t stream);
 
+/* ------------------------------------------------------------------ decoder score-head losses
+ * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in
+ * (ggpm/decoder.py:66-69,143-157,268-271): z[m,:] = logits[m,:] + mask[mask_row[m],:] (mask / mask_row both null for
+ * no mask), loss[0] = sum_m logsumexp(z[m,:]) - z[m,label[m]]; dlogits (nullable) = softmax(z) - onehot(label);
+ * argmax (nullable) = first maximal class per row (get_accuracy, ggpm/nnutils.py:84-87).  work: M floats.
+ * ggpm_bce_logits: nn.BCEWithLogitsLoss(size_average=False) of the topology head (decoder.py:66,262-264).
+ * ggpm_scale_rows: d[m,:] *= scale[0] (upstream gradient held on the device).  All sums are order-fixed. */
+int ggpm_softmax_ce(const float* logits, int ld, int M, int N, const float* mask, int ld_mask, const int32_t* mask_row,
+                    const int32_t* label, float* loss, float* dlogits, int ld_d, int32_t* argmax, float* work,
+                    ggpm_stream_t stream);
+int ggpm_bce_logits(const float* x, const float* y, int M, float* loss, float* dx, float* work, ggpm_stream_t stream);
+int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scale, ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ whole-encoder drivers
  * HierMPNEncoder.forward (ggpm/encoder.py:140-157, with embed_graph/inter/tree/root :96-138) and its backward as ONE
  * call each: the same kernels the op-by-op host path issues, sequenced from C++ (GRU or LSTM message function).

@@ -400,6 +400,38 @@ def inc_teacher_forced(p: Params, kind: str, rnn_type: str, depthT: int, depthG:
     return out, dec_tensors
 
 
+# ---------------------------------------------------------------- decoder score heads + losses (ggpm/decoder.py:35-69, 136-164, 262-283)
+def _head(p: Params, name: str, x: Tensor) -> Tensor:
+    """Sequential(Linear, ReLU, Dropout(inactive), Linear) -- ggpm/decoder.py:35-52."""
+    return _affine(p, name + ".3", torch.relu(_affine(p, name + ".0", x)))
+
+
+def vocab_mask(n_motif: int, n_attach: int, owner: Tensor, dtype) -> Tensor:
+    """PairVocab.mask -- ggpm/vocab.py:34-41: 0 where attachment `idx` belongs to motif `owner[idx]`, -1000 elsewhere."""
+    mask = torch.zeros(n_motif, n_attach, dtype=dtype)
+    mask[owner, torch.arange(n_attach)] = 1000.0
+    return mask - 1000.0
+
+
+def score_heads(p: Params, mask: Tensor, src_tree_vecs: Tensor, src_graph_vecs: Tensor, topo_vecs: Tensor,
+                topo_idx: Tensor, topo_labels: Tensor, cls_vecs: Tensor, cls_idx: Tensor, cls_labs: Tensor,
+                icls_labs: Tensor, assm_vecs: Tensor, assm_idx: Tensor, assm_labels: Tensor, batch_size: int):
+    """get_topo_score / get_cls_score / get_assm_score and the loss of HierMPNDecoder.forward --
+    ggpm/decoder.py:136-164, 262-283 (attention off, losses with size_average=False)."""
+    topo = _head(p, "topoNN", torch.cat([topo_vecs, src_tree_vecs.index_select(0, topo_idx)], dim=-1)).squeeze(-1)
+    x = torch.cat([cls_vecs, src_tree_vecs.index_select(0, cls_idx)], dim=-1)
+    cls = _head(p, "clsNN", x)
+    icls = _head(p, "iclsNN", x) + mask.index_select(0, cls_labs)
+    cxt = src_graph_vecs.index_select(0, assm_idx.reshape(-1)).view(assm_idx.shape + (-1,))
+    assm = (_affine(p, "W_assm", assm_vecs) * cxt).sum(dim=-1)
+    F = torch.nn.functional
+    topo_loss = F.binary_cross_entropy_with_logits(topo, topo_labels.to(topo.dtype), reduction="sum")
+    cls_loss = F.cross_entropy(cls, cls_labs, reduction="sum") + F.cross_entropy(icls, icls_labs, reduction="sum")
+    assm_loss = F.cross_entropy(assm, assm_labels, reduction="sum")
+    loss = (topo_loss + cls_loss + assm_loss) / batch_size
+    return {"topo": topo, "cls": cls, "icls": icls, "assm": assm, "loss": loss}
+
+
 # ---------------------------------------------------------------- KL (ggpm/property_vae.py:26-33)
 def rsample_kl(p: Params, hroot: Tensor, pre_mean: str = "R_mean", pre_var: str = "R_var",
                eps: Tensor | None = None) -> Tuple[Tensor, Tensor]:

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from ggpm_amd.params import (encoder_param_shapes, vae_head_shapes, seeded_state_dict,
-                             motif_encoder_param_shapes)
+                             motif_encoder_param_shapes, score_head_shapes)
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 N_PROBE = 64
@@ -15,7 +15,7 @@ N_PROBE = 64
 def case_names(prefix="", motif=False):
     """HierMPNEncoder fixtures by default; ``motif=True`` lists the MotifEncoder fixtures instead."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    names = [n for n in names if not n.startswith(("sparse_", "inc_"))]   # those fixtures have their own tests
+    names = [n for n in names if not n.startswith(("sparse_", "inc_", "heads_"))]   # those fixtures have their own tests
     return [n for n in names if n.startswith("motif_") == motif]
 
 
@@ -156,3 +156,49 @@ class IncGolden(Golden):
         if self.kind == "hier":
             keys += ["inter_mess", "graph_mess", "graph_node", "inter_node"]
         return keys
+
+
+def heads_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "heads_*.npz")))
+
+
+class HeadsGolden:
+    """Decoder score-head fixtures (tests/golden/make_golden_heads.py)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.H, self.L, self.n_motif, self.n_attach, self.B, self.seed = [int(v) for v in self.z["meta"]]
+
+    def params(self, dtype=torch.float32, device="cpu", requires_grad=False):
+        sd = seeded_state_dict(score_head_shapes(self.H, self.L, self.H, self.n_motif, self.n_attach), self.seed)
+        out = {}
+        for k, v in sd.items():
+            t = torch.from_numpy(v).to(dtype).to(device)
+            out[k] = t.requires_grad_(True) if requires_grad else t
+        return out
+
+    def inputs(self, dtype=torch.float32, device="cpu"):
+        fl = {k[3:]: torch.from_numpy(self.z[k]).to(dtype).to(device).requires_grad_(True)
+              for k in self.z.files if k.startswith("in/")}
+        ix = {k[4:]: torch.from_numpy(self.z[k]).to(device) for k in self.z.files if k.startswith("idx/")}
+        return fl, ix
+
+    def check_grad(self, pname, g, rel):
+        g = np.asarray(g, dtype=np.float64)
+        if "grad/" + pname in self.z.files:
+            want = self.z["grad/" + pname]
+            if np.abs(want).max() < 1e-6:      # analytically zero (W_assm.bias: the candidates of a row share one
+                assert np.abs(g).max() < 1e-5, pname      # context and softmax gradients sum to 0): rounding noise only
+                return
+            assert rel_err(g, want) < rel, pname
+            return
+        h = 0
+        for ch in pname:
+            h = (h * 131 + ord(ch)) % (2 ** 31)
+        rs = np.random.RandomState((h + self.seed) % (2 ** 31))
+        idx = rs.randint(0, g.size, size=min(N_PROBE, g.size))
+        stat = self.z["gstat/" + pname]
+        scale = max(float(stat[2]), 1e-12)
+        assert np.abs(g.reshape(-1)[idx] - self.z["gprobe/" + pname]).max() <= rel * scale, pname
+        assert abs(np.sqrt((g ** 2).sum()) - stat[1]) <= rel * max(stat[1], 1e-12) * 10, pname

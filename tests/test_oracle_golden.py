@@ -7,7 +7,8 @@ from ggpm_amd import synth
 from oracle import ref_encoder as ref
 import os
 
-from golden_utils import GOLDEN_DIR, Golden, IncGolden, case_names, inc_case_names, rel_err, sparse_inputs
+from golden_utils import (GOLDEN_DIR, Golden, HeadsGolden, IncGolden, case_names, heads_case_names, inc_case_names,
+                          rel_err, sparse_inputs)
 
 CASES = case_names()
 
@@ -161,3 +162,25 @@ def test_prefetcher_layout_matches_make_cuda_on_cpu():
         assert tree[-1] == htree[-1] and graph[-1] == hgraph[-1]
     flat, layout, ts, gs = pack_batch(host[0])
     assert all(off % 2 == 0 for off, _ in layout)
+
+
+# ---------------------------------------------------------------- decoder score heads + losses
+@pytest.mark.parametrize("name", heads_case_names())
+def test_oracle_score_heads_match_reference(name):
+    g = HeadsGolden(name)
+    dtype = torch.float64
+    p = g.params(dtype=dtype, requires_grad=True)
+    fl, ix = g.inputs(dtype=dtype)
+    mask = ref.vocab_mask(g.n_motif, g.n_attach, torch.from_numpy(g.z["owner"]), dtype)
+    out = ref.score_heads(p, mask, fl["src_tree_vecs"], fl["src_graph_vecs"], fl["topo_vecs"], ix["topo_idx"],
+                          ix["topo_labels"], fl["cls_vecs"], ix["cls_idx"], ix["cls_labs"], ix["icls_labs"],
+                          fl["assm_vecs"], ix["assm_idx"], ix["assm_labels"], g.B)
+    out["loss"].backward()
+    for k in ("topo", "cls", "icls", "assm"):
+        assert rel_err(out[k].detach().numpy(), g.z[k]) < 2e-5, k
+    assert abs(float(out["loss"].detach()) - float(g.z["loss"])) < 2e-5 * abs(float(g.z["loss"]))
+    for k, t in fl.items():
+        assert rel_err(t.grad.numpy(), g.z["din/" + k]) < 1e-4, k
+    for k, t in p.items():
+        if t.grad is not None:
+            g.check_grad(k, t.grad.numpy(), 1e-4)
