@@ -53,6 +53,8 @@ SIGNATURES = {
                                      P, I, P]),
     "ggpm_lstm_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                       P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_rsample_forward": (I, [P, P, P, I, I, P, P, P]),
+    "ggpm_rsample_backward": (I, [P, P, P, P, P, I, I, P, P, P]),
     "ggpm_softmax_ce": (I, [P, I, I, I, P, I, P, P, P, P, I, P, P, P]),
     "ggpm_bce_logits": (I, [P, P, I, P, P, P, P]),
     "ggpm_scale_rows": (I, [P, I, I, I, P, P]),

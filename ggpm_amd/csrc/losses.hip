@@ -127,3 +127,59 @@ extern "C" int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scal
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// KL head of HierPropertyVAE.rsample (reference ggpm/property_vae.py:26-33), the elementwise part after the two
+// [B,H]x[H,L] products:  lv = -|pv| ; kl = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B ; z = mean + exp(lv/2) * eps.
+// One workgroup (B*L is ~1e3); the sum runs over fixed slots -> bitwise reproducible.
+namespace {
+__global__ void __launch_bounds__(256) rsample_fwd_k(const float* __restrict__ mean, const float* __restrict__ pv,
+                                                     const float* __restrict__ eps, int n, int B, float* __restrict__ z,
+                                                     float* __restrict__ kl) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float m = mean[i], lv = -fabsf(pv[i]);
+        acc += 1.f + lv - m * m - expf(lv);
+        z[i] = eps ? m + expf(0.5f * lv) * eps[i] : m;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kl[0] = -0.5f * part[0] / (float)B;
+}
+
+__global__ void rsample_bwd_k(const float* __restrict__ mean, const float* __restrict__ pv, const float* __restrict__ eps,
+                              const float* __restrict__ dz, const float* __restrict__ dkl, int n, int B,
+                              float* __restrict__ dmean, float* __restrict__ dpv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = mean[i], p = pv[i], lv = -fabsf(p);
+    const float gk = dkl ? dkl[0] : 0.f, gz = dz ? dz[i] : 0.f;
+    dmean[i] = gz + gk * m / (float)B;
+    float dlv = gk * (-0.5f / (float)B) * (1.f - expf(lv));
+    if (eps) dlv += gz * eps[i] * 0.5f * expf(0.5f * lv);
+    dpv[i] = (p > 0.f ? -1.f : (p < 0.f ? 1.f : 0.f)) * dlv;      // d(-|p|)/dp = -sign(p)  (0 at p = 0, as torch.abs)
+}
+}  // namespace
+
+extern "C" int ggpm_rsample_forward(const float* mean, const float* pv, const float* eps, int B, int L, float* z,
+                                    float* kl, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!mean || !pv || !z || !kl || B <= 0 || L <= 0) return GGPM_ERR_ARG;
+    rsample_fwd_k<<<1, 256, 0, (hipStream_t)stream>>>(mean, pv, eps, B * L, B, z, kl);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_rsample_backward(const float* mean, const float* pv, const float* eps, const float* dz,
+                                     const float* dkl, int B, int L, float* dmean, float* dpv, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!mean || !pv || !dmean || !dpv || B <= 0 || L <= 0) return GGPM_ERR_ARG;
+    rsample_bwd_k<<<ggpm_ceil_div(B * L, 256), 256, 0, (hipStream_t)stream>>>(mean, pv, eps, dz, dkl, B * L, B, dmean, dpv);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

@@ -2,7 +2,7 @@
 
 The decoder is outside this build's scope.  ``rsample`` restates
 ggpm/property_vae.py:26-33; the two [B,H]x[H,latent] products run through the library GEMM, the
-[B,latent] elementwise tail is plain torch on the same stream (negligible, listed for parity only).
+[B,latent] elementwise tail (|.|, exp, KL sum, reparameterisation) is one HIP launch each way (csrc/losses.hip).
 """
 from __future__ import annotations
 
@@ -14,20 +14,44 @@ from .encoder import HierMPNEncoder
 from .nnutils import make_cuda
 
 
+class _RsampleTail(torch.autograd.Function):
+    """(mean, pv, eps) -> (z, kl): the elementwise part of rsample in one launch each way (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, mean, pv, eps):
+        from . import _lib
+        B, L = mean.shape
+        mean, pv = mean.contiguous(), pv.contiguous()
+        eps = eps.contiguous() if eps is not None else None
+        z = torch.empty_like(mean)
+        kl = torch.empty(1, dtype=torch.float32, device=mean.device)
+        _lib.check(_lib.load().ggpm_rsample_forward(F_._p(mean), F_._p(pv), F_._p(eps), B, L, F_._p(z), F_._p(kl),
+                                                    F_._stream()), "rsample_forward")
+        ctx.save_for_backward(mean, pv)
+        ctx.eps = eps
+        return z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        from . import _lib
+        mean, pv = ctx.saved_tensors
+        B, L = mean.shape
+        dz = dz.contiguous() if dz is not None else None
+        dkl = dkl.reshape(1).contiguous() if dkl is not None else None
+        dmean, dpv = torch.empty_like(mean), torch.empty_like(pv)
+        _lib.check(_lib.load().ggpm_rsample_backward(F_._p(mean), F_._p(pv), F_._p(ctx.eps), F_._p(dz), F_._p(dkl), B, L,
+                                                     F_._p(dmean), F_._p(dpv), F_._stream()), "rsample_backward")
+        return dmean, dpv, None
+
+
 def rsample(z_vecs, W_mean: nn.Linear, W_var: nn.Linear, perturb: bool = True, z_width=None):
     """(z, kl) -- reference ggpm/property_vae.py:26-33. ``z_vecs`` may carry zero pad columns."""
-    batch_size = z_vecs.size(0)
     H = W_mean.weight.shape[1]
     L = W_mean.weight.shape[0]
     z_mean = F_.linear([z_vecs], [H], W_mean.weight, W_mean.bias, ld_out=L)
-    z_log_var = -torch.abs(F_.linear([z_vecs], [H], W_var.weight, W_var.bias, ld_out=L))
-    kl_loss = -0.5 * torch.sum(1.0 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)) / batch_size
-    if perturb:
-        epsilon = torch.randn_like(z_mean)
-        z = z_mean + torch.exp(z_log_var / 2) * epsilon
-    else:
-        z = z_mean
-    return z, kl_loss
+    pre_var = F_.linear([z_vecs], [H], W_var.weight, W_var.bias, ld_out=L)
+    eps = torch.randn_like(z_mean) if perturb else None        # the reference draws epsilon with torch's generator too
+    return _RsampleTail.apply(z_mean, pre_var, eps)
 
 
 class HierEncoderVAE(nn.Module):

@@ -232,6 +232,14 @@ int ggpm_softmax_ce(const float* logits, int ld, int M, int N, const float* mask
 int ggpm_bce_logits(const float* x, const float* y, int M, float* loss, float* dx, float* work, ggpm_stream_t stream);
 int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scale, ggpm_stream_t stream);
 
+/* KL head, elementwise part of HierPropertyVAE.rsample (ggpm/property_vae.py:26-33) after the two [B,H]x[H,L] products:
+ * lv = -|pv|; kl[0] = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B; z = mean + exp(lv/2) * eps (eps null: z = mean).
+ * mean, pv, eps, z, dz, dmean, dpv: contiguous [B, L]; dz / dkl may be null (no gradient from that output). */
+int ggpm_rsample_forward(const float* mean, const float* pv, const float* eps, int B, int L, float* z, float* kl,
+                         ggpm_stream_t stream);
+int ggpm_rsample_backward(const float* mean, const float* pv, const float* eps, const float* dz, const float* dkl,
+                          int B, int L, float* dmean, float* dpv, ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ whole-encoder drivers
  * HierMPNEncoder.forward (ggpm/encoder.py:140-157, with embed_graph/inter/tree/root :96-138) and its backward as ONE
  * call each: the same kernels the op-by-op host path issues, sequenced from C++ (GRU or LSTM message function).

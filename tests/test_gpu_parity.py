@@ -538,3 +538,30 @@ def test_decoder_score_heads_match_reference_golden(name):
         if k.startswith("matchNN"):
             continue                          # enum_attach is decoder-loop code, not part of the score/loss path
         g.check_grad(k, v.grad.cpu().numpy(), TOL)
+
+
+def test_rsample_with_perturbation_matches_torch_formula():
+    """A8 with perturb=True: z = mean + exp(lv/2) * eps and the KL, forward and backward, against the reference's torch
+    formula (ggpm/property_vae.py:26-33) evaluated with the SAME epsilon draw."""
+    from ggpm_amd.property_vae import rsample
+    dev = _dev()
+    torch.manual_seed(5)
+    B, H, L = 9, 40, 12
+    hv = torch.randn(B, H, device=dev, requires_grad=True)
+    Wm, Wv = torch.nn.Linear(H, L).to(dev), torch.nn.Linear(H, L).to(dev)
+    cz = torch.randn(B, L, device=dev)
+    torch.manual_seed(11)
+    z, kl = rsample(hv, Wm, Wv, perturb=True)
+    (0.3 * kl + (cz * z).sum()).backward()
+    got = [z.detach().clone(), kl.detach().clone(), hv.grad.clone(), Wm.weight.grad.clone(), Wv.weight.grad.clone(),
+           Wv.bias.grad.clone()]
+    hv.grad = None
+    Wm.zero_grad(); Wv.zero_grad()
+    torch.manual_seed(11)
+    mean, lv = Wm(hv), -torch.abs(Wv(hv))
+    kl2 = -0.5 * torch.sum(1.0 + lv - mean * mean - torch.exp(lv)) / B
+    z2 = mean + torch.exp(lv / 2) * torch.randn_like(mean)
+    (0.3 * kl2 + (cz * z2).sum()).backward()
+    want = [z2.detach(), kl2.detach(), hv.grad, Wm.weight.grad, Wv.weight.grad, Wv.bias.grad]
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
