@@ -37,6 +37,14 @@ __device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
     return make_float4(ggpm_sigmoid(a.x), ggpm_sigmoid(a.y), ggpm_sigmoid(a.z), ggpm_sigmoid(a.w));
 }
 __device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// sigmoid on the hardware exp2 / rcp units (~2 ulp): the gather phases of the depth kernels evaluate one per gathered
+// neighbour element and were VALU bound with the libm expf + IEEE division forms
+__device__ __forceinline__ float ggpm_fsigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// tanh(x) = 1 - 2 / (1 + exp(2x)) on the same units (absolute error ~2e-7)
+__device__ __forceinline__ float ggpm_ftanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {
+    return make_float4(ggpm_fsigmoid(a.x), ggpm_fsigmoid(a.y), ggpm_fsigmoid(a.z), ggpm_fsigmoid(a.w));
+}
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global stores / loads
 // (__syncthreads() also drains vmcnt, which puts every store's acknowledgement on the critical path).  A wave

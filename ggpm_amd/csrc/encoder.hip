@@ -35,6 +35,7 @@ struct Csr {
     int32_t *rowptr, *col;
     int rows, ncols, cap;
     int32_t *rowptrT, *colT, *cursor;
+    int32_t *tab, *tabT;          // 4-entry neighbour tables of the CSR / its transpose (pred levels only)
 };
 
 struct LevelSaved {
@@ -76,6 +77,8 @@ void take_csr(Arena& A, Csr& c, int rows, int ncols, int cap) {
     c.rowptrT = A.take<int32_t>(ncols + 1);
     c.colT = A.take<int32_t>(c.cap);
     c.cursor = A.take<int32_t>(ncols);
+    c.tab = A.take<int32_t>((size_t)rows * 4);
+    c.tabT = A.take<int32_t>((size_t)ncols * 4);
 }
 
 void take_level(Arena& A, LevelSaved& L, int E1, int N1, int Hp, int H, int depth, bool lstm) {
@@ -104,6 +107,7 @@ void layout_saved(Arena& A, const Dims& d, Saved& s) {
         c.rows = rows; c.ncols = ncols; c.cap = rows;
         c.rowptr = s.iota; c.col = nullptr;
         c.rowptrT = A.take<int32_t>(ncols + 1); c.colT = A.take<int32_t>(rows); c.cursor = A.take<int32_t>(ncols);
+        c.tab = c.tabT = nullptr;
     };
     take_index(s.tsrc, d.E1t, d.N1t);
     take_index(s.root, d.B, d.N1t);
@@ -134,6 +138,11 @@ inline int lp(int level, int which) { return P_LEVEL0 + level * L_COUNT + which;
 inline int lq(int level, int which) { return P_LEVEL0 + level * Q_COUNT + which; }
 inline int lwo(bool lstm, int level) { return lstm ? lq(level, Q_WO) : lp(level, L_WO); }
 inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level, L_BO); }
+
+inline bool use_tables() {
+    static const bool on = getenv("GGPM_TABLES") != nullptr && atoi(getenv("GGPM_TABLES")) != 0;   // opt-in: measured slower
+    return on;
+}
 
 #define CK(expr)                    \
     do {                            \
@@ -172,9 +181,9 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
     CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wh, I + H, L.X + 2 * slot, Hp, Hp, P[lp(level, L_BH)], 0, GGPM_ACT_NONE, 0,
                  nullptr, 0, s));
     const size_t ds = (size_t)depth * slot;
-    CK(ggpm_gru_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
-                        P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, L.Hs, L.Qs, L.St, L.St + ds,
-                        L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
+    CK(ggpm_gru_forward_tab(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
+                            P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, use_tables() ? pred.tab : nullptr,
+                            L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
     CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
     return GGPM_OK;
 }
@@ -219,6 +228,8 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, stream));
     CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, stream));
     CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, stream));
+    CK(ggpm_csr_table4(S.gpred.rowptr, S.gpred.col, d.E1g, S.gpred.tab, stream));
+    CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, stream));
     CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, stream));
     CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, stream));
     CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, stream));
@@ -237,8 +248,10 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     {
         ggpm_stream_t ts = side_stream ? side_stream : stream;
         CK(transpose(S.gpred, nullptr, ts));
+        CK(ggpm_csr_table4(S.gpred.rowptrT, S.gpred.colT, d.E1g, S.gpred.tabT, ts));
         CK(transpose(S.gagr, nullptr, ts));
         CK(transpose(S.tpred, nullptr, ts));
+        CK(ggpm_csr_table4(S.tpred.rowptrT, S.tpred.colT, d.E1t, S.tpred.tabT, ts));
         CK(transpose(S.tagr, nullptr, ts));
         CK(transpose(S.tcgr, nullptr, ts));
         CK(transpose(S.tsrc, S.src, ts));
@@ -411,10 +424,11 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             (void)hipStreamWaitEvent((hipStream_t)st.side, ev, 0);
         }
     } else {
-        CK(ggpm_gru_backward(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H, pred.rowptr,
-                             pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds,
-                             L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dWz + I, I + H, dUr, H,
-                             G[lp(level, L_BU)], dWh + I, I + H, level_work, w.level_work_bytes, 0, st.main));
+        CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
+                                 pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
+                                 L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
+                                 dX + 2 * slot, dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
+                                 w.level_work_bytes, 0, st.main));
     }
     if (dx) {       // needed upstream right away: main stream
         CK(ggpm_gemm(0, 0, E1, I, H, dX, Hp, Wz, I + H, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, st.main));

@@ -15,6 +15,7 @@
 // Weight gradients are three tall split-K GEMMs over the [depth*E1, Hp] stashes (gemm.hip).
 #include "tile_mma.h"
 #include <cstdlib>
+#include <cstdio>
 
 __global__ void ggpm_pack_weight_kernel(GgpmPackArgs a) {
     const int Hp = a.Hp, H = a.H, KC = Hp / 16;
@@ -61,6 +62,8 @@ struct GruFwdArgs {
     int ablate;                    // timing experiments only (GGPM_ABLATE): 1 no gather, 2 no GEMM
     const unsigned char* frozen;   // sparse_forward only: rows with frozen[row] != 0 keep their state (h' = h)
     int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
+    unsigned long long* dbg;       // optional phase stamps of workgroup (0,0) (GGPM_ADEBUG; dev only)
+    const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
 };
 
 __global__ void gru_init_state(float* __restrict__ H0, float* __restrict__ Q0, const float* __restrict__ bu,
@@ -94,11 +97,16 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
     const int t = grp * a.tg + wave;              // this wave's output tile (if wave < tg)
+    const bool dbg_on = a.dbg && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (dbg_on) a.dbg[0] = wall_clock64();
 
     // ---- P1: gather
     for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
         const int row = r0 + lr;
-        GgpmRowList rl = ggpm_row_list(a.rowptr, row, a.E1);
+        bool fast;
+        const int tchunk = ggpm_table_chunk(a.ptab, row, a.E1, lane, fast);
+        GgpmRowList rl;
+        if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
         if (a.ablate & 1) rl.n = 0;
         const size_t rowo = (size_t)(row < a.E1 ? row : 0) * Hp;
         for (int c0 = 0; c0 < Hp; c0 += 512) {
@@ -114,7 +122,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                 xr[k] = ggpm_ld4(a.Xr + rowo + cs[k]);
             }
             for (int base = 0; base < rl.n; base += 64) {
-                const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
+                const int chunk = fast ? tchunk : ggpm_list_chunk(a.col, rl, base, lane);
                 const int m = min(64, rl.n - base);
                 for (int j = 0; j < m; j += 4) {
                     float4 h[4][2], q[4][2];
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {          // null slots: h[0] == 0 contributes nothing
-                            const float4 r = ggpm_sigmoid4(xr[k] + q[u][k]);
+                            const float4 r = ggpm_fsigmoid4(xr[k] + q[u][k]);
                             const float4 rh = r * h[u][k];
                             s[k] = s[k] + h[u][k];
                             g[k] = g[k] + rh;
@@ -154,7 +162,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         }
     }
 
+    if (dbg_on) a.dbg[1] = wall_clock64();
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
+    if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
     const int lr = lane & 15, row = r0 + lr;
@@ -171,6 +181,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             const float* const wps[2] = {a.Wz, a.Wh};
             ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
+        if (dbg_on) a.dbg[3] = wall_clock64();
         float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
         if (row >= a.E1) {
             if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, h);
@@ -193,6 +204,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             ggpm_st4(a.M + o, m);
         }
     }
+    if (dbg_on) a.dbg[4] = wall_clock64();
     if (!a.fuse_b) return;
 
     // ---- P3 (single column group only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
@@ -259,6 +271,7 @@ struct GruBwdArgs {
     int final_pass;                // t == 0: P1 + dq.U_r only, result to dHin
     float* dHin;                   // [E1,Hp]
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
+    const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
@@ -279,7 +292,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     if (!a.first) {
         for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
             const int p = r0 + lr;
-            const GgpmRowList rl = ggpm_row_list(a.srowptr, p, a.E1);
+            bool fast;
+            const int tchunk = ggpm_table_chunk(a.stab, p, a.E1, lane, fast);
+            GgpmRowList rl;
+            if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.srowptr, p, a.E1);
             const size_t po = (size_t)(p < a.E1 ? p : 0) * Hp;
             for (int c0 = 0; c0 < Hp; c0 += 512) {
                 int c[2], cs[2];
@@ -295,7 +311,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                     qp[k] = ggpm_ld4(a.Qcur + po + cs[k]);
                 }
                 for (int base = 0; base < rl.n; base += 64) {
-                    const int chunk = ggpm_list_chunk(a.scol, rl, base, lane);
+                    const int chunk = fast ? tchunk : ggpm_list_chunk(a.scol, rl, base, lane);
                     const int m = min(64, rl.n - base);
                     for (int j = 0; j < m; j += 2) {
                         float4 xr[2][2], dg[2][2], ds[2][2];
@@ -313,7 +329,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                const float4 r = ggpm_sigmoid4(xr[u][k] + qp[k]);
+                                const float4 r = ggpm_fsigmoid4(xr[u][k] + qp[k]);
                                 const float4 dgr = dg[u][k] * r;
                                 dh[k] = dh[k] + ds[u][k] + dgr;
                                 dq[k] = dq[k] + dgr * hp[k] * one_minus(r);
@@ -486,6 +502,13 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
     a.fuse_b = (with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    static unsigned long long* dbg_buf = nullptr;
+    static int dbg_count = 0;
+    a.dbg = nullptr;
+    if (getenv("GGPM_ADEBUG")) {
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
+        a.dbg = dbg_buf;
+    }
     if (a.fuse_b) with_b = false;
     const size_t lds_a = (a.fuse_b ? 3 : 2) * lds_b;
     ggpm_timing_begin(0, s, (a.fuse_b ? 3 : 2) * flops1);
@@ -497,6 +520,14 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
         gru_fwd_a<false><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     }
     ggpm_timing_end(0, s);
+    if (a.dbg && (++dbg_count % 97) == 0) {
+        unsigned long long h[5];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[adebug E1=%d grid=%dx%d fuse=%d] gather %.2f barrier %.2f gemm %.2f epilogue %.2f us\n", a.E1,
+                grid_a.x, grid_a.y, a.fuse_b, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01,
+                (h[4] - h[3]) * 0.01);
+    }
     if (with_b) {
         set_lds(gru_fwd_b, lds_b);
         ggpm_timing_begin(4, s, 1 * flops1);
@@ -552,7 +583,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
                             const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
                             float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs,
                             float* wpack, int save_for_backward, const float* h_in, const unsigned char* frozen,
-                            ggpm_stream_t stream) {
+                            ggpm_stream_t stream, const int32_t* pred_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xz || !Xr || !Xh || !Wz_h || !Ur || !bu || !Wh_h || !pred_rowptr ||
         !pred_col || !Hs || !Qs || !wpack)
@@ -587,11 +618,12 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     const char* abl = getenv("GGPM_ABLATE");
     for (int t = 1; t <= depth; ++t) {
-        GruFwdArgs a;
+        GruFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xz = Xz; a.Xr = Xr; a.Xh = Xh;
         a.Wz = pWz; a.Wh = pWh; a.Ur = pUr; a.bu = pbu; a.rowptr = pred_rowptr; a.col = pred_col;
         a.ablate = abl ? atoi(abl) : 0;
         a.frozen = frozen;
+        a.ptab = pred_tab;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
             a.Qprev = Qs + (size_t)(t - 1) * slot;
@@ -618,6 +650,16 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
                                 ggpm_stream_t stream) {
     return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
                             Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, nullptr, nullptr, stream);
+}
+
+// ggpm_gru_forward / ggpm_gru_backward with the optional 4-entry neighbour tables of ggpm_csr_table4 (null = CSR walk)
+extern "C" int ggpm_gru_forward_tab(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
+                                    const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
+                                    const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
+                                    const int32_t* pred_tab, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs,
+                                    float* Ms, float* Rs, float* wpack, int save_for_backward, ggpm_stream_t stream) {
+    return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
+                            Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, nullptr, nullptr, stream, pred_tab);
 }
 
 extern "C" int ggpm_gru_sparse_forward(int E1, int H, int depth, const float* h_in, const unsigned char* frozen,
@@ -668,7 +710,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, int weight_grads,
                                  const unsigned char* frozen, float* dHin, ggpm_stream_t stream,
-                                 ggpm_stream_t side_stream = nullptr) {
+                                 ggpm_stream_t side_stream = nullptr, const int32_t* succ_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
@@ -708,7 +750,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     int chunk_hi = depth, n_ev = 0;
     bool first_chunk = true, dur_started = false;
     for (int t = depth; t >= 1; --t) {
-        GruBwdArgs a;
+        GruBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
         a.Xr = Xr;
         a.Hcur = Hs + (size_t)t * slot;
@@ -723,7 +765,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.DMP = DMP + (size_t)(t - 1) * slot; a.DZP = DZP + (size_t)(t - 1) * slot; a.DSD = DSD;
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
-        a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
         if (side_stream && !frozen) {
             // Overlapped weight gradients: the stash slots of the depths finished so far are final, so their share of
@@ -800,6 +842,20 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
                              succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
                              dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream);
+}
+
+extern "C" int ggpm_gru_backward_tab(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
+                                     const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
+                                     const int32_t* pred_rowptr, const int32_t* pred_col,
+                                     const int32_t* succ_rowptr, const int32_t* succ_col, const int32_t* succ_tab,
+                                     const float* Hs, const float* Qs, const float* Ss, const float* Gs, const float* Zs,
+                                     const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr,
+                                     float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
+                                     float* dWh_h, int ld_dwh, float* work, size_t work_bytes, int weight_grads,
+                                     ggpm_stream_t stream) {
+    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
+                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
+                             dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream, nullptr, succ_tab);
 }
 
 // As ggpm_gru_backward with weight_grads = 0, but the h-half weight gradients (dWz_h, dUr, dbu, dWh_h) are issued on
