@@ -272,6 +272,7 @@ struct GruBwdArgs {
     float* dHin;                   // [E1,Hp]
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
     const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
+    unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
@@ -287,6 +288,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     const int grp = blockIdx.y;
     const int t = grp * a.tg + wave;
 
+    const bool dbg_on = a.dbg && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (dbg_on) a.dbg[0] = wall_clock64();
     // ---- P1: dh_p += dS_e + dG_e*r ; dq_p += dG_e * h_p * r(1-r) over successors e (null slots: row 0,
     // where dS = dG = 0)
     if (!a.first) {
@@ -347,7 +350,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         }
     }
 
+    if (dbg_on) a.dbg[1] = wall_clock64();
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dq stash stores finish under the GEMM
+    if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: dh = partial + dq . U_r ; gate derivatives, for this wave's tiles
     const int lr = lane & 15, row = r0 + lr;
@@ -370,6 +375,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             const float* const wps[1] = {a.UrT};
             ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
         }
+        if (dbg_on) a.dbg[3] = wall_clock64();
         if (row >= a.E1) {
             if (a.fuse_b) {
                 ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, ggpm_zero4());
@@ -417,6 +423,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             ggpm_st4(a.DSD + o, dsdir);
         }
     }
+    if (dbg_on) a.dbg[4] = wall_clock64();
     if (!a.fuse_b) return;
 
     // ---- P3 (single column group only): the workgroup holds the complete dz_pre / dm_pre rows ->
@@ -545,9 +552,24 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     if (a.fuse_b) with_b = false;
     const size_t lds_a = a.fuse_b ? 2 * lds : lds;
     set_lds(gru_bwd_a, lds_a);
+    static unsigned long long* dbg_buf = nullptr;
+    static int dbg_count = 0;
+    a.dbg = nullptr;
+    if (getenv("GGPM_ADEBUG")) {
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
+        a.dbg = dbg_buf;
+    }
     ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
     gru_bwd_a<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     ggpm_timing_end(1, s);
+    if (a.dbg && !a.first && (++dbg_count % 89) == 0) {
+        unsigned long long h[5];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[adebug bwd E1=%d grid=%dx%d fuse=%d] gather %.2f barrier %.2f gemm %.2f epilogue %.2f us\n", a.E1,
+                grid_a.x, grid_a.y, a.fuse_b, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01,
+                (h[4] - h[3]) * 0.01);
+    }
     if (with_b) {
         set_lds(gru_bwd_b, lds);
         ggpm_timing_begin(5, s, 2 * flops1);

@@ -33,7 +33,7 @@ template <int NOPS, int RT>
 __device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS], int LD,
                                                const float* const (&wps)[NOPS], int KC, int t, int lane,
                                                f32x4 (&acc)[NOPS][RT]) {
-    constexpr int PF = GGPM_PF;
+    constexpr int PF = GGPM_PF;       // (a deeper ring for the single-product loops measured no faster)
     const int boff = (lane & 15) * LD + 4 * (lane >> 4);
     const float* wp[NOPS];
 #pragma unroll
