@@ -501,6 +501,10 @@ inline void set_lds(K kernel, size_t bytes) {
 
 inline int pick_tg(int E1, int NT) {
     if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
+    if (const char* e = getenv("GGPM_TG_SMALL")) {      // tuning override for the small (motif / attachment) levels only
+        int v = atoi(e);
+        if (v >= 1 && v <= 64 && (E1 + 15) / 16 <= 64) return v < NT ? v : NT;
+    }
     return ggpm_tiles_per_group(E1, NT);
 }
 
