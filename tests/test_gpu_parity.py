@@ -565,3 +565,72 @@ def test_rsample_with_perturbation_matches_torch_formula():
     want = [z2.detach(), kl2.detach(), hv.grad, Wm.weight.grad, Wv.weight.grad, Wv.bias.grad]
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("M,N,masked", [(1, 7, False), (5, 64, True), (130, 721, True), (33, 1000, False)])
+def test_softmax_ce_and_bce_kernels_against_torch(M, N, masked):
+    """ggpm_softmax_ce (optional additive mask rows, arg-max, gradient) and ggpm_bce_logits vs torch, odd shapes."""
+    from ggpm_amd.decoder_heads import bce_with_logits_sum, cross_entropy_sum
+    dev = _dev()
+    torch.manual_seed(M * 1000 + N)
+    ld = (N + 3) // 4 * 4
+    buf = torch.randn(M, ld, device=dev)
+    logits = buf[:, :N].detach().requires_grad_(True) if ld == N else None
+    x = torch.randn(M, N, device=dev, requires_grad=True)
+    labels = torch.randint(0, N, (M,), device=dev)
+    n_rows = 6
+    mask = (torch.rand(n_rows, N, device=dev) > 0.5).float() * -1000.0 if masked else None
+    mask_row = torch.randint(0, n_rows, (M,), device=dev) if masked else None
+    if masked:                                    # the label must stay unmasked (as the vocabulary guarantees)
+        mask[mask_row, labels] = 0.0
+    loss, amax = cross_entropy_sum(x, labels, mask=mask, mask_row=mask_row)
+    (1.7 * loss).backward()
+    z = x.detach().clone().requires_grad_(True)
+    zz = z + (mask.index_select(0, mask_row) if masked else 0.0)
+    want = torch.nn.functional.cross_entropy(zz, labels, reduction="sum")
+    (1.7 * want).backward()
+    assert abs(float(loss.detach()) - float(want.detach())) <= 2e-5 * max(abs(float(want.detach())), 1.0)
+    assert float((x.grad - z.grad).abs().max()) <= 2e-6
+    assert (amax.long() == zz.detach().argmax(-1)).all()
+    s = torch.randn(M, device=dev, requires_grad=True)
+    y = torch.randint(0, 2, (M,), device=dev)
+    l2 = bce_with_logits_sum(s, y)
+    l2.backward()
+    s2 = s.detach().clone().requires_grad_(True)
+    w2 = torch.nn.functional.binary_cross_entropy_with_logits(s2, y.float(), reduction="sum")
+    w2.backward()
+    assert abs(float(l2.detach()) - float(w2.detach())) <= 2e-5 * max(abs(float(w2.detach())), 1.0)
+    assert float((s.grad - s2.grad).abs().max()) <= 2e-6
+
+
+def test_csr_table4_and_cluster_builder():
+    """ggpm_csr_table4 (first four entries, overflow marker) and ggpm_build_clusters (closed row ranges) vs numpy."""
+    import ctypes
+    from ggpm_amd import _lib, synth, functional as F_
+    dev = _dev()
+    specs = synth.random_batch(3, 7, motifs=(3, 9), n_motif_vocab=11, n_attach_vocab=33)
+    tree, graph = synth.tensorize(specs)
+    bg = torch.from_numpy(graph[3].astype(np.int64)).to(dev)
+    E1 = bg.shape[0]
+    csr = F_.csr_from_padded(bg, ncols=E1)
+    lib = _lib.load()
+    tab = torch.empty(E1, 4, dtype=torch.int32, device=dev)
+    _lib.check(lib.ggpm_csr_table4(F_._p(csr.rowptr), F_._p(csr.col), E1, F_._p(tab), F_._stream()), "csr_table4")
+    pad = graph[3]
+    got = tab.cpu().numpy()
+    for r in range(E1):
+        ent = [int(v) for v in pad[r] if v != 0]
+        exp = (ent + [0, 0, 0, 0])[:4]
+        if len(ent) > 4:
+            exp[3] = -1
+        assert list(got[r]) == exp
+    for target in (8, 40, 10 ** 6):
+        table = csr.clusters(target).cpu().numpy()
+        n = int(table[0])
+        bounds = table[1:n + 2]
+        assert bounds[0] == 0 and bounds[-1] == E1 and (np.diff(bounds) > 0).all()
+        assert all(b - a >= target for a, b in zip(bounds[:-2], bounds[1:-1]))
+        for a, b in zip(bounds[:-1], bounds[1:]):           # closed: every predecessor of a row lies in its own range
+            sub = pad[a:b]
+            nz = sub[sub != 0]
+            assert nz.size == 0 or (nz.min() >= a and nz.max() < b)
