@@ -4,15 +4,21 @@
 // (ggpm/nnutils.py:65-70).  Restated over CSR predecessor lists with the x-halves of W_z/W_r/W_h hoisted
 // out of the depth loop and U_r applied once per message (q = U_r h + b_u) instead of once per padded slot.
 //
-// One launch per depth; a workgroup (4 waves) owns 16 message rows for all Hp feature columns:
-//   P1  CSR gather of predecessor rows (h_p, q_p) from L2 -> s, g tiles in LDS   (coalesced 16B/lane)
-//   P2  gate GEMMs on MFMA f32 16x16x4:  Wz_h . s  and  Wh_h . g  (weights streamed packed from L2)
-//       + fused gate math -> h' (global + LDS tile)
-//   P3  q' = U_r h' + b_u on MFMA from the LDS tile
+// Geometry (tile_mma.h): grid = (16-row message tiles) x (column groups of `tg` output tiles), 16 waves per workgroup.
+// Per depth, forward:
+//   kernel A  P1  CSR gather of predecessor rows (h_p, q_p) -> s, g tiles in LDS (one wave per row, 16 B per lane,
+//                 hardware exp2/rcp sigmoid; the stash stores drain under the GEMM: LDS-only barrier)
+//             P2  gate GEMMs on MFMA f32 16x16x4:  Wz_h . s  and  Wh_h . g  (weights streamed packed from L2)
+//                 + fused gate math -> h'
+//             P3  only when the level has ONE column group (the workgroup then holds the complete h' rows):
+//                 q' = U_r h' + b_u from an LDS tile -- no second launch
+//   kernel B  otherwise: q' = U_r h' + b_u with the h' rows re-read from L2
 // Backward mirrors it (gather over SUCCESSORS through the transposed CSR, so no atomics):
-//   P1  dq, dh-partial tiles from successors   P2  dh = partial + dq.U_r ; gate derivatives
-//   P3  dG = dm_pre.Wh_h, dS = ds_dir + dz_pre.Wz_h   P4  dXr accumulation over predecessors
-// Weight gradients are three tall split-K GEMMs over the [depth*E1, Hp] stashes (gemm.hip).
+//   kernel A  P1  dq, dh-partial tiles from successors   P2  dh = partial + dq.U_r ; gate derivatives
+//             P3  (one column group) dG = dm_pre.Wh_h, dS = ds_dir + dz_pre.Wz_h, dXr += dG * R
+//   kernel B  otherwise the same products from rows re-read from L2
+// Weight gradients are three tall split-K GEMMs over the [depth*E1, Hp] stashes (gemm.hip), issued by the caller
+// on a second stream.  sparse_forward (rows with a `frozen` mask) reuses the same kernels.
 #include "tile_mma.h"
 #include <cstdlib>
 #include <cstdio>

@@ -4,11 +4,11 @@
 // predecessors; the x-halves of W_i/W_o/W/W_f (+ their biases) are hoisted (Xi, Xo, Xu, Xf) and the hidden
 // half of the forget gate is applied once per message (qf = Wf_h h) instead of once per padded slot.
 //
-// Same workgroup geometry as mpn_gru.hip (16 message rows x all Hp columns, 4 waves, MFMA f32 16x16x4):
-//   fwd  P1 gather (h_p, c_p, qf_p) -> s, fc tiles | P2 [Wi_h;Wo_h;Wu_h].s + gate math -> h', c'
-//        P3 qf' = Wf_h h'
-//   bwd  P1 successors -> dh partial, dqf, dc tiles | P2 dh += dqf.Wf_h ; gate derivatives
-//        P3 dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h | P4 dXf accumulation over predecessors
+// Same geometry as mpn_gru.hip (16-row message tiles x column groups, 16 waves, MFMA f32 16x16x4):
+//   fwd  A: P1 gather (h_p, c_p, qf_p) -> s, fc tiles | P2 [Wi_h;Wo_h;Wu_h].s + gate math -> h', c'
+//           P3 (one column group) qf' = Wf_h h'          B: otherwise the same product from rows re-read from L2
+//   bwd  A: P1 successors -> dh partial, dqf, dc tiles | P2 dh += dqf.Wf_h ; gate derivatives, dXf += dFC * F
+//           P3 (one column group) dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h      B: otherwise, from L2
 #include "tile_mma.h"
 #include <cstdlib>
 
