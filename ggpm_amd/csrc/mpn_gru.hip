@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     const int t = grp * a.tg + wave;              // this wave's output tile (if wave < tg)
     const bool dbg_on = a.dbg && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
     if (dbg_on) a.dbg[0] = wall_clock64();
+    const bool dbg15 = a.dbg && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 15 * 64;
+    if (dbg15) a.dbg[5] = wall_clock64();
 
     // ---- P1: gather
     for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
@@ -169,6 +171,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     }
 
     if (dbg_on) a.dbg[1] = wall_clock64();
+    if (dbg15) a.dbg[6] = wall_clock64();
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
@@ -538,12 +541,12 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
     }
     ggpm_timing_end(0, s);
     if (a.dbg && (++dbg_count % 97) == 0) {
-        unsigned long long h[5];
+        unsigned long long h[7];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[adebug E1=%d grid=%dx%d fuse=%d] gather %.2f barrier %.2f gemm %.2f epilogue %.2f us\n", a.E1,
-                grid_a.x, grid_a.y, a.fuse_b, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01,
-                (h[4] - h[3]) * 0.01);
+        fprintf(stderr, "[adebug E1=%d grid=%dx%d fuse=%d] gather %.2f barrier %.2f gemm %.2f epilogue %.2f us; wave 15 starts "
+                "+%.2f, gathers %.2f\n", a.E1, grid_a.x, grid_a.y, a.fuse_b, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01,
+                (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, ((double)h[5] - (double)h[0]) * 0.01, (h[6] - h[5]) * 0.01);
     }
     if (with_b) {
         set_lds(gru_fwd_b, lds_b);
