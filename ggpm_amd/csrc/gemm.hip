@@ -8,6 +8,14 @@
 // Operands are staged k-major in LDS so that the MFMA A/B fragments (lane l: row l&31, k = l>>5)
 // are conflict-free ds_read_b32.  MFMA f32 is an exact k-ordered fmaf chain (guide section 3), so the
 // result does not depend on how tiles are scheduled; split-K partial slabs are reduced in a fixed order.
+//
+// Tall weight-gradient contractions (C = A^T B with K = depth*E in the tens of thousands and a 300 x 300 output) take
+// gemm_tn_tall instead: 160 x 160 output tile per workgroup on v_mfma_f32_16x16x4_f32 (25 independent accumulator
+// blocks per wave, 10 LDS reads per 25 MFMAs), operands double-buffered in LDS with ONE LDS-only barrier per k-step
+// and the next step's global loads issued a full step ahead.  The 64 x 64 kernel moved 31 B of operands per KFLOP
+// through L2 and spent as long on that as on the MFMAs (253 + 270 us of a 500 us launch, not overlapped).
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -24,6 +32,7 @@ struct GemmArgs {
     int vecA, vecB;          // 16-byte vector loads legal for A / B
     int k_chunk;             // K range per blockIdx.z (multiple of BK); == K when not split
     float* ws;               // split-K slabs [gridDim.z][M][N] or nullptr
+    unsigned long long* dbg; // dev (GGPM_GEMM_DEBUG): loop stamps of workgroup 0
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -148,6 +157,208 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// C (or split-K slab) = A^T B for row-major A [K x lda], B [K x ldb]: both operands are contiguous along the
+// output dimensions, so tiles go global -> registers -> LDS as float4 without any transposition.
+constexpr int TM = 160, TN = 160, TK = 16, TLD = 176;   // TLD % 64 == 48: the 4 k-rows of a fragment read hit disjoint banks
+constexpr int T_F4 = (TM + TN) / 4 * TK;                // float4 per k-step (1280) = 5 per thread
+
+__global__ void __launch_bounds__(256) gemm_tn_tall(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][2 * TK * TLD];   // [buffer][A rows | B rows][k][column]
+    // workgroups are dealt round-robin over the 8 XCDs: renumber so that the tiles of one K chunk share an L2
+    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);
+    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+    const int m0 = by * TM, n0 = bx * TN;
+    const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Waves 0-1 stage the A rows of every k-step, waves 2-3 the B rows: 640 float4 per operand = 5 per thread, fetched
+    // with buffer loads.  The descriptor ends at row `kend`, so the K tail reads zeros, and columns beyond M / N get an
+    // out-of-range offset (zeros too) -- no branches in the loop.  (The operand choice is wave-uniform and made scalar
+    // explicitly: a lane-dependent descriptor would turn every load into a waterfall loop.)
+    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+    const float* P = isb ? g.B : g.A;
+    const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0,
+                                                                        (unsigned)((size_t)kend * ld * 4), 0x00020000);
+    unsigned voff[5];
+    int loff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int f = (threadIdx.x & 127) + 128 * i;
+        const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
+        loff[i] = isb * TK * TLD + k * TLD + c;
+        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
+    }
+    const unsigned vstep = (unsigned)TK * ld * 4;
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Two register sets: the loads of k-step s+2 are issued at the top of step s and written to LDS at the end of
+    // step s+1, so every load has two full steps (~2.6 us of MFMAs) to land; LDS holds steps s and s+1.
+    f32x4 r0[5], r1[5];
+    auto fetch1 = [&](f32x4& r, int i) {
+        r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+        if (voff[i] != 0xffffff00u) voff[i] += vstep;
+    };
+    // One k-step = 4 k-quads of 25 MFMAs on buffer `cur`, software-pipelined so that the matrix pipe never waits.
+    // A quad is 5 rounds of [a few staging instructions | 5 MFMAs]: the pipe idles while a wave issues a RUN of LDS or
+    // memory instructions (10 fragment reads in front of every quad cost 15 %), so they are dealt out by hand and
+    // fenced -- the scheduler otherwise regroups them.
+    //   * round i of every quad reads fragment i (one a, one b value) of the NEXT quad into the other fragment set;
+    //   * quad 0 also issues the loads of k-step s+2 and writes the rows of step s+1 (loaded a step ago) to the other
+    //     buffer: load i is issued right before row i is written, so each write waits for exactly vmcnt(5);
+    //   * the step's only barrier sits in front of quad 3: by then every wave has written the other buffer and has
+    //     received its last fragments of this one, so the next step's quad 0 is read behind it, under quad 3's MFMAs,
+    //     and the next step's writes into `cur` cannot overtake a reader.
+    const int fbase = (lane >> 4) * TLD + wm * 80 + (lane & 15), bdelta = TK * TLD + (wn - wm) * 80;
+    float fa[2][5], fb[2][5];
+    auto quad = [&](int set, const float* next, bool staging, const f32x4 (&rs_)[5], f32x4 (&rl)[5], int sbuf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (staging) fetch1(rl[i], i);
+            fa[set ^ 1][i] = next[16 * i];
+            fb[set ^ 1][i] = next[bdelta + 16 * i];
+            if (staging) *reinterpret_cast<f32x4*>(&Ls[sbuf][loff[i]]) = rs_[i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                // accumulator tied to one AGPR block: with the builtin the allocator gave 36 of the 200 MFMAs of the
+                // unrolled loop a destination different from their addend and rotated 48 registers back every trip
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[set][i]), "v"(fb[set][j]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Branch-free: loads past `kend` return zeros without touching memory, so the loop runs an even number of steps
+    // (at most one of them on zeros) and needs no tail conditions.
+    auto step = [&](const f32x4 (&rs_)[5], f32x4 (&rl)[5], int cur) {
+        const float* F = &Ls[cur][fbase];
+        quad(0, F + 4 * TLD, true, rs_, rl, cur ^ 1);
+        quad(1, F + 8 * TLD, false, rs_, rl, cur ^ 1);
+        quad(0, F + 12 * TLD, false, rs_, rl, cur ^ 1);
+        ggpm_lds_barrier();
+        quad(1, &Ls[cur ^ 1][fbase], false, rs_, rl, cur ^ 1);
+    };
+
+    const bool dbg_on = g.dbg && L == 0 && threadIdx.x == 0;
+    if (dbg_on) { g.dbg[0] = clock64(); g.dbg[1] = wall_clock64(); }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) fetch1(r0[i], i);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(&Ls[0][loff[i]]) = r0[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) fetch1(r1[i], i);
+    ggpm_lds_barrier();
+    if (dbg_on) { g.dbg[2] = clock64(); g.dbg[3] = wall_clock64(); }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        fa[0][i] = Ls[0][fbase + 16 * i];
+        fb[0][i] = Ls[0][fbase + bdelta + 16 * i];
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
+        step(r1, r0, 0);
+        step(r0, r1, 1);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulators are read
+    if (dbg_on) { g.dbg[4] = clock64(); g.dbg[5] = wall_clock64(); }
+
+    // lane l holds rows 4*(l>>4) + 0..3, column (l & 15) of every 16 x 16 block
+    if (g.ws) {
+        // split-K slab in FRAGMENT order [chunk][tile][wave][block][lane][4]: one coalesced 16-byte store per block
+        // (row-major slabs meant 400 predicated 4-byte stores per lane, ~15 us of a 125 us launch); tall_reduce
+        // undoes the order once, after summing
+        f32x4* slab = reinterpret_cast<f32x4*>(g.ws) +
+                      ((((size_t)bz * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + wave) * 25) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) slab[(i * 5 + j) * 64] = acc[i][j];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int n = n0 + wn * 80 + 16 * j + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 80 + 16 * i + 4 * (lane >> 4) + e;
+                if (m >= g.M) continue;
+                if (n < g.N) {
+                    float v = acc[i][j][e];
+                    if (g.bias) v += g.bias[n];
+                    float* dst = g.C + (size_t)m * g.ldc + n;
+                    if (g.accumulate) v += *dst;
+                    v = apply_act(v, g.act);
+                    if (g.zero_row0 && m == 0) v = 0.f;
+                    *dst = v;
+                } else if (n < g.n_pad) {
+                    g.C[(size_t)m * g.ldc + n] = 0.f;
+                }
+            }
+        }
+}
+
+// Sums the fragment-order slabs of gemm_tn_tall over the K chunks (fixed order: four interleaved partial sums per
+// workgroup, combined as (0+1)+(2+3)) and writes C.  One workgroup per (tile, wave, 16 x 16 block).
+__global__ void __launch_bounds__(256) tall_reduce(GemmArgs g, int splits, int tiles_n, int tiles) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int blk = blockIdx.x % 25, wave = (blockIdx.x / 25) & 3, tile = blockIdx.x / 100;
+    const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + (((size_t)tile * 4 + wave) * 25 + blk) * 64 + lane;
+    const size_t zstride = (size_t)tiles * 4 * 25 * 64;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int z = zg; z < splits; z += 4) v += p[z * zstride];
+    part[zg][lane] = v;
+    __syncthreads();
+    if (zg) return;
+    v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int i = blk / 5, j = blk % 5;
+    const int n = (tile % tiles_n) * TN + (wave & 1) * 80 + 16 * j + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = (tile / tiles_n) * TM + (wave >> 1) * 80 + 16 * i + 4 * (lane >> 4) + e;
+        if (m >= g.M) continue;
+        float* dst = g.C + (size_t)m * g.ldc + n;
+        if (n < g.N) {
+            float x = v[e];
+            if (g.bias) x += g.bias[n];
+            if (g.accumulate) x += *dst;
+            x = apply_act(x, g.act);
+            if (g.zero_row0 && m == 0) x = 0.f;
+            *dst = x;
+        } else if (n < g.n_pad) {
+            *dst = 0.f;
+        }
+    }
+}
+
+// The tall kernel pays when the 160 x 160 tiles cover the output without much padding and K is long.
+inline bool tall_shape(int M, int N, int K) {
+    if (K < 6144 || M < 64 || N < 64) return false;     // measured: 300 x 300 x 2843 is faster on the 64 x 64 kernel
+    const double cover = (double)ggpm_round_up(M, TM) * ggpm_round_up(N, TN);
+    return (double)M * N >= 0.8 * cover;
+}
+inline size_t tall_slab_bytes(int M, int N) {
+    return (size_t)ggpm_ceil_div(M, TM) * ggpm_ceil_div(N, TN) * 4 * 25 * 64 * sizeof(f32x4);
+}
+inline int tall_splits(int M, int N, int K) {
+    static const int target = [] { const char* e = getenv("GGPM_GEMM_TALL_WGS"); return e ? atoi(e) : 256; }();
+    const int tiles = ggpm_ceil_div(M, TM) * ggpm_ceil_div(N, TN);
+    int s = target / tiles, maxs = K / (8 * TK);
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : s;
+}
+
 __global__ void splitk_reduce(GemmArgs g, int splits) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
@@ -226,8 +437,13 @@ __global__ void act_backward_k(const float* __restrict__ dy, const float* __rest
 }  // namespace
 
 extern "C" size_t ggpm_gemm_workspace_bytes(int M, int N, int K) {
-    int s = choose_splits(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    const int s = choose_splits(M, N, K);
+    size_t bytes = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    if (tall_shape(M, N, K)) {      // the caller's transposes are not known here: room for either kernel
+        const int ts = tall_splits(M, N, K);
+        if (ts > 1) bytes = max(bytes, ts * tall_slab_bytes(M, N));
+    }
+    return bytes;
 }
 
 extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda,
@@ -242,6 +458,38 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     g.n_pad = n_pad; g.bias = bias; g.accumulate = accumulate; g.act = act; g.zero_row0 = zero_row0;
     g.vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    if (use_tall && trans_a && !trans_b && g.vecA && g.vecB && lda >= ggpm_round_up(M, 4) && ldb >= ggpm_round_up(N, 4) &&
+        tall_shape(M, N, K) && n_pad <= ggpm_round_up(N, TN) && (size_t)K * lda * 4 < 0xffffff00ull && (size_t)K * ldb * 4 < 0xffffff00ull) {
+        int splits = splitk_ws ? tall_splits(M, N, K) : 1;
+        const size_t slab = tall_slab_bytes(M, N);
+        if (splits > 1 && (size_t)splits * slab > splitk_ws_bytes) splits = (int)(splitk_ws_bytes / slab);
+        if (splits < 1) splits = 1;
+        g.k_chunk = ggpm_round_up(ggpm_ceil_div(K, splits), TK);
+        splits = ggpm_ceil_div(K, g.k_chunk);
+        g.ws = splits > 1 ? splitk_ws : nullptr;
+        const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
+        dim3 grid(tiles_n, tiles_m, splits);
+        static unsigned long long* dbg = [] {
+            unsigned long long* p = nullptr;
+            if (getenv("GGPM_GEMM_DEBUG")) (void)hipMalloc(&p, 64);
+            return p;
+        }();
+        g.dbg = dbg;
+        gemm_tn_tall<<<grid, 256, 0, s>>>(g);
+        if (dbg) {
+            unsigned long long h[6];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            const int steps = ggpm_ceil_div(g.k_chunk, 2 * TK) * 2;
+            fprintf(stderr, "[gemm_tn_tall %dx%dx%d grid %dx%dx%d] prologue %.2f us, loop %.2f us = %d steps x %.0f cycles, "
+                    "shader clock %.2f GHz\n", M, N, K, grid.x, grid.y, grid.z, (h[3] - h[1]) * 0.01, (h[5] - h[3]) * 0.01,
+                    steps, (double)(h[4] - h[2]) / steps, (double)(h[4] - h[2]) / ((h[5] - h[3]) * 10.0));
+        }
+        if (splits > 1) tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(g, splits, tiles_n, tiles_n * tiles_m);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     int splits = 1;
     if (splitk_ws) {
         splits = choose_splits(M, N, K);

@@ -49,7 +49,9 @@ def test_padded_to_csr_and_transpose(rows, width):
 
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 33, 70, 62), (0, 1, 513, 300, 320), (0, 0, 257, 62, 300),
                                          (1, 0, 300, 320, 5000), (1, 0, 16, 16, 40), (0, 1, 1, 1, 1),
-                                         (1, 1, 65, 66, 67), (0, 1, 2751, 300, 62)])
+                                         (1, 1, 65, 66, 67), (0, 1, 2751, 300, 62),
+                                         # tall contractions: the 160 x 160 split-K kernel (ragged tiles, K % 16 != 0)
+                                         (1, 0, 300, 300, 7000), (1, 0, 160, 320, 6200), (1, 0, 148, 468, 9001)])
 def test_gemm_against_fp64(ta, tb, M, N, K):
     from ggpm_amd import functional as F_
     rs = np.random.RandomState(M * 7 + N * 3 + K)
@@ -66,13 +68,14 @@ def test_gemm_against_fp64(ta, tb, M, N, K):
     Bm = (B[:, :K].T if tb else B[:, :N]).astype(np.float64)
     ref = Am @ Bm + bias
     got = C.cpu().numpy()
-    assert rel_err(got[:, :N], ref) < 2e-6
+    tol = 2e-6 if K <= 5000 else 5e-6          # one fp32 chain over K terms (the unsplit second call below)
+    assert rel_err(got[:, :N], ref) < tol
     assert (got[:, N:ldc - 8] == 0).all() and (got[:, ldc - 8:] == 7.0).all()
     # accumulate + relu + row-0 mask
     F_.gemm(ta, tb, M, N, K, a, lda, b, ldb, C, ldc, N, accumulate=True, act=F_.ACT_RELU, zero_row0=True)
     ref2 = np.maximum((ref - bias) + got[:, :N], 0.0)
     ref2[0] = 0
-    assert rel_err(C.cpu().numpy()[:, :N], ref2) < 2e-6
+    assert rel_err(C.cpu().numpy()[:, :N], ref2) < tol
 
 
 def test_segment_sum_and_gather():
