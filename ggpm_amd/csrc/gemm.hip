@@ -158,6 +158,158 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same 64 x 64 tile with the pipeline of gemm_tn_tall (used whenever both operands allow 16-byte loads):
+// 64-wide k-steps, LDS double-buffered with ONE LDS-only barrier per step, two register sets so that every global
+// load has two full steps to land, buffer loads whose descriptors make row / column / K tails read zeros (no
+// branches), and the staging instructions dealt out by hand between pairs of MFMAs.  The old loop exposed one global
+// round trip per 32-wide k-step, which is what bounded the short-K projections (5-30 steps per workgroup).
+constexpr int BK2 = 64;
+
+template <bool CONTIG_K>
+struct OperandStage {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff[4], vstep;
+    int loff[4];       // LDS float offset of the thread's 4 float4 inside one operand buffer
+    int kq[4];         // CONTIG_K: first k of the float4 inside the step (for the K-tail mask)
+
+    // P: operand base, R rows/columns of the output dimension starting at r0, k range [kbeg, kend)
+    __device__ __forceinline__ void init(const float* P, int ld, int r0, int R, int kbeg, int kend, int total_rows) {
+        // CONTIG_K: element (r, k) at P[r*ld + k]: descriptor covers all rows; else (k, r) at P[k*ld + r]: ends at kend
+        const size_t bytes = CONTIG_K ? (size_t)total_rows * ld * 4 : (size_t)kend * ld * 4;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (unsigned)bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = threadIdx.x + 256 * i;           // 1024 float4 per operand per step
+            if (CONTIG_K) {
+                const int r = f >> 4, k4 = (f & 15) * 4;
+                kq[i] = k4;
+                loff[i] = k4 * LDT + r;
+                voff[i] = r0 + r < R ? (unsigned)(((size_t)(r0 + r) * ld + kbeg + k4) * 4) : 0xffffff00u;
+            } else {
+                const int k = f >> 4, c = (f & 15) * 4;
+                kq[i] = 0;
+                loff[i] = k * LDT + c;
+                voff[i] = r0 + c < R ? (unsigned)(((size_t)(kbeg + k) * ld + r0 + c) * 4) : 0xffffff00u;
+            }
+        }
+        vstep = CONTIG_K ? BK2 * 4u : (unsigned)BK2 * ld * 4;
+    }
+    __device__ __forceinline__ void load(f32x4& r, int i) {
+        r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+        if (voff[i] != 0xffffff00u) voff[i] += vstep;
+    }
+    // klen: valid k of the step being written (CONTIG_K reads past the row's K into the padding / the next row)
+    __device__ __forceinline__ void store(float* T, const f32x4& r, int i, int klen) const {
+        if (CONTIG_K) {
+            float* d = T + loff[i];
+            d[0] = kq[i] + 0 < klen ? r[0] : 0.f;
+            d[LDT] = kq[i] + 1 < klen ? r[1] : 0.f;
+            d[2 * LDT] = kq[i] + 2 < klen ? r[2] : 0.f;
+            d[3 * LDT] = kq[i] + 3 < klen ? r[3] : 0.f;
+        } else {
+            *reinterpret_cast<f32x4*>(T + loff[i]) = r;
+        }
+    }
+};
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][2][BK2 * LDT];      // [buffer][A | B][k][column]
+    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);        // XCD-contiguous tiles (see gemm_tn_tall)
+    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    OperandStage<!TA> sa;
+    OperandStage<TB> sb;
+    sa.init(g.A, g.lda, m0, g.M, kbeg, kend, TA ? g.K : g.M);
+    sb.init(g.B, g.ldb, n0, g.N, kbeg, kend, TB ? g.N : g.K);
+
+    const int fA = (lane >> 5) * LDT + wm * 32 + (lane & 31), fB = (lane >> 5) * LDT + wn * 32 + (lane & 31);
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    float fa[2][2], fb[2][2];
+    auto frag = [&](int buf, int pair2, int set) {       // the two k-pairs 2*pair2, 2*pair2 + 1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            fa[set][u] = Ls[buf][0][fA + (4 * pair2 + 2 * u) * LDT];
+            fb[set][u] = Ls[buf][1][fB + (4 * pair2 + 2 * u) * LDT];
+        }
+    };
+    // One 64-wide k-step on buffer `cur` = 16 rounds of [staging | 2 MFMAs]: round r reads the fragments of round
+    // r+1, rounds 0-7 issue the loads of step s+2 and write the rows of step s+1 (loaded one step ago) to the other
+    // buffer.  klen_next: valid k of step s+1.
+    auto step = [&](const f32x4 (&sa_)[4], const f32x4 (&sb_)[4], f32x4 (&la)[4], f32x4 (&lb)[4], int cur, int klen_next) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < 15) frag(cur, r + 1, (r + 1) & 1);
+            if (r < 8) {
+                if (r & 1) sb.load(lb[r >> 1], r >> 1); else sa.load(la[r >> 1], r >> 1);
+                if (r & 1) sb.store(Ls[cur ^ 1][1], sb_[r >> 1], r >> 1, klen_next);
+                else sa.store(Ls[cur ^ 1][0], sa_[r >> 1], r >> 1, klen_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[r & 1][0]), "v"(fb[r & 1][0]));
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[r & 1][1]), "v"(fb[r & 1][1]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ggpm_lds_barrier();
+        frag(cur ^ 1, 0, 0);
+    };
+
+    if (n0 < g.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sa.load(ra0[i], i); sb.load(rb0[i], i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa.store(Ls[0][0], ra0[i], i, kend - kbeg);
+            sb.store(Ls[0][1], rb0[i], i, kend - kbeg);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sa.load(ra1[i], i); sb.load(rb1[i], i); }
+        ggpm_lds_barrier();
+        frag(0, 0, 0);
+        // Whole steps in pairs (the register sets swap roles); loads past the end return zeros without touching
+        // memory, so at most one step of the pair multiplies zeros.
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK2) {
+            step(ra1, rb1, ra0, rb0, 0, kend - k0 - BK2);
+            step(ra0, rb0, ra1, rb1, 1, kend - k0 - 2 * BK2);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulator is read
+    }
+
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        if (g.ws) {
+            if (n < g.N) g.ws[((size_t)bz * g.M + m) * g.N + n] = acc[r];
+            continue;
+        }
+        if (n < g.N) {
+            float v = acc[r];
+            if (g.bias) v += g.bias[n];
+            float* dst = g.C + (size_t)m * g.ldc + n;
+            if (g.accumulate) v += *dst;
+            v = apply_act(v, g.act);
+            if (g.zero_row0 && m == 0) v = 0.f;
+            *dst = v;
+        } else if (n < g.n_pad) {
+            g.C[(size_t)m * g.ldc + n] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // C (or split-K slab) = A^T B for row-major A [K x lda], B [K x ldb]: both operands are contiguous along the
 // output dimensions, so tiles go global -> registers -> LDS as float4 without any transposition.
 constexpr int TM = 160, TN = 160, TK = 16, TLD = 176;   // TLD % 64 == 48: the 4 k-rows of a fragment read hit disjoint banks
@@ -501,7 +653,17 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     }
     if (splits <= 1) { splits = 1; g.k_chunk = ggpm_round_up(K, BK); g.ws = nullptr; } else { g.ws = splitk_ws; }
     dim3 grid(ggpm_ceil_div(splits > 1 ? N : n_pad, BN), ggpm_ceil_div(M, BM), splits);
-    if (!trans_a && !trans_b) gemm_kernel<false, false><<<grid, 256, 0, s>>>(g);
+    static const int use_v2 = [] { const char* e = getenv("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
+    const size_t rows_a = trans_a ? K : M, rows_b = trans_b ? N : K;
+    // v2 keeps 70 KB of LDS per workgroup (two resident per CU): it wins while the whole grid is resident at once
+    // (latency-bound launches: 573 x 600 x 912 35 -> 25 us) and loses beyond (2843 x 912 x 340: 33 -> 37 us)
+    const bool resident = (size_t)grid.x * grid.y * grid.z <= 512 || use_v2 == 2;
+    if (use_v2 && resident && g.vecA && g.vecB && rows_a * lda * 4 < 0xffffff00ull && rows_b * ldb * 4 < 0xffffff00ull) {
+        if (!trans_a && !trans_b) gemm_kernel_v2<false, false><<<grid, 256, 0, s>>>(g);
+        else if (!trans_a && trans_b) gemm_kernel_v2<false, true><<<grid, 256, 0, s>>>(g);
+        else if (trans_a && !trans_b) gemm_kernel_v2<true, false><<<grid, 256, 0, s>>>(g);
+        else gemm_kernel_v2<true, true><<<grid, 256, 0, s>>>(g);
+    } else if (!trans_a && !trans_b) gemm_kernel<false, false><<<grid, 256, 0, s>>>(g);
     else if (!trans_a && trans_b) gemm_kernel<false, true><<<grid, 256, 0, s>>>(g);
     else if (trans_a && !trans_b) gemm_kernel<true, false><<<grid, 256, 0, s>>>(g);
     else gemm_kernel<true, true><<<grid, 256, 0, s>>>(g);

@@ -14,12 +14,14 @@ from ggpm_amd import _lib  # noqa: E402
 SHAPES = [  # (trans_a, trans_b, M, N, K, label)
     (1, 0, 300, 300, 56860, "atom level dW_h / dW_z / dU_r (K = E*depth)"),
     (1, 0, 300, 300, 11460, "motif level dW (K = E*depth)"),
-    (1, 0, 300, 300, 2843, "short K"),
-    (1, 0, 450, 300, 20000, "LSTM-like"),
     (1, 0, 340, 912, 2843, "atom level dW_x (K = E)"),
+    (1, 0, 600, 900, 573, "motif level dW_x (K = E)"),
     (0, 1, 2843, 912, 340, "atom level input projection"),
+    (0, 1, 573, 912, 600, "motif level input projection"),
     (0, 0, 2843, 340, 912, "atom level dX"),
+    (0, 0, 573, 600, 912, "motif level dX"),
     (0, 1, 1225, 300, 600, "W_o readout"),
+    (0, 0, 1225, 600, 300, "W_o readout dX"),
 ]
 
 
@@ -30,7 +32,7 @@ def main():
     only = os.environ.get("SHAPE")
     for ta, tb, M, N, K, label in (SHAPES if only is None else [SHAPES[int(only)]]):
         make = torch.zeros if os.environ.get("ZEROS") else torch.randn
-        pad = lambda n: (n + 15) // 16 * 16 if n in (300, 450) else n     # the stashes are padded to Hp
+        pad = lambda n: (n + 15) // 16 * 16 if n in (300, 340, 600, 900) else n     # the stashes are padded to Hp
         A = make((K, pad(M)) if ta else (M, K), device=dev)
         B = make((N, K) if tb else (K, pad(N)), device=dev)
         if ta:
