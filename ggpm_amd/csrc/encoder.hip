@@ -154,9 +154,10 @@ inline bool use_tables() {
 int linear2(int M, int N, const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const float* W,
             const float* b, int act, int zero_row0, float* y, int ldy, ggpm_stream_t s) {
     const int ldw = K1 + K2;
-    CK(ggpm_gemm(0, 1, M, N, K1, x1, ld1, W, ldw, y, ldy, ldy, b, 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
-    CK(ggpm_gemm(0, 1, M, N, K2, x2, ld2, W + K1, ldw, y, ldy, ldy, nullptr, 1, act, zero_row0, nullptr, 0, s));
-    return GGPM_OK;
+    const float* A[2] = {x1, x2};
+    const float* B[2] = {W, W + K1};
+    const int lda[2] = {ld1, ld2}, ldb[2] = {ldw, ldw}, K[2] = {K1, K2};
+    return ggpm_gemm_ksegments(1, M, N, 2, A, lda, B, ldb, K, y, ldy, ldy, b, 0, act, zero_row0, s);
 }
 
 int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* x, int ldx, float* const* P, int level,
@@ -166,8 +167,9 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         const float* b[4] = {P[lq(level, Q_BI)], P[lq(level, Q_BOG)], P[lq(level, Q_BU)], P[lq(level, Q_BF)]};
-        for (int k = 0; k < 4; ++k)
-            CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, W[k], I + H, L.X + k * slot, Hp, Hp, b[k], 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
+        GgpmGemmProblem gp[4];
+        for (int k = 0; k < 4; ++k) gp[k] = {x, ldx, W[k], I + H, L.X + k * slot, Hp, Hp, b[k], 0, GGPM_ACT_NONE, 0};
+        CK(ggpm_gemm_grouped(0, 1, E1, H, I, 4, gp, s));      // the four input projections in one launch
         const size_t dsl = (size_t)depth * slot;
         CK(ggpm_lstm_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H,
                              W[2] + I, I + H, W[3] + I, I + H, pred.rowptr, pred.col, L.Hs, L.Cs, L.Qs, L.St, L.St + dsl,
@@ -176,10 +178,10 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
         return GGPM_OK;
     }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
-    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wz, I + H, L.X, Hp, Hp, P[lp(level, L_BZ)], 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
-    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wr, I, L.X + slot, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, s));
-    CK(ggpm_gemm(0, 1, E1, H, I, x, ldx, Wh, I + H, L.X + 2 * slot, Hp, Hp, P[lp(level, L_BH)], 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, s));
+    const GgpmGemmProblem gp[3] = {{x, ldx, Wz, I + H, L.X, Hp, Hp, P[lp(level, L_BZ)], 0, GGPM_ACT_NONE, 0},
+                                   {x, ldx, Wr, I, L.X + slot, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0},
+                                   {x, ldx, Wh, I + H, L.X + 2 * slot, Hp, Hp, P[lp(level, L_BH)], 0, GGPM_ACT_NONE, 0}};
+    CK(ggpm_gemm_grouped(0, 1, E1, H, I, 3, gp, s));          // the three input projections in one launch
     const size_t ds = (size_t)depth * slot;
     CK(ggpm_gru_forward_tab(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
                             P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, use_tables() ? pred.tab : nullptr,
@@ -350,6 +352,21 @@ struct Streams {
     ggpm_stream_t w() const { return side ? side : main; }      // where weight gradients go
 };
 
+// d(x1), d(x2) of y = act(x1 W1^T + x2 W2^T + b) from dpre: two products with the same left operand, one launch when
+// the halves have the same width
+int linear2_dx(int M, int H, int K1, const float* dpre, int ldp, const float* W, float* d1, int ld1, int acc1, float* d2,
+               int ld2, int acc2, ggpm_stream_t s) {
+    const int ldw = K1 + H;
+    if (K1 == H) {
+        const GgpmGemmProblem gp[2] = {{dpre, ldp, W, ldw, d1, ld1, ld1, nullptr, acc1, GGPM_ACT_NONE, 0},
+                                       {dpre, ldp, W + K1, ldw, d2, ld2, ld2, nullptr, acc2, GGPM_ACT_NONE, 0}};
+        return ggpm_gemm_grouped(0, 0, M, H, H, 2, gp, s);
+    }
+    CK(ggpm_gemm(0, 0, M, K1, H, dpre, ldp, W, ldw, d1, ld1, ld1, nullptr, acc1, GGPM_ACT_NONE, 0, nullptr, 0, s));
+    CK(ggpm_gemm(0, 0, M, H, H, dpre, ldp, W + K1, ldw, d2, ld2, ld2, nullptr, acc2, GGPM_ACT_NONE, 0, nullptr, 0, s));
+    return GGPM_OK;
+}
+
 // weight / bias gradients of y = act(x1 W1^T + x2 W2^T + b): dW[:, :K1] = dpre^T x1, dW[:, K1:] = dpre^T x2, db = colsum
 int linear2_wgrad(int M, int N, const float* dpre, int ldp, const float* x1, int ld1, int K1, const float* x2, int ld2,
                   int K2, float* dW, float* db, BwdWork& w, Streams& st) {
@@ -377,18 +394,24 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                               L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dX + 3 * slot,
                               dW[0] + I, I + H, dW[1] + I, I + H, dW[2] + I, I + H, dW[3] + I, I + H, level_work,
                               w.level_work_bytes, 0, st.main));
-        if (dx)
-            for (int k = 0; k < 4; ++k)
-                CK(ggpm_gemm(0, 0, E1, I, H, dX + k * slot, Hp, W[k], I + H, dx, lddx, k == 0 ? lddx : I, nullptr, k > 0,
-                             GGPM_ACT_NONE, 0, nullptr, 0, st.main));
+        if (dx) {       // dx = sum over the gates of dX_k W_k[:, :I]: one launch over four K segments
+            const float* A[4] = {dX, dX + slot, dX + 2 * slot, dX + 3 * slot};
+            const int lda[4] = {Hp, Hp, Hp, Hp}, ldb[4] = {I + H, I + H, I + H, I + H}, K[4] = {H, H, H, H};
+            CK(ggpm_gemm_ksegments(0, E1, I, 4, A, lda, W, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
+        }
         CK(st.side_after_main());
         CK(ggpm_lstm_weight_grads(E1, H, depth, L.Hs, L.St, level_work, w.level_work_bytes, dW[0] + I, I + H, dW[1] + I,
                                   I + H, dW[2] + I, I + H, dW[3] + I, I + H, st.w()));
-        for (int k = 0; k < 4; ++k) {
-            CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
-                         w.skws_bytes, st.w()));
-            CK(ggpm_colsum(dX + k * slot, Hp, E1, H, db[k], w.csws, st.w()));
+        if (ggpm_gemm_workspace_bytes(H, I, E1) == 0) {      // no split-K for this shape: the four in one launch
+            GgpmGemmProblem gp[4];
+            for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
+            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, st.w()));
+        } else {
+            for (int k = 0; k < 4; ++k)
+                CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
+                             w.skws_bytes, st.w()));
         }
+        for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, db[k], w.csws, st.w()));
         return GGPM_OK;
     }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
@@ -431,20 +454,28 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                                  w.level_work_bytes, 0, st.main));
     }
     if (dx) {       // needed upstream right away: main stream
-        CK(ggpm_gemm(0, 0, E1, I, H, dX, Hp, Wz, I + H, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, nullptr, 0, st.main));
-        CK(ggpm_gemm(0, 0, E1, I, H, dX + slot, Hp, Wr, I, dx, lddx, I, nullptr, 1, GGPM_ACT_NONE, 0, nullptr, 0, st.main));
-        CK(ggpm_gemm(0, 0, E1, I, H, dX + 2 * slot, Hp, Wh, I + H, dx, lddx, I, nullptr, 1, GGPM_ACT_NONE, 0, nullptr, 0,
-                     st.main));
+        // dx = dX_z W_z[:, :I] + dX_r W_r + dX_h W_h[:, :I]: one launch over three K segments
+        const float* A[3] = {dX, dX + slot, dX + 2 * slot};
+        const float* B[3] = {Wz, Wr, Wh};
+        const int lda[3] = {Hp, Hp, Hp}, ldb[3] = {I + H, I, I + H}, K[3] = {H, H, H};
+        CK(ggpm_gemm_ksegments(0, E1, I, 3, A, lda, B, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
     }
     CK(st.side_after_main());
     if (!overlap)
         CK(ggpm_gru_weight_grads(E1, H, depth, L.Hs, L.St, L.St + ds, level_work, w.level_work_bytes, dWz + I, I + H, dUr,
                                  H, G[lp(level, L_BU)], dWh + I, I + H, st.w()));
-    CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
-    CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
-                 st.w()));
-    CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
-                 w.skws_bytes, st.w()));
+    if (ggpm_gemm_workspace_bytes(H, I, E1) == 0) {      // no split-K for this shape: the three in one launch
+        const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                       {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                       {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
+        CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, st.w()));
+    } else {
+        CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
+        CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
+                     st.w()));
+        CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
+                     w.skws_bytes, st.w()));
+    }
     CK(ggpm_colsum(dX, Hp, E1, H, G[lp(level, L_BZ)], w.csws, st.w()));
     CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, G[lp(level, L_BH)], w.csws, st.w()));
     return GGPM_OK;
@@ -507,10 +538,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     // ---- root readout
     if (d_hroot) {
         CK(ggpm_act_backward(d_hroot, hroot, d.B, H, Hp, GGPM_ACT_TANH, 0, w.dpre_root, stream));
-        CK(ggpm_gemm(0, 0, d.B, H, H, w.dpre_root, Hp, P[P_WROOT], 2 * H, w.df, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0, nullptr,
-                     0, stream));
-        CK(ggpm_gemm(0, 0, d.B, H, H, w.dpre_root, Hp, P[P_WROOT] + H, 2 * H, w.dn, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
-                     nullptr, 0, stream));
+        CK(linear2_dx(d.B, H, H, w.dpre_root, Hp, P[P_WROOT], w.df, Hp, 0, w.dn, Hp, 0, stream));
         CK(ggpm_segment_sum(w.df, Hp, S.root.rowptrT, S.root.colT, d.N1t, H, w.d_hnode_t, Hp, 0, Hp, stream));
         CK(ggpm_segment_sum(w.dn, Hp, S.root.rowptrT, S.root.colT, d.N1t, H, w.d_nei_t, Hp, 0, Hp, stream));
         CK(linear2_wgrad(d.B, H, w.dpre_root, Hp, S.f, Hp, H, S.n, Hp, H, G[P_WROOT], G[P_BROOT], w, st));
@@ -524,10 +552,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     // ---- motif level: W_o, message function, W_c / E_c
     if (d_hnode) {
         CK(ggpm_act_backward(d_hnode, hnode, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[0], stream));
-        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)], 2 * H, w.d_hnode_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE, 0,
-                     nullptr, 0, stream));
-        CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)] + H, 2 * H, w.d_nei_t, Hp, Hp, nullptr, 1, GGPM_ACT_NONE,
-                     0, nullptr, 0, stream));
+        CK(linear2_dx(d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)], w.d_hnode_t, Hp, 1, w.d_nei_t, Hp, 1, stream));
         CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lwo(d.lstm, 0)], G[lbo(d.lstm, 0)], w, st));
     } else {
         (void)hipMemsetAsync(G[lwo(d.lstm, 0)], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
@@ -538,20 +563,14 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                       w.dx_mess, d.ld_t, w, st));
     CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_t, Hp, 1, 0, stream));
     CK(ggpm_act_backward(w.d_hnode_t, S.hnode_t, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[1], stream));
-    CK(ggpm_gemm(0, 0, d.N1t, He, H, dpre[1], Hp, P[P_WC], He + H, w.d_finput, d.Hep, d.Hep, nullptr, 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, stream));
     if (d_hinter) (void)hipMemcpyAsync(w.d_hinter, d_hinter, nt, hipMemcpyDeviceToDevice, s);
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[1], Hp, P[P_WC] + He, He + H, w.d_hinter, Hp, Hp, nullptr, d_hinter ? 1 : 0,
-                 GGPM_ACT_NONE, 0, nullptr, 0, stream));
+    CK(linear2_dx(d.N1t, H, He, dpre[1], Hp, P[P_WC], w.d_finput, d.Hep, 0, w.d_hinter, Hp, d_hinter ? 1 : 0, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[1], Hp, S.finput_t, d.Hep, He, hinter, Hp, H, G[P_WC], G[P_BC], w, st));
     CK(ggpm_segment_sum(w.d_finput, d.Hep, S.motif.rowptrT, S.motif.colT, d.n_motif, He, G[P_EC], He, 0, He, st.w()));
 
     // ---- attachment level: W_o, message function, W_i / E_i, pooling over atoms
     CK(ggpm_act_backward(w.d_hinter, hinter, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[2], stream));
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)], 2 * H, w.d_hnode_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, stream));
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)] + H, 2 * H, w.d_nei_i, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, stream));
+    CK(linear2_dx(d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)], w.d_hnode_i, Hp, 0, w.d_nei_i, Hp, 0, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[2], Hp, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, G[lwo(d.lstm, 1)], G[lbo(d.lstm, 1)], w, st));
     CK(ggpm_segment_sum(w.d_nei_i, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, G, 1, S.tpred, S.lv[1], w.d_h, dXl[1], lwork[1],
@@ -559,10 +578,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_i, Hp, 1, 0, stream));
     CK(ggpm_act_backward(w.d_hnode_i, S.hnode_i, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[3], stream));
     float* d_finput_i = w.d_finput + (size_t)d.N1t * d.Hep;
-    CK(ggpm_gemm(0, 0, d.N1t, He, H, dpre[3], Hp, P[P_WI], He + H, d_finput_i, d.Hep, d.Hep, nullptr, 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, stream));
-    CK(ggpm_gemm(0, 0, d.N1t, H, H, dpre[3], Hp, P[P_WI] + He, He + H, w.d_pooled, Hp, Hp, nullptr, 0, GGPM_ACT_NONE, 0,
-                 nullptr, 0, stream));
+    CK(linear2_dx(d.N1t, H, He, dpre[3], Hp, P[P_WI], d_finput_i, d.Hep, 0, w.d_pooled, Hp, 0, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[3], Hp, S.finput_i, d.Hep, He, S.pooled, Hp, H, G[P_WI], G[P_BI], w, st));
     CK(ggpm_segment_sum(d_finput_i, d.Hep, S.attach.rowptrT, S.attach.colT, d.n_attach, He, G[P_EI], He, 0, He, st.w()));
     if (d_hatom) (void)hipMemcpyAsync(w.d_hatom, d_hatom, ng, hipMemcpyDeviceToDevice, s);

@@ -33,6 +33,16 @@ struct GemmArgs {
     int k_chunk;             // K range per blockIdx.z (multiple of BK); == K when not split
     float* ws;               // split-K slabs [gridDim.z][M][N] or nullptr
     unsigned long long* dbg; // dev (GGPM_GEMM_DEBUG): loop stamps of workgroup 0
+    // K segments (gemm_kernel_v2 only): C = sum_s A_s B_s with operand bases / leading dimensions / lengths per
+    // segment, e.g. the three gate slabs of dX against the three gate weights.  nseg == 0: the single (A, B, K) above.
+    int nseg;
+    const float* segA[GGPM_GEMM_MAX_GROUP];
+    const float* segB[GGPM_GEMM_MAX_GROUP];
+    int seg_lda[GGPM_GEMM_MAX_GROUP], seg_ldb[GGPM_GEMM_MAX_GROUP], segK[GGPM_GEMM_MAX_GROUP];
+};
+
+struct GemmGroupArgs {       // independent problems of one shape in one launch (blockIdx.z picks the problem)
+    GemmArgs p[GGPM_GEMM_MAX_GROUP];
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -174,8 +184,11 @@ struct OperandStage {
 
     // P: operand base, R rows/columns of the output dimension starting at r0, k range [kbeg, kend)
     __device__ __forceinline__ void init(const float* P, int ld, int r0, int R, int kbeg, int kend, int total_rows) {
-        // CONTIG_K: element (r, k) at P[r*ld + k]: descriptor covers all rows; else (k, r) at P[k*ld + r]: ends at kend
-        const size_t bytes = CONTIG_K ? (size_t)total_rows * ld * 4 : (size_t)kend * ld * 4;
+        // The descriptor ends EXACTLY behind the last element this operand owns (element (r, k) sits at P[r*ld + k] if
+        // CONTIG_K, at P[k*ld + r] otherwise): P may point into the middle of a wider matrix whose allocation ends
+        // less than a row behind that element, and everything past the end must read as zero, not as memory.
+        const size_t last = CONTIG_K ? (size_t)(total_rows - 1) * ld + kend : (size_t)(max(kend, 1) - 1) * ld + R;
+        const size_t bytes = kend > 0 ? last * 4 : 0;
         rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (unsigned)bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -213,15 +226,8 @@ struct OperandStage {
 };
 
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float Ls[2][2][BK2 * LDT];      // [buffer][A | B][k][column]
-    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
-    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);        // XCD-contiguous tiles (see gemm_tn_tall)
-    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+__device__ __forceinline__ void gemm_v2_tile(const GemmArgs& g, int bx, int by, int bz, float (&Ls)[2][2][BK2 * LDT]) {
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -231,8 +237,6 @@ __global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
 
     OperandStage<!TA> sa;
     OperandStage<TB> sb;
-    sa.init(g.A, g.lda, m0, g.M, kbeg, kend, TA ? g.K : g.M);
-    sb.init(g.B, g.ldb, n0, g.N, kbeg, kend, TB ? g.N : g.K);
 
     const int fA = (lane >> 5) * LDT + wm * 32 + (lane & 31), fB = (lane >> 5) * LDT + wn * 32 + (lane & 31);
     f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
@@ -266,22 +270,32 @@ __global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
     };
 
     if (n0 < g.N) {
+        const int nseg = g.nseg ? g.nseg : 1;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const float* A = g.nseg ? g.segA[sg] : g.A;
+            const float* B = g.nseg ? g.segB[sg] : g.B;
+            const int lda = g.nseg ? g.seg_lda[sg] : g.lda, ldb = g.nseg ? g.seg_ldb[sg] : g.ldb, K = g.nseg ? g.segK[sg] : g.K;
+            const int kbeg = g.nseg ? 0 : bz * g.k_chunk, kend = g.nseg ? K : min(K, kbeg + g.k_chunk);
+            sa.init(A, lda, m0, g.M, kbeg, kend, TA ? K : g.M);
+            sb.init(B, ldb, n0, g.N, kbeg, kend, TB ? g.N : K);
+            if (sg) ggpm_lds_barrier();     // the previous segment's last fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sa.load(ra0[i], i); sb.load(rb0[i], i); }
+            for (int i = 0; i < 4; ++i) { sa.load(ra0[i], i); sb.load(rb0[i], i); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sa.store(Ls[0][0], ra0[i], i, kend - kbeg);
-            sb.store(Ls[0][1], rb0[i], i, kend - kbeg);
-        }
+            for (int i = 0; i < 4; ++i) {
+                sa.store(Ls[0][0], ra0[i], i, kend - kbeg);
+                sb.store(Ls[0][1], rb0[i], i, kend - kbeg);
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sa.load(ra1[i], i); sb.load(rb1[i], i); }
-        ggpm_lds_barrier();
-        frag(0, 0, 0);
-        // Whole steps in pairs (the register sets swap roles); loads past the end return zeros without touching
-        // memory, so at most one step of the pair multiplies zeros.
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK2) {
-            step(ra1, rb1, ra0, rb0, 0, kend - k0 - BK2);
-            step(ra0, rb0, ra1, rb1, 1, kend - k0 - 2 * BK2);
+            for (int i = 0; i < 4; ++i) { sa.load(ra1[i], i); sb.load(rb1[i], i); }
+            ggpm_lds_barrier();
+            frag(0, 0, 0);
+            // Whole steps in pairs (the register sets swap roles); loads past the end return zeros without touching
+            // memory, so at most one step of the pair multiplies zeros.
+            for (int k0 = kbeg; k0 < kend; k0 += 2 * BK2) {
+                step(ra1, rb1, ra0, rb0, 0, kend - k0 - BK2);
+                step(ra0, rb0, ra1, rb1, 1, kend - k0 - 2 * BK2);
+            }
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulator is read
     }
@@ -307,6 +321,33 @@ __global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
             g.C[(size_t)m * g.ldc + n] = 0.f;
         }
     }
+}
+
+// XCD-contiguous renumbering of the launch's workgroups (see gemm_tn_tall): (x fastest, then y, then z)
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);
+    bx = logical % gridDim.x;
+    by = (logical / gridDim.x) % gridDim.y;
+    bz = logical / (gridDim.x * gridDim.y);
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_kernel_v2(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][2][BK2 * LDT];      // [buffer][A | B][k][column]
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_v2_tile<TA, TB>(g, bx, by, bz, Ls);
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_group_v2(GemmGroupArgs gg) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][2][BK2 * LDT];
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_v2_tile<TA, TB>(gg.p[bz], bx, by, 0, Ls);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -336,7 +377,7 @@ __global__ void __launch_bounds__(256) gemm_tn_tall(GemmArgs g) {
     const float* P = isb ? g.B : g.A;
     const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0,
-                                                                        (unsigned)((size_t)kend * ld * 4), 0x00020000);
+                                                                        (unsigned)(((size_t)(kend - 1) * ld + climit) * 4), 0x00020000);
     unsigned voff[5];
     int loff[5];
 #pragma unroll
@@ -605,7 +646,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     GGPM_CLEAR_STALE_ERROR();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || n_pad < N || n_pad > ldc) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    GemmArgs g;
+    GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.n_pad = n_pad; g.bias = bias; g.accumulate = accumulate; g.act = act; g.zero_row0 = zero_row0;
     g.vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
@@ -671,6 +712,89 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
         dim3 rg(ggpm_ceil_div(n_pad, 256), M);
         splitk_reduce<<<rg, 256, 0, s>>>(g, splits);
     }
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+namespace {
+inline bool v2_operands_ok(const float* A, int lda, size_t rows_a, const float* B, int ldb, size_t rows_b) {
+    static const int use_v2 = [] { const char* e = getenv("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
+    return use_v2 && (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+           rows_a * lda * 4 < 0xffffff00ull && rows_b * ldb * 4 < 0xffffff00ull;
+}
+inline void fill_args(GemmArgs& g, int M, int N, int K, const GgpmGemmProblem& p) {
+    g = GemmArgs{};
+    g.M = M; g.N = N; g.K = K; g.A = p.A; g.lda = p.lda; g.B = p.B; g.ldb = p.ldb; g.C = p.C; g.ldc = p.ldc;
+    g.n_pad = p.n_pad; g.bias = p.bias; g.accumulate = p.accumulate; g.act = p.act; g.zero_row0 = p.zero_row0;
+    g.vecA = g.vecB = 1;
+    g.k_chunk = ggpm_round_up(K, BK);
+}
+}  // namespace
+
+int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const GgpmGemmProblem* p,
+                      ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || M <= 0 || N <= 0 || K <= 0) return GGPM_ERR_ARG;
+    bool ok = count > 1;
+    int n_pad_max = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!p[i].A || !p[i].B || !p[i].C || p[i].n_pad < N || p[i].n_pad > p[i].ldc) return GGPM_ERR_ARG;
+        ok = ok && v2_operands_ok(p[i].A, p[i].lda, trans_a ? K : M, p[i].B, p[i].ldb, trans_b ? N : K);
+        n_pad_max = max(n_pad_max, p[i].n_pad);
+    }
+    if (!ok) {
+        for (int i = 0; i < count; ++i) {
+            const int rc = ggpm_gemm(trans_a, trans_b, M, N, K, p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc,
+                                     p[i].n_pad, p[i].bias, p[i].accumulate, p[i].act, p[i].zero_row0, nullptr, 0, stream);
+            if (rc) return rc;
+        }
+        return GGPM_OK;
+    }
+    GemmGroupArgs gg;
+    for (int i = 0; i < count; ++i) fill_args(gg.p[i], M, N, K, p[i]);
+    for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ggpm_ceil_div(n_pad_max, BN), ggpm_ceil_div(M, BM), count);
+    if (!trans_a && !trans_b) gemm_group_v2<false, false><<<grid, 256, 0, s>>>(gg);
+    else if (!trans_a && trans_b) gemm_group_v2<false, true><<<grid, 256, 0, s>>>(gg);
+    else if (trans_a && !trans_b) gemm_group_v2<true, false><<<grid, 256, 0, s>>>(gg);
+    else gemm_group_v2<true, true><<<grid, 256, 0, s>>>(gg);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda, const float* const* B,
+                        const int* ldb, const int* K, float* C, int ldc, int n_pad, const float* bias, int accumulate,
+                        int act, int zero_row0, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (nseg <= 0 || nseg > GGPM_GEMM_MAX_GROUP || !A || !lda || !B || !ldb || !K || !C || M <= 0 || N <= 0 || n_pad < N ||
+        n_pad > ldc)
+        return GGPM_ERR_ARG;
+    bool ok = nseg > 1;
+    for (int i = 0; i < nseg; ++i) {
+        if (!A[i] || !B[i] || K[i] <= 0) return GGPM_ERR_ARG;
+        ok = ok && v2_operands_ok(A[i], lda[i], M, B[i], ldb[i], trans_b ? N : K[i]);
+    }
+    if (!ok) {      // bias with the first product, activation / row mask with the last
+        for (int i = 0; i < nseg; ++i) {
+            const bool last = i == nseg - 1;
+            const int rc = ggpm_gemm(0, trans_b, M, N, K[i], A[i], lda[i], B[i], ldb[i], C, ldc, i == 0 ? n_pad : N,
+                                     i == 0 ? bias : nullptr, i == 0 ? accumulate : 1, last ? act : GGPM_ACT_NONE,
+                                     last ? zero_row0 : 0, nullptr, 0, stream);
+            if (rc) return rc;
+        }
+        return GGPM_OK;
+    }
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K[0]; g.A = A[0]; g.lda = lda[0]; g.B = B[0]; g.ldb = ldb[0]; g.C = C; g.ldc = ldc; g.n_pad = n_pad;
+    g.bias = bias; g.accumulate = accumulate; g.act = act; g.zero_row0 = zero_row0; g.vecA = g.vecB = 1;
+    g.k_chunk = ggpm_round_up(K[0], BK);
+    g.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) { g.segA[i] = A[i]; g.segB[i] = B[i]; g.seg_lda[i] = lda[i]; g.seg_ldb[i] = ldb[i]; g.segK[i] = K[i]; }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ggpm_ceil_div(n_pad, BN), ggpm_ceil_div(M, BM), 1);
+    if (trans_b) gemm_kernel_v2<false, true><<<grid, 256, 0, s>>>(g);
+    else gemm_kernel_v2<false, false><<<grid, 256, 0, s>>>(g);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

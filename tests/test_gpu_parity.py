@@ -440,7 +440,7 @@ def test_persistent_depth_loop_matches_stepwise_kernels(rnn, H, depth, motifs, B
 @pytest.mark.parametrize("which", ["all", "root_only", "atom_only", "node_inter"])
 def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
     """ggpm_encoder_forward/backward (one C call per direction) against the op-by-op host composition of the same
-    kernels: identical outputs, and identical gradients for every subset of outputs that receives a gradient
+    kernels: the same outputs and gradients (to fp32 summation order) for every subset of outputs that receives a gradient
     (absent output gradients take the null-pointer branches of the backward driver)."""
     g = Golden(name)
     res = []
@@ -462,7 +462,10 @@ def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
         res.append(([o.detach().clone() for o in outs],
                     {k: (v.grad.clone() if v.grad is not None else None) for k, v in model.named_parameters()}))
     for a, b in zip(res[0][0], res[1][0]):
-        assert torch.equal(a, b)                     # same kernels, same order: bit-identical forward
+        # same kernels except that the driver sums the two halves of a readout (and the gate slabs of dx) inside one
+        # GEMM launch where the op-by-op path accumulates launch by launch: fp32 rounding of the running sum differs
+        scale = max(float(a.abs().max()), 1e-12)
+        assert float((a - b).abs().max()) <= 5e-5 * scale        # (1e-5 observed at hidden 300, depth 20)
     for k in res[0][1]:
         ga, gb = res[0][1][k], res[1][1][k]
         if ga is None or gb is None:                 # the fused node always returns a (zero) gradient
