@@ -26,6 +26,8 @@ SIGNATURES = {
     "ggpm_extract_column": (I, [P, I, I, I, P, P]),
     "ggpm_gemm_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, I, P, I, I, I, P, c_size_t, P]),
+    "ggpm_gemm_grouped": (I, [I, I, I, I, I, I, P, P]),                   # problems: ggpm_gemm_problem[count]
+    "ggpm_gemm_ksegments": (I, [I, I, I, I, P, P, P, P, P, P, I, I, P, I, I, I, P]),
     "ggpm_colsum": (I, [P, I, I, I, P, P, P]),
     "ggpm_act_backward": (I, [P, P, I, I, I, I, I, P, P]),
     "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, I, P]),

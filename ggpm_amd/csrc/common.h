@@ -53,25 +53,8 @@ __device__ __forceinline__ void ggpm_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Library-internal GEMM forms (gemm.hip) used by the whole-encoder drivers; each falls back to a sequence of
-// ggpm_gemm calls when the operands do not allow the pipelined kernel, so results never depend on which path ran
-// beyond fp32 summation order.
-#define GGPM_GEMM_MAX_GROUP 4
-struct GgpmGemmProblem {      // one member of a group: C = act(A' B' + bias (+ C))
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc; int n_pad;
-    const float* bias;
-    int accumulate, act, zero_row0;
-};
-// `count` (<= 4) independent products of the same shape and transposes in ONE launch
-int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const GgpmGemmProblem* p,
-                      ggpm_stream_t stream);
-// C = act(sum_s A_s B_s' + bias (+ C)) over `nseg` (<= 4) K segments in one launch: A_s [M x K_s] (row-major),
-// B_s [K_s x N] (trans_b = 0) or [N x K_s] (trans_b = 1), each with its own leading dimension
-int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda, const float* const* B,
-                        const int* ldb, const int* K, float* C, int ldc, int n_pad, const float* bias, int accumulate,
-                        int act, int zero_row0, ggpm_stream_t stream);
+#define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
+typedef ggpm_gemm_problem GgpmGemmProblem;
 
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
 void ggpm_timing_begin(int which, hipStream_t s, double flops);

@@ -731,8 +731,8 @@ inline void fill_args(GemmArgs& g, int M, int N, int K, const GgpmGemmProblem& p
 }
 }  // namespace
 
-int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const GgpmGemmProblem* p,
-                      ggpm_stream_t stream) {
+extern "C" int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* p,
+                                 ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || M <= 0 || N <= 0 || K <= 0) return GGPM_ERR_ARG;
     bool ok = count > 1;
@@ -763,7 +763,7 @@ int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, 
     return GGPM_OK;
 }
 
-int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda, const float* const* B,
+extern "C" int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda, const float* const* B,
                         const int* ldb, const int* K, float* C, int ldc, int n_pad, const float* bias, int accumulate,
                         int act, int zero_row0, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();

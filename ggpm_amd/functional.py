@@ -162,6 +162,39 @@ def gemm(ta: int, tb: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B:
                              int(accumulate), act, int(zero_row0), _p(ws), wsb, _stream()), "gemm")
 
 
+class GemmProblem(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_gemm_problem"""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int),
+                ("C", ctypes.c_void_p), ("ldc", ctypes.c_int), ("n_pad", ctypes.c_int), ("bias", ctypes.c_void_p),
+                ("accumulate", ctypes.c_int), ("act", ctypes.c_int), ("zero_row0", ctypes.c_int)]
+
+
+def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems) -> None:
+    """problems: list of dicts(A, lda, B, ldb, C, ldc, n_pad, bias=None, accumulate=False, act=ACT_NONE, zero_row0=False);
+    up to four independent products of one shape in one launch."""
+    arr = (GemmProblem * len(problems))()
+    for i, q in enumerate(problems):
+        arr[i] = GemmProblem(_p(q["A"]), q["lda"], _p(q["B"]), q["ldb"], _p(q["C"]), q["ldc"], q["n_pad"],
+                             _p(q.get("bias")), int(q.get("accumulate", False)), q.get("act", ACT_NONE),
+                             int(q.get("zero_row0", False)))
+    _lib.check(_lib.load().ggpm_gemm_grouped(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p),
+                                             _stream()), "gemm_grouped")
+
+
+def gemm_ksegments(tb: int, M: int, N: int, As, ldas, Bs, ldbs, Ks, C: torch.Tensor, ldc: int, n_pad: int,
+                   bias: Optional[torch.Tensor] = None, accumulate: bool = False, act: int = ACT_NONE,
+                   zero_row0: bool = False) -> None:
+    """C = act(sum_s A_s B_s' + bias (+ C)) in one launch (up to four K segments)."""
+    n = len(As)
+    pa = (ctypes.c_void_p * n)(*[_p(a) for a in As])
+    pb = (ctypes.c_void_p * n)(*[_p(b) for b in Bs])
+    la, lb, kk = (ctypes.c_int * n)(*ldas), (ctypes.c_int * n)(*ldbs), (ctypes.c_int * n)(*Ks)
+    cast = lambda x: ctypes.cast(x, ctypes.c_void_p)
+    _lib.check(_lib.load().ggpm_gemm_ksegments(tb, M, N, n, cast(pa), cast(la), cast(pb), cast(lb), cast(kk), _p(C), ldc,
+                                               n_pad, _p(bias), int(accumulate), act, int(zero_row0), _stream()),
+               "gemm_ksegments")
+
+
 def colsum(A: torch.Tensor, M: int, N: int) -> torch.Tensor:
     out = torch.empty(N, dtype=torch.float32, device=A.device)
     ws = torch.empty(256 * N, dtype=torch.float32, device=A.device)

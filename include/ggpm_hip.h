@@ -81,6 +81,28 @@ size_t ggpm_gemm_workspace_bytes(int M, int N, int K);
 int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
               int ldb, float* C, int ldc, int n_pad, const float* bias, int accumulate, int act,
               int zero_row0, float* splitk_ws, size_t splitk_ws_bytes, ggpm_stream_t stream);
+/* Several products in ONE launch (the motif / attachment levels have a few hundred rows, so one product fills a
+ * fraction of the chip and is bound by launch latency):
+ *   ggpm_gemm_grouped   -- `count` (<= 4) independent products of the same (M, N, K, transposes), e.g. the gate input
+ *                          projections x W_z^T, x W_r^T, x W_h^T of GRU.forward (ggpm/rnn.py:25-39; LSTM: rnn.py:85-94);
+ *   ggpm_gemm_ksegments -- C = act(sum_s A_s B_s' + bias (+ C)) over `nseg` (<= 4) K segments in one accumulator chain:
+ *                          A_s is [M x K_s] row-major, B_s is [K_s x N] (trans_b = 0) or [N x K_s] (trans_b = 1), each
+ *                          with its own leading dimension -- nn.Linear over a torch.cat of inputs without the cat
+ *                          (ggpm/encoder.py:31-35,62-82), and its input gradient summed over the gate slabs.
+ * Both fall back to a sequence of ggpm_gemm calls when an operand does not allow 16-byte loads.
+ */
+typedef struct ggpm_gemm_problem {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc; int n_pad;
+    const float* bias;
+    int accumulate, act, zero_row0;
+} ggpm_gemm_problem;
+int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* problems,
+                      ggpm_stream_t stream);
+int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda,
+                        const float* const* B, const int* ldb, const int* K, float* C, int ldc, int n_pad,
+                        const float* bias, int accumulate, int act, int zero_row0, ggpm_stream_t stream);
 /* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 256*N floats. */
 int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream);
 /* dpre = dy * act'(y) given the activation OUTPUT y; optional row-0 zeroing. In-place allowed. */

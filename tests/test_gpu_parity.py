@@ -78,6 +78,68 @@ def test_gemm_against_fp64(ta, tb, M, N, K):
     assert rel_err(C.cpu().numpy()[:, :N], ref2) < tol
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K,count,aligned", [(0, 1, 573, 300, 600, 3, True), (0, 1, 45, 16, 30, 4, True),
+                                                      (1, 0, 300, 340, 573, 3, True), (0, 0, 130, 300, 300, 2, True),
+                                                      (0, 1, 77, 50, 41, 3, False)])
+def test_gemm_grouped_against_fp64(ta, tb, M, N, K, count, aligned):
+    """Up to four products of one shape in one launch; per-problem bias / accumulate / leading dimensions; the
+    unaligned case takes the sequential fallback."""
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(M + 3 * N + 7 * K + count)
+    probs, refs = [], []
+    for i in range(count):
+        pad = 4 * (i + 1) if aligned else 1 + 2 * i
+        lda = (M if ta else K) + (pad if aligned else pad)
+        ldb = (K if tb else N) + pad
+        if aligned:
+            lda, ldb = (lda + 3) // 4 * 4, (ldb + 3) // 4 * 4
+        A = rs.standard_normal((K if ta else M, lda)).astype(np.float32)
+        B = rs.standard_normal((N if tb else K, ldb)).astype(np.float32)
+        ldc = (N + 15) // 16 * 16 + 4 * i
+        C0 = rs.standard_normal((M, ldc)).astype(np.float32)
+        bias = rs.standard_normal(N).astype(np.float32) if i % 2 == 0 else None
+        acc = i == 1
+        Am = (A[:, :M].T if ta else A[:, :K]).astype(np.float64)
+        Bm = (B[:, :K].T if tb else B[:, :N]).astype(np.float64)
+        ref = Am @ Bm + (bias if bias is not None else 0) + (C0[:, :N] if acc else 0)
+        refs.append(ref)
+        probs.append(dict(A=torch.from_numpy(A).to(_dev()), lda=lda, B=torch.from_numpy(B).to(_dev()), ldb=ldb,
+                          C=torch.from_numpy(C0).to(_dev()), ldc=ldc, n_pad=N,
+                          bias=None if bias is None else torch.from_numpy(bias).to(_dev()), accumulate=acc))
+    F_.gemm_grouped(ta, tb, M, N, K, probs)
+    for q, ref in zip(probs, refs):
+        assert rel_err(q["C"].cpu().numpy()[:, :N], ref) < 3e-6
+
+
+@pytest.mark.parametrize("tb,M,N,Ks,aligned", [(1, 573, 300, (300, 300), True), (0, 573, 340, (300, 300, 300), True),
+                                               (0, 100, 48, (16, 16, 16, 16), True), (1, 70, 33, (41, 300), True),
+                                               (1, 64, 64, (30, 50), False)])
+def test_gemm_ksegments_against_fp64(tb, M, N, Ks, aligned):
+    """C = relu(sum_s A_s B_s' + bias), row 0 masked, pad columns zeroed, in one launch; ragged segment lengths."""
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(M + 5 * N + sum(Ks))
+    As, Bs, ldas, ldbs = [], [], [], []
+    ref = np.zeros((M, N))
+    for i, K in enumerate(Ks):
+        lda = (K + 3) // 4 * 4 + 4 * i if aligned else K + 1
+        ldb = ((K if tb else N) + 3) // 4 * 4 + 8 if aligned else (K if tb else N) + 3
+        A = rs.standard_normal((M, lda)).astype(np.float32)
+        B = rs.standard_normal((N if tb else K, ldb)).astype(np.float32)
+        ref += A[:, :K].astype(np.float64) @ (B[:, :K].T if tb else B[:, :N]).astype(np.float64)
+        As.append(torch.from_numpy(A).to(_dev())); Bs.append(torch.from_numpy(B).to(_dev()))
+        ldas.append(lda); ldbs.append(ldb)
+    bias = rs.standard_normal(N).astype(np.float32)
+    ldc = (N + 15) // 16 * 16 + 16
+    C = torch.full((M, ldc), 7.0, device=_dev())
+    F_.gemm_ksegments(tb, M, N, As, ldas, Bs, ldbs, list(Ks), C, ldc, ldc - 8, bias=torch.from_numpy(bias).to(_dev()),
+                      act=F_.ACT_RELU, zero_row0=True)
+    ref = np.maximum(ref + bias, 0.0)
+    ref[0] = 0
+    got = C.cpu().numpy()
+    assert rel_err(got[:, :N], ref) < 3e-6
+    assert (got[:, N:ldc - 8] == 0).all() and (got[:, ldc - 8:] == 7.0).all()
+
+
 def test_segment_sum_and_gather():
     from ggpm_amd import functional as F_
     rs = np.random.RandomState(0)
