@@ -219,14 +219,20 @@ class _Linear(torch.autograd.Function):
         M = xs[0].shape[0]
         assert sum(Ks) == weight.shape[1] and weight.stride(1) == 1
         y = torch.empty(M, ld_out, dtype=torch.float32, device=weight.device)
-        off = 0
-        last = len(xs) - 1
-        for i, (x, K) in enumerate(zip(xs, Ks)):
-            wv = weight[:, off:]
-            gemm(0, 1, M, N, K, x, _ld(x), wv, weight.stride(0), y, ld_out, ld_out,
-                 bias=bias if i == 0 else None, accumulate=i > 0, act=act if i == last else ACT_NONE,
-                 zero_row0=zero_row0 and i == last)
-            off += K
+        if 1 < len(xs) <= 4:        # the inputs are K segments of ONE product: no cat, no read-modify-write of y
+            offs = [sum(Ks[:i]) for i in range(len(Ks))]
+            gemm_ksegments(1, M, N, list(xs), [_ld(x) for x in xs], [weight[:, o:] for o in offs],
+                           [weight.stride(0)] * len(xs), list(Ks), y, ld_out, ld_out, bias=bias, act=act,
+                           zero_row0=zero_row0)
+        else:
+            off = 0
+            last = len(xs) - 1
+            for i, (x, K) in enumerate(zip(xs, Ks)):
+                wv = weight[:, off:]
+                gemm(0, 1, M, N, K, x, _ld(x), wv, weight.stride(0), y, ld_out, ld_out,
+                     bias=bias if i == 0 else None, accumulate=i > 0, act=act if i == last else ACT_NONE,
+                     zero_row0=zero_row0 and i == last)
+                off += K
         ctx.save_for_backward(weight, y, *xs)
         ctx.meta = (act, zero_row0, Ks, bias is not None)
         ctx.weight_ref, ctx.bias_ref = weight, bias       # the Parameter objects themselves (their .grad is assigned)
