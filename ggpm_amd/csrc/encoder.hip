@@ -224,36 +224,49 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     float* const* P = params;
     const int H = d.H, Hp = d.Hp, He = d.He;
 
-    // ---- graph layout
+    // ---- graph layout.  Only the atom level's two CSRs sit in front of the first depth loop; the tree-side layout (three
+    // CSRs, four index columns, iota) is built on the second stream beside the atom level and joined before the
+    // attachment level, and the transposes (read by the backward only) follow there.
+    ggpm_stream_t ts = side_stream ? side_stream : stream;
+    if (side_stream) {
+        hipEvent_t ev = ggpm_wgrad_event(60);
+        if (!ev) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev, s);                 // the caller's index tensors are ready from here on
+        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+    }
     CK(ggpm_padded_to_csr(gbgraph, d.E1g, d.Kgb, S.gpred.rowptr, S.gpred.col, stream));
     CK(ggpm_padded_to_csr(gagraph, d.N1g, d.Kga, S.gagr.rowptr, S.gagr.col, stream));
-    CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, stream));
-    CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, stream));
-    CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, stream));
-    CK(ggpm_csr_table4(S.gpred.rowptr, S.gpred.col, d.E1g, S.gpred.tab, stream));
-    CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, stream));
-    CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, stream));
-    CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, stream));
-    CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, stream));
-    CK(ggpm_extract_column(tfnode, d.N1t, 2, 1, S.attach_id, stream));
+    if (use_tables()) CK(ggpm_csr_table4(S.gpred.rowptr, S.gpred.col, d.E1g, S.gpred.tab, stream));
+    hipEvent_t ev_atom = nullptr, ev_tree = nullptr;
+    if (side_stream) {
+        ev_atom = ggpm_wgrad_event(54);
+        ev_tree = ggpm_wgrad_event(53);
+        if (!ev_atom || !ev_tree) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev_atom, s);
+    }
+    CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, ts));
+    CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, ts));
+    CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, ts));
+    if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, ts));
+    CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, ts));
+    CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, ts));
+    CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, ts));
+    CK(ggpm_extract_column(tfnode, d.N1t, 2, 1, S.attach_id, ts));
     {
         const int nio = (d.E1t > d.N1t ? d.E1t : d.N1t) + 1;
         const int n = nio > d.B + 1 ? nio : d.B + 1;
-        iota_k<<<ggpm_ceil_div(n, 256), 256, 0, s>>>(S.iota, n);
+        iota_k<<<ggpm_ceil_div(n, 256), 256, 0, (hipStream_t)ts>>>(S.iota, n);
     }
-    if (side_stream) {      // transposes are only read by the backward: build them beside the forward
-        hipEvent_t ev = ggpm_wgrad_event(60);
-        if (!ev) return GGPM_ERR_LAUNCH;
-        (void)hipEventRecord(ev, s);
-        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+    if (side_stream) {
+        (void)hipEventRecord(ev_tree, (hipStream_t)side_stream);
+        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_atom, 0);     // the atom CSRs, for their transposes
     }
     {
-        ggpm_stream_t ts = side_stream ? side_stream : stream;
         CK(transpose(S.gpred, nullptr, ts));
-        CK(ggpm_csr_table4(S.gpred.rowptrT, S.gpred.colT, d.E1g, S.gpred.tabT, ts));
+        if (use_tables()) CK(ggpm_csr_table4(S.gpred.rowptrT, S.gpred.colT, d.E1g, S.gpred.tabT, ts));
         CK(transpose(S.gagr, nullptr, ts));
         CK(transpose(S.tpred, nullptr, ts));
-        CK(ggpm_csr_table4(S.tpred.rowptrT, S.tpred.colT, d.E1t, S.tpred.tabT, ts));
+        if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptrT, S.tpred.colT, d.E1t, S.tpred.tabT, ts));
         CK(transpose(S.tagr, nullptr, ts));
         CK(transpose(S.tcgr, nullptr, ts));
         CK(transpose(S.tsrc, S.src, ts));
@@ -269,6 +282,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
                hatom, Hp, stream));
 
     // ---- attachment level (embed_inter, inter_encoder)
+    if (side_stream) (void)hipStreamWaitEvent(s, ev_tree, 0);      // tree-side layout built beside the atom level
     CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, stream));
     CK(ggpm_segment_sum(hatom, Hp, S.tcgr.rowptr, S.tcgr.col, d.N1t, H, S.pooled, Hp, 0, Hp, stream));
     CK(linear2(d.N1t, H, S.finput_i, d.Hep, He, S.pooled, Hp, H, P[P_WI], P[P_BI], GGPM_ACT_RELU, 0, S.hnode_i, Hp,
