@@ -257,6 +257,11 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
         const int n = nio > d.B + 1 ? nio : d.B + 1;
         iota_k<<<ggpm_ceil_div(n, 256), 256, 0, (hipStream_t)ts>>>(S.iota, n);
     }
+    // inputs of the two tree-side levels that do not depend on the level below: embedding rows, one-hot bond positions
+    CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, ts));
+    CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, ts));
+    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, ts));
+    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, ts));
     if (side_stream) {
         (void)hipEventRecord(ev_tree, (hipStream_t)side_stream);
         (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_atom, 0);     // the atom CSRs, for their transposes
@@ -283,21 +288,17 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
 
     // ---- attachment level (embed_inter, inter_encoder)
     if (side_stream) (void)hipStreamWaitEvent(s, ev_tree, 0);      // tree-side layout built beside the atom level
-    CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, stream));
     CK(ggpm_segment_sum(hatom, Hp, S.tcgr.rowptr, S.tcgr.col, d.N1t, H, S.pooled, Hp, 0, Hp, stream));
     CK(linear2(d.N1t, H, S.finput_i, d.Hep, He, S.pooled, Hp, H, P[P_WI], P[P_BI], GGPM_ACT_RELU, 0, S.hnode_i, Hp,
                stream));
     CK(ggpm_gather_rows(S.hnode_i, Hp, S.src, d.E1t, H, S.hmess_i, d.ld_t, 0, 0, stream));
-    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, 1, S.tpred, S.tagr, S.lv[1], stream));
     CK(linear2(d.N1t, H, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, P[lwo(d.lstm, 1)], P[lbo(d.lstm, 1)], GGPM_ACT_RELU, 1, hinter, Hp,
                stream));
 
     // ---- motif level (embed_tree, tree_encoder)
-    CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, stream));
     CK(linear2(d.N1t, H, S.finput_t, d.Hep, He, hinter, Hp, H, P[P_WC], P[P_BC], GGPM_ACT_RELU, 0, S.hnode_t, Hp, stream));
     CK(ggpm_gather_rows(S.hnode_t, Hp, S.src, d.E1t, H, S.hmess_t, d.ld_t, 0, 0, stream));
-    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, 0, S.tpred, S.tagr, S.lv[0], stream));
     CK(linear2(d.N1t, H, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, P[lwo(d.lstm, 0)], P[lbo(d.lstm, 0)], GGPM_ACT_RELU, 1, hnode, Hp,
                stream));
