@@ -44,14 +44,82 @@ class _RsampleTail(torch.autograd.Function):
         return dmean, dpv, None
 
 
+class _KLHead(torch.autograd.Function):
+    """The whole of rsample as ONE autograd node: both [B,H]x[H,latent] products in one grouped launch, the elementwise
+    tail in one launch, and on the way back one launch for d(z_vecs) (two K segments), one grouped launch for the two
+    weight gradients (second stream, straight into ``.grad`` like the level functions do)."""
+
+    @staticmethod
+    def forward(ctx, z_vecs, Wm, bm, Wv, bv, eps):
+        from . import _lib
+        B, (L, H) = z_vecs.shape[0], Wm.shape
+        dev = z_vecs.device
+        mean = torch.empty(B, L, dtype=torch.float32, device=dev)
+        pv = torch.empty(B, L, dtype=torch.float32, device=dev)
+        F_.gemm_grouped(0, 1, B, L, H, [
+            dict(A=z_vecs, lda=F_._ld(z_vecs), B=Wm, ldb=Wm.stride(0), C=mean, ldc=L, n_pad=L, bias=bm),
+            dict(A=z_vecs, lda=F_._ld(z_vecs), B=Wv, ldb=Wv.stride(0), C=pv, ldc=L, n_pad=L, bias=bv)])
+        z = torch.empty_like(mean)
+        kl = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().ggpm_rsample_forward(F_._p(mean), F_._p(pv), F_._p(eps), B, L, F_._p(z), F_._p(kl),
+                                                    F_._stream()), "rsample_forward")
+        ctx.save_for_backward(z_vecs, Wm, Wv, mean, pv)
+        ctx.eps = eps
+        ctx.params = (Wm, bm, Wv, bv)           # the Parameter objects themselves (their .grad is assigned)
+        return z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        from . import _lib
+        z_vecs, Wm, Wv, mean, pv = ctx.saved_tensors
+        B, (L, H) = z_vecs.shape[0], Wm.shape
+        dz = dz.contiguous() if dz is not None else None
+        dkl = dkl.reshape(1).contiguous() if dkl is not None else None
+        dmean, dpv = torch.empty_like(mean), torch.empty_like(pv)
+        _lib.check(_lib.load().ggpm_rsample_backward(F_._p(mean), F_._p(pv), F_._p(ctx.eps), F_._p(dz), F_._p(dkl), B, L,
+                                                     F_._p(dmean), F_._p(dpv), F_._stream()), "rsample_backward")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(z_vecs)
+            F_.gemm_ksegments(0, B, H, [dmean, dpv], [L, L], [Wm, Wv], [Wm.stride(0), Wv.stride(0)], [L, L], dx,
+                              F_._ld(dx), z_vecs.shape[1])
+
+        pWm, pbm, pWv, pbv = ctx.params
+
+        def param_grads():
+            dWm, dWv = torch.empty_like(Wm), torch.empty_like(Wv)
+            F_.gemm_grouped(1, 0, L, H, B, [
+                dict(A=dmean, lda=L, B=z_vecs, ldb=F_._ld(z_vecs), C=dWm, ldc=dWm.stride(0), n_pad=H),
+                dict(A=dpv, lda=L, B=z_vecs, ldb=F_._ld(z_vecs), C=dWv, ldc=dWv.stride(0), n_pad=H)])
+            return dWm, F_.colsum(dmean, B, L), dWv, F_.colsum(dpv, B, L)
+
+        leaf = all(getattr(q, "is_leaf", False) for q in ctx.params)
+        if F_.side_stream_enabled() and leaf and all(ctx.needs_input_grad[1:5]):
+            main = torch.cuda.current_stream()
+            side = F_._side_stream(z_vecs.device)
+            side.wait_stream(main)
+            for t in (dmean, dpv, z_vecs):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                for q, g in zip(ctx.params, param_grads()):
+                    F_._accumulate_grad(q, g, main)
+            F_._join_later(main, side)
+            return dx, None, None, None, None, None
+        dWm, dbm, dWv, dbv = param_grads()
+        return dx, dWm, dbm, dWv, dbv, None
+
+
 def rsample(z_vecs, W_mean: nn.Linear, W_var: nn.Linear, perturb: bool = True, z_width=None):
     """(z, kl) -- reference ggpm/property_vae.py:26-33. ``z_vecs`` may carry zero pad columns."""
-    H = W_mean.weight.shape[1]
-    L = W_mean.weight.shape[0]
-    z_mean = F_.linear([z_vecs], [H], W_mean.weight, W_mean.bias, ld_out=L)
-    pre_var = F_.linear([z_vecs], [H], W_var.weight, W_var.bias, ld_out=L)
-    eps = torch.randn_like(z_mean) if perturb else None        # the reference draws epsilon with torch's generator too
-    return _RsampleTail.apply(z_mean, pre_var, eps)
+    B, L = z_vecs.shape[0], W_mean.weight.shape[0]
+    # the reference draws epsilon with torch's generator too
+    eps = torch.randn(B, L, dtype=torch.float32, device=z_vecs.device) if perturb else None
+    if W_mean.bias is None or W_var.bias is None:
+        H = W_mean.weight.shape[1]
+        z_mean = F_.linear([z_vecs], [H], W_mean.weight, W_mean.bias, ld_out=L)
+        pre_var = F_.linear([z_vecs], [H], W_var.weight, W_var.bias, ld_out=L)
+        return _RsampleTail.apply(z_mean, pre_var, eps)
+    return _KLHead.apply(z_vecs, W_mean.weight, W_mean.bias, W_var.weight, W_var.bias, eps)
 
 
 class HierEncoderVAE(nn.Module):
