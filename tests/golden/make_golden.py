@@ -67,7 +67,15 @@ CASES = [
     ("cfg_gru_s1", "GRU", 300, 32, 20, 20, 4, (7, 11), 50, 150, 1, False),
     ("cfg_lstm_s0", "LSTM", 300, 32, 20, 20, 4, (7, 11), 50, 150, 0, False),
     ("cfg_lstm_s2", "LSTM", 250, 24, 20, 20, 5, (7, 11), 50, 150, 2, False),
+    # edge cases: a single molecule of a single motif at depth 1 (no tree messages at all), hidden sizes that are not
+    # multiples of 4 or 16 (unaligned GEMM operands), one larger molecule alone in its batch
+    ("edge_gru_s30", "GRU", 18, 6, 1, 1, 1, (1, 1), 11, 33, 30, True),
+    ("edge_lstm_s31", "LSTM", 21, 10, 1, 2, 2, (1, 2), 11, 33, 31, True),
+    ("edge_gru_s32", "GRU", 300, 32, 2, 3, 1, (12, 12), 50, 150, 32, False),
 ]
+ONLY = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+if ONLY:
+    CASES = [c for c in CASES if c[0] in ONLY[0]]
 MOTIF_CASES = [
     # name, rnn, H, depthT, B, motifs, n_motif, n_attach, seed
     ("motif_gru_s3", "GRU", 24, 4, 3, (2, 6), 11, 33, 3),
@@ -354,5 +362,7 @@ if __name__ == "__main__":
         main()
     else:
         import_reference()
+    if ONLY:
+        sys.exit(0)
     main_motif()
     main_sparse()
