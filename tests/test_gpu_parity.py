@@ -498,7 +498,8 @@ def test_persistent_depth_loop_matches_stepwise_kernels(rnn, H, depth, motifs, B
 
 
 # ------------------------------------------------------------------------------------------ whole-encoder C++ drivers
-@pytest.mark.parametrize("name", ["tiny_gru_s0", "tiny_gru_s1", "cfg_gru_s1", "tiny_lstm_s0", "tiny_lstm_s2", "cfg_lstm_s2"])
+@pytest.mark.parametrize("name", ["tiny_gru_s0", "tiny_gru_s1", "cfg_gru_s1", "tiny_lstm_s0", "tiny_lstm_s2", "cfg_lstm_s2",
+                                  "edge_gru_s30", "edge_lstm_s31"])
 @pytest.mark.parametrize("which", ["all", "root_only", "atom_only", "node_inter"])
 def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
     """ggpm_encoder_forward/backward (one C call per direction) against the op-by-op host composition of the same
