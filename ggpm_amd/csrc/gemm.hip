@@ -351,6 +351,197 @@ __global__ void __launch_bounds__(256) gemm_group_v2(GemmGroupArgs gg) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Small products (the readouts over a few hundred tree nodes, the input gradients of the motif / attachment levels):
+// with 64 x 64 tiles such a launch has 5-50 workgroups, each a serial chain of K/2 MFMAs behind a drained prologue per
+// K segment -- 27 us for 0.1 GFLOP.  gemm_small_v3 gives it 4x the workgroups and a 4x shorter chain: 32 x 32 output
+// tile, the four waves split every 64-wide k-step four ways and sum their partial tiles through LDS at the end (fixed
+// order), and the K segments run through ONE pipeline (the staging descriptors are re-pointed when the load cursor
+// crosses a segment boundary; no drain, no second prologue).
+constexpr int SM = 32, SN = 32, SK = 64, SLD = 36;
+
+template <bool CONTIG_K>
+struct SmallStage {
+    static constexpr int LD = CONTIG_K ? 33 : SLD;      // 33: conflict-free transposing writes; 36: 16-byte aligned rows
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff[2], vstep;
+    int loff[2], kq[2];
+
+    __device__ __forceinline__ void init(const float* P, int ld, int r0, int R, int K, int total_rows) {
+        const size_t last = CONTIG_K ? (size_t)(total_rows - 1) * ld + K : (size_t)(K - 1) * ld + R;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (unsigned)(last * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = threadIdx.x + 256 * i;           // 512 float4 per operand per step
+            if (CONTIG_K) {
+                const int r = f >> 4, k4 = (f & 15) * 4;
+                kq[i] = k4;
+                loff[i] = k4 * LD + r;
+                voff[i] = r0 + r < R ? (unsigned)(((size_t)(r0 + r) * ld + k4) * 4) : 0xffffff00u;
+            } else {
+                const int k = f >> 3, c = (f & 7) * 4;
+                kq[i] = 0;
+                loff[i] = k * LD + c;
+                voff[i] = r0 + c < R ? (unsigned)(((size_t)k * ld + r0 + c) * 4) : 0xffffff00u;
+            }
+        }
+        vstep = CONTIG_K ? SK * 4u : (unsigned)SK * ld * 4;
+    }
+    __device__ __forceinline__ void off() { voff[0] = voff[1] = 0xffffff00u; }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (voff[i] != 0xffffff00u) voff[i] += vstep;
+    }
+    __device__ __forceinline__ void load(f32x4& r, int i) const {
+        r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+    }
+    __device__ __forceinline__ void store(float* T, const f32x4& r, int i, int klen) const {
+        if (CONTIG_K) {
+            float* d = T + loff[i];
+            d[0] = kq[i] + 0 < klen ? r[0] : 0.f;
+            d[LD] = kq[i] + 1 < klen ? r[1] : 0.f;
+            d[2 * LD] = kq[i] + 2 < klen ? r[2] : 0.f;
+            d[3 * LD] = kq[i] + 3 < klen ? r[3] : 0.f;
+        } else {
+            *reinterpret_cast<f32x4*>(T + loff[i]) = r;
+        }
+    }
+};
+
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, float (&Ls)[2][2][SK * SLD]) {
+    constexpr int LDA = SmallStage<!TA>::LD, LDB = SmallStage<TB>::LD;
+    const int m0 = by * SM, n0 = bx * SN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (n0 < g.N) {
+        const int nseg = g.nseg ? g.nseg : 1;
+        auto seg_A = [&](int sg) { return g.nseg ? g.segA[sg] : g.A; };
+        auto seg_B = [&](int sg) { return g.nseg ? g.segB[sg] : g.B; };
+        auto seg_lda = [&](int sg) { return g.nseg ? g.seg_lda[sg] : g.lda; };
+        auto seg_ldb = [&](int sg) { return g.nseg ? g.seg_ldb[sg] : g.ldb; };
+        auto seg_K = [&](int sg) { return g.nseg ? g.segK[sg] : g.K; };
+        int total_steps = 0;
+        for (int sg = 0; sg < nseg; ++sg) total_steps += (seg_K(sg) + SK - 1) / SK;
+
+        SmallStage<!TA> sa;
+        SmallStage<TB> sb;
+        // load cursor (runs two steps ahead of the MFMAs) and store cursor (one step ahead): (segment, first k)
+        int lseg = 0, lk = 0, sseg = 0, sk = 0;
+        auto point = [&](int sg) {
+            const int K = seg_K(sg);
+            sa.init(seg_A(sg), seg_lda(sg), m0, g.M, K, TA ? K : g.M);
+            sb.init(seg_B(sg), seg_ldb(sg), n0, g.N, K, TB ? g.N : K);
+        };
+        auto next_load = [&]() {         // after the loads of one step have been issued
+            lk += SK;
+            if (lseg < nseg && lk >= seg_K(lseg)) {
+                ++lseg;
+                lk = 0;
+                if (lseg < nseg) point(lseg);
+                else { sa.off(); sb.off(); }
+            } else {
+                sa.advance();
+                sb.advance();
+            }
+        };
+        auto store_klen = [&]() { return sseg < nseg ? seg_K(sseg) - sk : 0; };
+        auto next_store = [&]() {
+            sk += SK;
+            if (sseg < nseg && sk >= seg_K(sseg)) { ++sseg; sk = 0; }
+        };
+
+        const int fA = (16 * wave + (lane >> 5)) * LDA + (lane & 31), fB = (16 * wave + (lane >> 5)) * LDB + (lane & 31);
+        f32x4 ra0[2], rb0[2], ra1[2], rb1[2];
+        float fa[2][2], fb[2][2];
+        auto frag = [&](int buf, int rnd, int set) {       // this wave's k-pairs 2*rnd, 2*rnd + 1 of its quarter step
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                fa[set][u] = Ls[buf][0][fA + (4 * rnd + 2 * u) * LDA];
+                fb[set][u] = Ls[buf][1][fB + (4 * rnd + 2 * u) * LDB];
+            }
+        };
+        // one 64-wide k-step on buffer `cur`: 4 rounds of [staging | 2 MFMAs] per wave
+        auto step = [&](const f32x4 (&sa_)[2], const f32x4 (&sb_)[2], f32x4 (&la)[2], f32x4 (&lb)[2], int cur) {
+            const int klen = store_klen();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < 3) frag(cur, r + 1, (r + 1) & 1);
+                if (r & 1) sb.load(lb[r >> 1], r >> 1); else sa.load(la[r >> 1], r >> 1);
+                if (r & 1) sb.store(Ls[cur ^ 1][1], sb_[r >> 1], r >> 1, klen);
+                else sa.store(Ls[cur ^ 1][0], sa_[r >> 1], r >> 1, klen);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[r & 1][0]), "v"(fb[r & 1][0]));
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[r & 1][1]), "v"(fb[r & 1][1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            next_load();
+            next_store();
+            ggpm_lds_barrier();
+            frag(cur ^ 1, 0, 0);
+        };
+
+        point(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { sa.load(ra0[i], i); sb.load(rb0[i], i); }
+        next_load();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sa.store(Ls[0][0], ra0[i], i, store_klen());
+            sb.store(Ls[0][1], rb0[i], i, store_klen());
+        }
+        next_store();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { sa.load(ra1[i], i); sb.load(rb1[i], i); }
+        next_load();
+        ggpm_lds_barrier();
+        frag(0, 0, 0);
+        for (int s2 = 0; s2 < total_steps; s2 += 2) {      // pairs: the register sets swap roles; a surplus step multiplies zeros
+            step(ra1, rb1, ra0, rb0, 0);
+            step(ra0, rb0, ra1, rb1, 1);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulator is read
+    }
+
+    // sum the four waves' partial tiles in fixed order, then the usual epilogue (4 elements per thread)
+    float* part = &Ls[0][0][0];                                  // 4 x 16 x 64 floats = 16 KB <= one buffer pair
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = threadIdx.x + 256 * j, r = idx >> 6, l = idx & 63;
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = n0 + (l & 31);
+        if (m >= g.M) continue;
+        if (n < g.N) {
+            float v = (part[(0 * 16 + r) * 64 + l] + part[(1 * 16 + r) * 64 + l]) +
+                      (part[(2 * 16 + r) * 64 + l] + part[(3 * 16 + r) * 64 + l]);
+            if (g.bias) v += g.bias[n];
+            float* dst = g.C + (size_t)m * g.ldc + n;
+            if (g.accumulate) v += *dst;
+            v = apply_act(v, g.act);
+            if (g.zero_row0 && m == 0) v = 0.f;
+            *dst = v;
+        } else if (n < g.n_pad) {
+            g.C[(size_t)m * g.ldc + n] = 0.f;
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_small_v3(GemmGroupArgs gg) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][2][SK * SLD];
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_v3_tile<TA, TB>(gg.p[bz], bx, by, Ls);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // C (or split-K slab) = A^T B for row-major A [K x lda], B [K x ldb]: both operands are contiguous along the
 // output dimensions, so tiles go global -> registers -> LDS as float4 without any transposition.
 constexpr int TM = 160, TN = 160, TK = 16, TLD = 176;   // TLD % 64 == 48: the 4 k-rows of a fragment read hit disjoint banks
@@ -629,6 +820,23 @@ __global__ void act_backward_k(const float* __restrict__ dy, const float* __rest
 
 }  // namespace
 
+namespace {
+// gemm_small_v3 when the 64 x 64 kernels would launch about one workgroup per CU or fewer (swept: 128 / 300 / 1024
+// tiles -> 4.51 / 4.49 / 4.53 ms per GRU step)
+inline bool small_launch(int M, int N, int count) {
+    static const int use_v3 = [] { const char* e = getenv("GGPM_GEMM_V3"); return e ? atoi(e) : 1; }();
+    static const int max_tiles = [] { const char* e = getenv("GGPM_GEMM_V3_TILES"); return e ? atoi(e) : 300; }();
+    return use_v3 && (size_t)ggpm_ceil_div(M, BM) * ggpm_ceil_div(N, BN) * count <= (size_t)max_tiles;
+}
+inline void launch_small(int trans_a, int trans_b, const GemmGroupArgs& gg, int count, int M, int n_pad_max, hipStream_t s) {
+    dim3 grid(ggpm_ceil_div(n_pad_max, SN), ggpm_ceil_div(M, SM), count);
+    if (!trans_a && !trans_b) gemm_small_v3<false, false><<<grid, 256, 0, s>>>(gg);
+    else if (!trans_a && trans_b) gemm_small_v3<false, true><<<grid, 256, 0, s>>>(gg);
+    else if (trans_a && !trans_b) gemm_small_v3<true, false><<<grid, 256, 0, s>>>(gg);
+    else gemm_small_v3<true, true><<<grid, 256, 0, s>>>(gg);
+}
+}  // namespace
+
 extern "C" size_t ggpm_gemm_workspace_bytes(int M, int N, int K) {
     const int s = choose_splits(M, N, K);
     size_t bytes = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
@@ -696,6 +904,14 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     dim3 grid(ggpm_ceil_div(splits > 1 ? N : n_pad, BN), ggpm_ceil_div(M, BM), splits);
     static const int use_v2 = [] { const char* e = getenv("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
     const size_t rows_a = trans_a ? K : M, rows_b = trans_b ? N : K;
+    if (use_v2 && splits == 1 && small_launch(M, N, 1) && g.vecA && g.vecB && rows_a * lda * 4 < 0xffffff00ull &&
+        rows_b * ldb * 4 < 0xffffff00ull) {
+        GemmGroupArgs gg;
+        for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
+        launch_small(trans_a, trans_b, gg, 1, M, n_pad, s);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     // v2 keeps 70 KB of LDS per workgroup (two resident per CU): it wins while the whole grid is resident at once
     // (latency-bound launches: 573 x 600 x 912 35 -> 25 us) and loses beyond (2843 x 912 x 340: 33 -> 37 us)
     const bool resident = (size_t)grid.x * grid.y * grid.z <= 512 || use_v2 == 2;
@@ -754,6 +970,11 @@ extern "C" int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, 
     for (int i = 0; i < count; ++i) fill_args(gg.p[i], M, N, K, p[i]);
     for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
     hipStream_t s = (hipStream_t)stream;
+    if (small_launch(M, N, count)) {
+        launch_small(trans_a, trans_b, gg, count, M, n_pad_max, s);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     dim3 grid(ggpm_ceil_div(n_pad_max, BN), ggpm_ceil_div(M, BM), count);
     if (!trans_a && !trans_b) gemm_group_v2<false, false><<<grid, 256, 0, s>>>(gg);
     else if (!trans_a && trans_b) gemm_group_v2<false, true><<<grid, 256, 0, s>>>(gg);
@@ -792,6 +1013,13 @@ extern "C" int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const fl
     g.nseg = nseg;
     for (int i = 0; i < nseg; ++i) { g.segA[i] = A[i]; g.segB[i] = B[i]; g.seg_lda[i] = lda[i]; g.seg_ldb[i] = ldb[i]; g.segK[i] = K[i]; }
     hipStream_t s = (hipStream_t)stream;
+    if (small_launch(M, N, 1)) {
+        GemmGroupArgs gg;
+        for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
+        launch_small(0, trans_b, gg, 1, M, n_pad, s);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     dim3 grid(ggpm_ceil_div(n_pad, BN), ggpm_ceil_div(M, BM), 1);
     if (trans_b) gemm_kernel_v2<false, true><<<grid, 256, 0, s>>>(g);
     else gemm_kernel_v2<false, false><<<grid, 256, 0, s>>>(g);

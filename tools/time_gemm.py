@@ -22,6 +22,10 @@ SHAPES = [  # (trans_a, trans_b, M, N, K, label)
     (0, 0, 573, 600, 912, "motif level dX"),
     (0, 1, 1225, 300, 600, "W_o readout"),
     (0, 0, 1225, 600, 300, "W_o readout dX"),
+    (0, 1, 310, 300, 600, "tree-node readout (25 tiles of 64 x 64)"),
+    (0, 0, 310, 300, 300, "tree-node readout dX"),
+    (0, 0, 573, 340, 900, "motif level dx over the gate slabs"),
+    (0, 1, 32, 300, 600, "root readout"),
 ]
 
 
