@@ -53,6 +53,9 @@ __device__ __forceinline__ void ggpm_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// true when `count` products of this shape are better issued as ONE unsplit grouped launch (small output, K short enough
+// for the in-workgroup K split) than as separate split-K launches
+bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count);
 #define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
 typedef ggpm_gemm_problem GgpmGemmProblem;
 

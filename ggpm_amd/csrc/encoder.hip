@@ -417,7 +417,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         CK(st.side_after_main());
         CK(ggpm_lstm_weight_grads(E1, H, depth, L.Hs, L.St, level_work, w.level_work_bytes, dW[0] + I, I + H, dW[1] + I,
                                   I + H, dW[2] + I, I + H, dW[3] + I, I + H, st.w()));
-        if (ggpm_gemm_workspace_bytes(H, I, E1) == 0) {      // no split-K for this shape: the four in one launch
+        if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
             GgpmGemmProblem gp[4];
             for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
             CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, st.w()));
@@ -479,7 +479,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     if (!overlap)
         CK(ggpm_gru_weight_grads(E1, H, depth, L.Hs, L.St, L.St + ds, level_work, w.level_work_bytes, dWz + I, I + H, dUr,
                                  H, G[lp(level, L_BU)], dWh + I, I + H, st.w()));
-    if (ggpm_gemm_workspace_bytes(H, I, E1) == 0) {      // no split-K for this shape: the three in one launch
+    if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
         const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
                                        {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
                                        {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};

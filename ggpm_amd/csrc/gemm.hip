@@ -947,6 +947,10 @@ inline void fill_args(GemmArgs& g, int M, int N, int K, const GgpmGemmProblem& p
 }
 }  // namespace
 
+bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count) {
+    return ggpm_gemm_workspace_bytes(M, N, K) == 0 || (small_launch(M, N, count) && K <= 8192);
+}
+
 extern "C" int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* p,
                                  ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
