@@ -56,6 +56,10 @@ __device__ __forceinline__ void ggpm_lds_barrier() {
 // true when `count` products of this shape are better issued as ONE unsplit grouped launch (small output, K short enough
 // for the in-workgroup K split) than as separate split-K launches
 bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count);
+// `count` (<= 4) tall contractions C_i = A_i^T B_i of one output shape (K_i may differ) in one launch + one reduce;
+// falls back to sequential ggpm_gemm calls when a member does not qualify for the tall kernel
+int ggpm_gemm_tall_grouped(int M, int N, int count, const ggpm_gemm_problem* p, const int* K, float* ws, size_t ws_bytes,
+                           ggpm_stream_t stream);
 #define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
 typedef ggpm_gemm_problem GgpmGemmProblem;
 

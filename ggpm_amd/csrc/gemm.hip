@@ -547,14 +547,17 @@ __global__ void __launch_bounds__(256) gemm_small_v3(GemmGroupArgs gg) {
 constexpr int TM = 160, TN = 160, TK = 16, TLD = 176;   // TLD % 64 == 48: the 4 k-rows of a fragment read hit disjoint banks
 constexpr int T_F4 = (TM + TN) / 4 * TK;                // float4 per k-step (1280) = 5 per thread
 
-__global__ void __launch_bounds__(256) gemm_tn_tall(GemmArgs g) {
+__global__ void __launch_bounds__(256) gemm_tn_tall(GemmGroupArgs gg, int splits) {
     __shared__ __attribute__((aligned(16))) float Ls[2][2 * TK * TLD];   // [buffer][A rows | B rows][k][column]
     // workgroups are dealt round-robin over the 8 XCDs: renumber so that the tiles of one K chunk share an L2
     const unsigned T = gridDim.x * gridDim.y * gridDim.z;
     const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
     const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);
-    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y;
+    const int bzz = logical / (gridDim.x * gridDim.y);      // (problem of the group, K chunk)
+    const GemmArgs& g = gg.p[bzz / splits];
+    const int bz = bzz % splits;
     const int m0 = by * TM, n0 = bx * TN;
     const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -693,7 +696,8 @@ __global__ void __launch_bounds__(256) gemm_tn_tall(GemmArgs g) {
 
 // Sums the fragment-order slabs of gemm_tn_tall over the K chunks (fixed order: four interleaved partial sums per
 // workgroup, combined as (0+1)+(2+3)) and writes C.  One workgroup per (tile, wave, 16 x 16 block).
-__global__ void __launch_bounds__(256) tall_reduce(GemmArgs g, int splits, int tiles_n, int tiles) {
+__global__ void __launch_bounds__(256) tall_reduce(GemmGroupArgs gg, int splits, int tiles_n, int tiles) {
+    const GemmArgs& g = gg.p[blockIdx.y];
     __shared__ f32x4 part[4][64];
     const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
     const int blk = blockIdx.x % 25, wave = (blockIdx.x / 25) & 3, tile = blockIdx.x / 100;
@@ -877,7 +881,9 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
             return p;
         }();
         g.dbg = dbg;
-        gemm_tn_tall<<<grid, 256, 0, s>>>(g);
+        GemmGroupArgs gg;
+        for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
+        gemm_tn_tall<<<grid, 256, 0, s>>>(gg, splits);
         if (dbg) {
             unsigned long long h[6];
             (void)hipStreamSynchronize(s);
@@ -887,7 +893,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
                     "shader clock %.2f GHz\n", M, N, K, grid.x, grid.y, grid.z, (h[3] - h[1]) * 0.01, (h[5] - h[3]) * 0.01,
                     steps, (double)(h[4] - h[2]) / steps, (double)(h[4] - h[2]) / ((h[5] - h[3]) * 10.0));
         }
-        if (splits > 1) tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(g, splits, tiles_n, tiles_n * tiles_m);
+        if (splits > 1) tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, splits, tiles_n, tiles_n * tiles_m);
         GGPM_CHECK_LAUNCH();
         return GGPM_OK;
     }
@@ -946,6 +952,47 @@ inline void fill_args(GemmArgs& g, int M, int N, int K, const GgpmGemmProblem& p
     g.k_chunk = ggpm_round_up(K, BK);
 }
 }  // namespace
+
+int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, const int* K, float* ws, size_t ws_bytes,
+                           ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || !K || M <= 0 || N <= 0) return GGPM_ERR_ARG;
+    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    const size_t slab = tall_slab_bytes(M, N);
+    bool ok = use_tall && count > 1 && ws != nullptr;
+    int splits = 1 << 30;
+    for (int i = 0; i < count && ok; ++i) {
+        ok = (p[i].lda & 3) == 0 && (p[i].ldb & 3) == 0 && ((uintptr_t)p[i].A & 15) == 0 && ((uintptr_t)p[i].B & 15) == 0 &&
+             p[i].lda >= ggpm_round_up(M, 4) && p[i].ldb >= ggpm_round_up(N, 4) && tall_shape(M, N, K[i]) &&
+             p[i].n_pad <= ggpm_round_up(N, TN) && p[i].n_pad >= N && p[i].n_pad <= p[i].ldc &&
+             (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
+        splits = min(splits, tall_splits(M, N, K[i]));
+    }
+    if (ok) splits = min(splits, (int)(ws_bytes / (count * slab)));      // the group shares the workspace
+    if (!ok || splits < 2) {
+        for (int i = 0; i < count; ++i) {
+            const int rc = ggpm_gemm(1, 0, M, N, K[i], p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].n_pad,
+                                     p[i].bias, p[i].accumulate, p[i].act, p[i].zero_row0, ws, ws_bytes, stream);
+            if (rc) return rc;
+        }
+        return GGPM_OK;
+    }
+    // one launch: the K chunks of all members share the grid (same number of chunks, chunk length per member), the
+    // slabs of member i start at ws + i * splits * slab, one reduce launch sums them all
+    GemmGroupArgs gg;
+    for (int i = 0; i < count; ++i) {
+        fill_args(gg.p[i], M, N, K[i], p[i]);
+        gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), TK);
+        gg.p[i].ws = ws + (size_t)i * splits * (slab / sizeof(float));
+    }
+    for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
+    gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits, tiles_n, tiles_n * tiles_m);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
 
 bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count) {
     return ggpm_gemm_workspace_bytes(M, N, K) == 0 || (small_launch(M, N, count) && K <= 8192);

@@ -949,20 +949,26 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = depth * E1;
     int rc;
-    rc = ggpm_gemm(1, 0, H, H, KD, DMP, Hp, Gs, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
-    if (rc) return rc;
-    rc = ggpm_gemm(1, 0, H, H, KD, DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
-    if (rc) return rc;
+    // the two or three contractions in ONE launch and one reduce (they share the split-K workspace)
+    ggpm_gemm_problem gp[3] = {{DMP, Hp, Gs, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {nullptr, Hp, nullptr, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0}};
+    int Ks[3] = {KD, KD, 0};
     if (depth > 1 || with_slot0) {
         // dq^t pairs with h^t; the dense level never produces dq^0 (h^0 = 0), sparse_forward does
         const int first_slot = with_slot0 ? 0 : 1;
         const int KQ = (depth - first_slot) * E1;
         const float* dq0 = DQ + (size_t)first_slot * slot;
-        rc = ggpm_gemm(1, 0, H, H, KQ, dq0, Hp, Hs + (size_t)first_slot * slot, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
+        gp[2].A = dq0;
+        gp[2].B = Hs + (size_t)first_slot * slot;
+        Ks[2] = KQ;
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
         if (rc) return rc;
         rc = ggpm_colsum(dq0, Hp, KQ, H, dbu, csws, stream);
         if (rc) return rc;
     } else {
+        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream);
+        if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
     }

@@ -769,18 +769,22 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = depth * E1;
     int rc;
-    rc = ggpm_gemm(1, 0, H, H, KD, DI, Hp, Ss, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
-    if (rc) return rc;
-    rc = ggpm_gemm(1, 0, H, H, KD, DO, Hp, Ss, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
-    if (rc) return rc;
-    rc = ggpm_gemm(1, 0, H, H, KD, DU, Hp, Ss, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
-    if (rc) return rc;
+    // the three or four contractions in ONE launch and one reduce (they share the split-K workspace)
+    ggpm_gemm_problem gp[4] = {{DI, Hp, Ss, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DO, Hp, Ss, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DU, Hp, Ss, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {nullptr, Hp, nullptr, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0}};
+    int Ks[4] = {KD, KD, KD, 0};
     if (depth > 1 || with_slot0) {
         const int first_slot = with_slot0 ? 0 : 1;     // dqf^t pairs with h^t; slot 0 exists for sparse_forward only
-        const int KQ = (depth - first_slot) * E1;
-        rc = ggpm_gemm(1, 0, H, H, KQ, DQ + (size_t)first_slot * slot, Hp, Hs + (size_t)first_slot * slot, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0, skws, skbytes, stream);
+        gp[3].A = DQ + (size_t)first_slot * slot;
+        gp[3].B = Hs + (size_t)first_slot * slot;
+        Ks[3] = (depth - first_slot) * E1;
+        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream);
         if (rc) return rc;
     } else {
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
+        if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }
     GGPM_CHECK_LAUNCH();
