@@ -139,6 +139,11 @@ inline int lq(int level, int which) { return P_LEVEL0 + level * Q_COUNT + which;
 inline int lwo(bool lstm, int level) { return lstm ? lq(level, Q_WO) : lp(level, L_WO); }
 inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level, L_BO); }
 
+inline int wgrad_overlap_mode() {
+    static const int v = getenv("GGPM_WGRAD_OVERLAP") ? atoi(getenv("GGPM_WGRAD_OVERLAP")) : 0;
+    return v;
+}
+
 inline bool use_tables() {
     static const bool on = getenv("GGPM_TABLES") != nullptr && atoi(getenv("GGPM_TABLES")) != 0;   // opt-in: measured slower
     return on;
@@ -614,7 +619,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                      st));
     CK(ggpm_segment_sum(w.d_nei_g, Hp, S.gagr.rowptrT, S.gagr.colT, d.E1g, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],
-                      nullptr, 0, w, st, getenv("GGPM_WGRAD_OVERLAP") ? atoi(getenv("GGPM_WGRAD_OVERLAP")) : 0));
+                      nullptr, 0, w, st, wgrad_overlap_mode()));
 
     if (side_stream) {      // every gradient buffer is complete once the main stream has passed this point
         hipEvent_t ev = ggpm_wgrad_event(62);

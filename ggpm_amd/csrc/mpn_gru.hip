@@ -508,9 +508,16 @@ inline void set_lds(K kernel, size_t bytes) {
     }
 }
 
+// Environment switches are read once: getenv walks the whole environment (~0.5 us) and the launch helpers below run
+// ~120 times per training step.
+inline bool env_no_fuse_b() { static const bool v = getenv("GGPM_NO_FUSE_B") != nullptr; return v; }
+inline bool env_adebug() { static const bool v = getenv("GGPM_ADEBUG") != nullptr; return v; }
+
 inline int pick_tg(int E1, int NT) {
-    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
-    if (const char* e = getenv("GGPM_TG_SMALL")) {      // tuning override for the small (motif / attachment) levels only
+    static const char* const tg_env = getenv("GGPM_TG");
+    if (const char* e = tg_env) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
+    static const char* const tg_small_env = getenv("GGPM_TG_SMALL");
+    if (const char* e = tg_small_env) {      // tuning override for the small (motif / attachment) levels only
         int v = atoi(e);
         if (v >= 1 && v <= 64 && (E1 + 15) / 16 <= 64) return v < NT ? v : NT;
     }
@@ -521,11 +528,11 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
-    a.fuse_b = (with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    a.fuse_b = (with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
-    if (getenv("GGPM_ADEBUG")) {
+    if (env_adebug()) {
         if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
         a.dbg = dbg_buf;
     }
@@ -561,14 +568,14 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t lds = (size_t)2 * ROWS * (Hp + 4) * sizeof(float);
     a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && 2 * lds <= 160 * 1024 &&
-                !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+                !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t lds_a = a.fuse_b ? 2 * lds : lds;
     set_lds(gru_bwd_a, lds_a);
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
-    if (getenv("GGPM_ADEBUG")) {
+    if (env_adebug()) {
         if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
         a.dbg = dbg_buf;
     }
@@ -651,7 +658,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
-    const char* abl = getenv("GGPM_ABLATE");
+    static const char* const abl = getenv("GGPM_ABLATE");
     for (int t = 1; t <= depth; ++t) {
         GruFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xz = Xz; a.Xr = Xr; a.Xh = Xh;

@@ -451,15 +451,21 @@ inline void set_lds(K kernel, size_t bytes) {
 
 inline size_t lds_tiles(int n, int Hp) { return (size_t)n * ROWS * (Hp + 4) * sizeof(float); }
 
+// Environment switches are read once: getenv walks the whole environment (~0.5 us) and the launch helpers below run
+// ~120 times per training step.
+inline bool env_no_fuse_b() { static const bool v = getenv("GGPM_NO_FUSE_B") != nullptr; return v; }
+inline bool env_adebug() { static const bool v = getenv("GGPM_ADEBUG") != nullptr; return v; }
+
 inline int pick_tg(int E1, int NT) {
-    if (const char* e = getenv("GGPM_TG")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
+    static const char* const tg_env = getenv("GGPM_TG");
+    if (const char* e = tg_env) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
     return ggpm_tiles_per_group(E1, NT);
 }
 
 void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    a.fuse_b = (with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+    a.fuse_b = (with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp), lb = lds_tiles(1, Hp);
     ggpm_timing_begin(2, s, (a.fuse_b ? 4 : 3) * flops1);
@@ -484,7 +490,7 @@ void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
     const size_t l3 = lds_tiles(3, Hp);
     a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && lds_tiles(6, Hp) <= 160 * 1024 &&
-                !getenv("GGPM_NO_FUSE_B")) ? 1 : 0;
+                !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t la = a.fuse_b ? lds_tiles(6, Hp) : l3;
     set_lds(lstm_bwd_a, la);

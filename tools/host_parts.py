@@ -18,6 +18,73 @@ sync = FlatGradSync(model.parameters(), encoder=model.encoder)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 acc = {}
 
+# time spent inside the two C driver calls themselves (the rest of "encoder forward" / "backward" is Python + autograd)
+from ggpm_amd import _lib as _L
+_lib_obj = _L.load()
+_c_time = {"ggpm_encoder_forward": 0.0, "ggpm_encoder_backward": 0.0}
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name, self.fn = name, getattr(_lib_obj, name)
+
+    def __call__(self, *a):
+        t0 = time.perf_counter()
+        r = self.fn(*a)
+        _c_time[self.name] += time.perf_counter() - t0
+        return r
+
+
+class _Proxy:
+    def __getattr__(self, k):
+        return _Timed(k) if k in _c_time else getattr(_lib_obj, k)
+
+
+_L.load = lambda *a, **k: _Proxy()
+
+# finer: the pinned-ring upload and the autograd Function call of the encoder forward
+from ggpm_amd import encoder as _E, fused as _Fz
+_big = []
+_sub = {"ring upload": 0.0, "_HierEncoder.apply": 0.0, "torch.empty(saved)": 0.0}
+_up = _E._RING.upload
+
+
+def _upload(values, device):
+    t0 = time.perf_counter()
+    r = _up(values, device)
+    _sub["ring upload"] += time.perf_counter() - t0
+    return r
+
+
+_E._RING.upload = _upload
+_apply = _Fz._HierEncoder.apply
+
+
+def _timed_apply(*a):
+    t0 = time.perf_counter()
+    r = _apply(*a)
+    _sub["_HierEncoder.apply"] += time.perf_counter() - t0
+    return r
+
+
+_Fz._HierEncoder.apply = staticmethod(_timed_apply)
+_empty = torch.empty
+
+
+def _timed_empty(*a, **k):
+    big = len(a) == 1 and isinstance(a[0], int) and a[0] > (1 << 24)
+    if not big:
+        return _empty(*a, **k)
+    t0 = time.perf_counter()
+    r = _empty(*a, **k)
+    dt = time.perf_counter() - t0
+    _sub["torch.empty(saved)"] += dt
+    _big.append((a[0], dt, torch.cuda.memory_reserved()))
+    return r
+
+
+torch.empty = _timed_empty
+
 
 def lap(name, t0):
     t1 = time.perf_counter()
@@ -51,3 +118,9 @@ t2 = time.perf_counter()
 print("enqueue %.3f ms/step, total %.3f ms/step" % (1e3 * (t1 - t0) / N, 1e3 * (t2 - t0) / N))
 for k, v in acc.items():
     print("  %-16s %.3f ms" % (k, 1e3 * v / N))
+for k, v in _sub.items():
+    print("  sub %-27s %.3f ms (/ %d)" % (k, 1e3 * v / (N + 40), N + 40))
+for n, dt, res in _big[-12:]:
+    print("    big alloc %6.1f MB took %8.1f us, reserved %.2f GB" % (n / 1e6, dt * 1e6, res / 1e9))
+for k, v in _c_time.items():
+    print("  inside %-24s %.3f ms (all %d steps incl. warm-up: / %d)" % (k, 1e3 * v / (N + 40), N + 40, N + 40))
