@@ -154,7 +154,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=16,
+                    help="untimed steps; 16 = one pass over the pool of pre-tensorized batches, so that every batch shape has "
+                         "been seen (allocator blocks, lazily created streams and events) before the timed region")
     ap.add_argument("--rnn", default="GRU", choices=["GRU", "LSTM"])
     ap.add_argument("--hidden", type=int, default=300)
     ap.add_argument("--depth", type=int, default=20)

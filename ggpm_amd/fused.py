@@ -42,6 +42,14 @@ def enabled() -> bool:
     return os.environ.get("GGPM_FUSED_ENCODER", "1") != "0"
 
 
+def _arena_size(nbytes: int) -> int:
+    """Arena sizes follow the batch's node / message counts, so every batch asks for a slightly different size; rounded up
+    to 128 MiB the second batch already finds the first one's block in PyTorch's cache instead of paying a
+    several-hundred-MB hipMalloc whenever a new maximum shows up (≈1.5 % of the default bench run before)."""
+    step = 1 << 27
+    return (nbytes + step - 1) // step * step if nbytes > (1 << 24) else nbytes
+
+
 def _ptr_array(tensors) -> ctypes.Array:
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -66,7 +74,7 @@ class _HierEncoder(torch.autograd.Function):
         Hp = F_.padded_hidden(dims.H)
         f32 = dict(dtype=torch.float32, device=dev)
         saved_bytes = int(lib.ggpm_encoder_saved_bytes(ctypes.byref(dims)))
-        saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+        saved = torch.empty(_arena_size(saved_bytes), dtype=torch.uint8, device=dev)
         hroot = torch.empty(dims.B, Hp, **f32)
         hnode = torch.empty(dims.N1t, Hp, **f32)
         hinter = torch.empty(dims.N1t, Hp, **f32)
@@ -106,7 +114,7 @@ class _HierEncoder(torch.autograd.Function):
                 grads.append(flat[off:off + p.numel()].view(p.shape))
                 off += p.numel()
         work_bytes = int(lib.ggpm_encoder_work_bytes(ctypes.byref(dims)))
-        work = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
+        work = torch.empty(_arena_size(work_bytes), dtype=torch.uint8, device=dev)
         side, side_p = _side_ptr(dev)
         if side is not None:
             for t in (flat, work):
