@@ -70,16 +70,9 @@ struct GruFwdArgs {
     int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
     unsigned long long* dbg;       // optional phase stamps of workgroup (0,0) (GGPM_ADEBUG; dev only)
     const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
+    int h0_zero;                   // first depth of a dense level: h^0 = 0, so s = g = 0 without a gather and the gate
+                                   // products vanish (h^1 = sigmoid(x_z) tanh(x_h)); H^0 / Q^0 are neither built nor read
 };
-
-__global__ void gru_init_state(float* __restrict__ H0, float* __restrict__ Q0, const float* __restrict__ bu,
-                               int E1, int Hp) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= Hp) return;
-    H0[(size_t)r * Hp + c] = 0.f;
-    Q0[(size_t)r * Hp + c] = bu[c];
-}
 
 __global__ void pad_bias(const float* __restrict__ b, int H, int Hp, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +107,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         bool fast;
         const int tchunk = ggpm_table_chunk(a.ptab, row, a.E1, lane, fast);
         GgpmRowList rl;
-        if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
+        if (a.h0_zero) { rl.lo = 0; rl.n = 0; }
+        else if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
         if (a.ablate & 1) rl.n = 0;
         const size_t rowo = (size_t)(row < a.E1 ? row : 0) * Hp;
         for (int c0 = 0; c0 < Hp; c0 += 512) {
@@ -185,7 +179,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         const float4 xh = ggpm_ld4(a.Xh + o);
         f32x4 acc[2][RT];
         ggpm_zero_acc<2, RT>(acc);
-        if (!(a.ablate & 2)) {
+        if (!(a.ablate & 2) && !a.h0_zero) {
             const float* const tiles[2] = {Ts, Tg};
             const float* const wps[2] = {a.Wz, a.Wh};
             ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
@@ -652,9 +646,8 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
         set_lds(gru_fwd_b, lds_b);
         gru_fwd_b<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0);
-    } else {
-        gru_init_state<<<ig, 256, 0, s>>>(Hs, Qs, pbu, E1, Hp);
     }
+    // dense levels start from h^0 = 0: the first depth launch knows that (h0_zero), so H^0 / Q^0 are never materialised
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
@@ -666,6 +659,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         a.ablate = abl ? atoi(abl) : 0;
         a.frozen = frozen;
         a.ptab = pred_tab;
+        a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
             a.Qprev = Qs + (size_t)(t - 1) * slot;
