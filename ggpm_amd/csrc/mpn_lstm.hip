@@ -27,6 +27,7 @@ struct LstmFwdArgs {
     const int32_t *rowptr, *col;
     const unsigned char* frozen;     // sparse_forward only: rows that keep their (h, c)
     int fuse_b;                      // single column group: kernel A also forms qf' = Wf_h h' (no B launch)
+    int h0_zero;                     // first depth of a dense level: h^0 = c^0 = 0 -> no gather, no gate products
 };
 
 __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w); }
@@ -50,7 +51,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
 
     for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
         const int row = r0 + lr;
-        const GgpmRowList rl = ggpm_row_list(a.rowptr, row, a.E1);
+        GgpmRowList rl;
+        if (a.h0_zero) { rl.lo = 0; rl.n = 0; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
         const size_t rowo = (size_t)(row < a.E1 ? row : 0) * Hp;
         for (int c0 = 0; c0 < Hp; c0 += 512) {
             int c[2], cs[2], cf[2];
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         const float4 xi = ggpm_ld4(a.Xi + o), xo = ggpm_ld4(a.Xo + o), xu = ggpm_ld4(a.Xu + o);
         f32x4 acc[3][RT];
         ggpm_zero_acc<3, RT>(acc);
-        {
+        if (!a.h0_zero) {
             const float* const tiles[3] = {Ts, Ts, Ts};
             const float* const wps[3] = {a.Wi, a.Wo, a.Wu};
             ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
@@ -573,6 +575,7 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;
         a.frozen = frozen;
+        a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
             a.Cprev = Cs + (size_t)(t - 1) * slot; a.Cnew = Cs + (size_t)t * slot;
