@@ -532,7 +532,7 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
     }
     if (a.fuse_b) with_b = false;
     const size_t lds_a = (a.fuse_b ? 3 : 2) * lds_b;
-    ggpm_timing_begin(0, s, (a.fuse_b ? 3 : 2) * flops1);
+    ggpm_timing_begin(0, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 2)) * flops1);     // the first depth has no gate products
     if (stash) {
         set_lds(gru_fwd_a<true>, lds_a);
         gru_fwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);

@@ -470,7 +470,7 @@ void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream
     a.fuse_b = (with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp), lb = lds_tiles(1, Hp);
-    ggpm_timing_begin(2, s, (a.fuse_b ? 4 : 3) * flops1);
+    ggpm_timing_begin(2, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 3)) * flops1);     // the first depth has no gate products
     if (stash) {
         set_lds(lstm_fwd_a<true>, la);
         lstm_fwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
