@@ -63,6 +63,12 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const ggpm_gemm_problem* p, 
 #define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
 typedef ggpm_gemm_problem GgpmGemmProblem;
 
+// Message passing on a tree reaches a fixed point after as many steps as the longest dependency chain: the next dense
+// level forward of this thread (GRU or LSTM) issues only `run_depth` of its `depth` steps (0 / >= depth: all of them);
+// the caller then replicates the last computed slot of every stash array (encoder.hip).  Consumed by one call.
+void ggpm_forward_run_depth(int run_depth);
+int ggpm_take_run_depth();
+
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
 void ggpm_timing_begin(int which, hipStream_t s, double flops);
 void ggpm_timing_end(int which, hipStream_t s);

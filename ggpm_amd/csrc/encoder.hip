@@ -55,6 +55,7 @@ struct Dims {
     int N1g, E1g, Kga, Kgb, N1t, E1t, Kta, Ktb, Ktc, B;
     int ld_n, ld_m, ld_t, Ig, It;
     int lstm, nX, lcount;          // cell type, hoisted-input slots per level (3 / 4), parameter slots per level (9 / 10)
+    int tree_chain;                // longest dependency chain of the tree messages (0: unknown)
 };
 
 Dims make_dims(const ggpm_enc_dims* d) {
@@ -67,6 +68,7 @@ Dims make_dims(const ggpm_enc_dims* d) {
     x.Ig = x.atom + 4 + 20; x.ld_m = ggpm_round_up(x.Ig, 4);
     x.It = x.H + 20; x.ld_t = ggpm_round_up(x.It, 4);
     x.lstm = d->rnn_type == 1; x.nX = x.lstm ? 4 : 3; x.lcount = x.lstm ? 10 : 9;
+    x.tree_chain = d->tree_chain;
     return x;
 }
 
@@ -165,10 +167,50 @@ int linear2(int M, int N, const float* x1, int ld1, int K1, const float* x2, int
     return ggpm_gemm_ksegments(1, M, N, 2, A, lda, B, ldb, K, y, ldy, ldy, b, 0, act, zero_row0, s);
 }
 
+// Copies slot `src` of up to 8 slotted arrays to their slots lo..hi (a level that reached its fixed point early).
+struct ReplicateArgs {
+    float* base[8];
+    int src[8], lo[8], hi[8];
+    size_t slot4;      // float4 per slot
+};
+__global__ void __launch_bounds__(256) replicate_slots_k(ReplicateArgs r) {
+    const int a = blockIdx.y;
+    if (r.hi[a] < r.lo[a]) return;
+    float4* base = reinterpret_cast<float4*>(r.base[a]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < r.slot4; i += (size_t)gridDim.x * 256) {
+        const float4 v = base[(size_t)r.src[a] * r.slot4 + i];
+        for (int k = r.lo[a]; k <= r.hi[a]; ++k) base[(size_t)k * r.slot4 + i] = v;
+    }
+}
+
+// steps a tree-side level really has to run: chain + 1 (the step after the last change also fixes the stash)
+inline int run_steps(const Dims& d, int level, int depth) {
+    static const bool off = getenv("GGPM_TREE_FIXED_POINT") && atoi(getenv("GGPM_TREE_FIXED_POINT")) == 0;
+    if (off || level == 2 || d.tree_chain <= 0 || d.tree_chain + 1 >= depth) return depth;
+    return d.tree_chain + 1;
+}
+
+int replicate_tail(const Dims& d, int E1, int depth, int run, const LevelSaved& L, ggpm_stream_t s) {
+    if (run >= depth) return GGPM_OK;
+    const size_t slot = (size_t)E1 * d.Hp, ds = (size_t)depth * slot;
+    ReplicateArgs r = {};
+    int n = 0;
+    auto add = [&](float* base, int src, int lo, int hi) { r.base[n] = base; r.src[n] = src; r.lo[n] = lo; r.hi[n] = hi; ++n; };
+    add(L.Hs, run, run + 1, depth);                       // h^run == h^t for every later t
+    if (L.Cs) add(L.Cs, run, run + 1, depth);
+    add(L.Qs, run, run + 1, depth - 1);
+    for (int k = 0; k < 5; ++k) add(L.St + k * ds, run - 1, run, depth - 1);     // stash slot of step t is t - 1
+    r.slot4 = slot / 4;
+    dim3 grid((unsigned)ggpm_ceil_div((int)r.slot4, 256 * 4), n);
+    replicate_slots_k<<<grid, 256, 0, (hipStream_t)s>>>(r);
+    return GGPM_OK;
+}
+
 int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* x, int ldx, float* const* P, int level,
                   const Csr& pred, const Csr& agr, LevelSaved& L, ggpm_stream_t s) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp;
+    const int run = run_steps(d, level, depth);
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         const float* b[4] = {P[lq(level, Q_BI)], P[lq(level, Q_BOG)], P[lq(level, Q_BU)], P[lq(level, Q_BF)]};
@@ -176,9 +218,11 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
         for (int k = 0; k < 4; ++k) gp[k] = {x, ldx, W[k], I + H, L.X + k * slot, Hp, Hp, b[k], 0, GGPM_ACT_NONE, 0};
         CK(ggpm_gemm_grouped(0, 1, E1, H, I, 4, gp, s));      // the four input projections in one launch
         const size_t dsl = (size_t)depth * slot;
+        ggpm_forward_run_depth(run);
         CK(ggpm_lstm_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H,
                              W[2] + I, I + H, W[3] + I, I + H, pred.rowptr, pred.col, L.Hs, L.Cs, L.Qs, L.St, L.St + dsl,
                              L.St + 2 * dsl, L.St + 3 * dsl, L.St + 4 * dsl, L.wpack, 1, s));
+        CK(replicate_tail(d, E1, depth, run, L, s));
         CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
         return GGPM_OK;
     }
@@ -188,9 +232,11 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
                                    {x, ldx, Wh, I + H, L.X + 2 * slot, Hp, Hp, P[lp(level, L_BH)], 0, GGPM_ACT_NONE, 0}};
     CK(ggpm_gemm_grouped(0, 1, E1, H, I, 3, gp, s));          // the three input projections in one launch
     const size_t ds = (size_t)depth * slot;
+    ggpm_forward_run_depth(run);
     CK(ggpm_gru_forward_tab(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
                             P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, use_tables() ? pred.tab : nullptr,
                             L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
+    CK(replicate_tail(d, E1, depth, run, L, s));
     CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
     return GGPM_OK;
 }

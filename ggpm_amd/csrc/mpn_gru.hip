@@ -614,6 +614,10 @@ __global__ void sparse_init_state(const float* __restrict__ h_in, const unsigned
 }
 }  // namespace
 
+namespace { thread_local int g_run_depth = 0; }
+void ggpm_forward_run_depth(int run_depth) { g_run_depth = run_depth; }
+int ggpm_take_run_depth() { const int v = g_run_depth; g_run_depth = 0; return v; }
+
 static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
                             const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
                             const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
@@ -652,7 +656,9 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     static const char* const abl = getenv("GGPM_ABLATE");
-    for (int t = 1; t <= depth; ++t) {
+    int run_depth = ggpm_take_run_depth();
+    if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
+    for (int t = 1; t <= run_depth; ++t) {
         GruFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xz = Xz; a.Xr = Xr; a.Xh = Xh;
         a.Wz = pWz; a.Wh = pWh; a.Ur = pUr; a.bu = pbu; a.rowptr = pred_rowptr; a.col = pred_col;

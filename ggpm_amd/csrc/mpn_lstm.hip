@@ -570,7 +570,9 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
     }
 
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
-    for (int t = 1; t <= depth; ++t) {
+    int run_depth = ggpm_take_run_depth();
+    if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
+    for (int t = 1; t <= run_depth; ++t) {
         LstmFwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;

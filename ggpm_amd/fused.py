@@ -35,7 +35,8 @@ PARAM_ORDER = param_order("GRU")
 
 class EncDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("H", "He", "depthT", "depthG", "atom_size", "n_motif", "n_attach", "N1g",
-                                            "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B", "rnn_type")]
+                                            "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B", "rnn_type",
+                                            "tree_chain")]
 
 
 def enabled() -> bool:
@@ -161,5 +162,6 @@ def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
     dims = EncDims(encoder.hidden_size, encoder.embed_size, encoder.tree_encoder.depth, encoder.graph_encoder.depth,
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
-                   tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm))
+                   tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm),
+                   int(getattr(tf[3], "ggpm_chain", 0)))
     return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, getattr(encoder, "_grad_sink", None), *params)

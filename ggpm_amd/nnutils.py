@@ -29,9 +29,41 @@ def make_tensor(x):
     return to_cuda(x)
 
 
+def tree_chain_length(bgraph) -> int:
+    """Longest dependency chain among the tree messages, from the padded predecessor table ``tree bgraph`` (host data).
+
+    Message e depends on the messages listed in row e (0 = padding).  On a tree that relation is acyclic, and after
+    ``chain`` message-passing steps no message changes any more (chain(e) = 1 + max over its predecessors, 1 without
+    any): the encoder then runs ``chain + 1`` of its ``depthT`` steps and replicates the result.  Returns 0 ("unknown",
+    run every step) if the table is not acyclic or is not host data."""
+    import numpy as np
+    if isinstance(bgraph, torch.Tensor):
+        if bgraph.is_cuda:
+            return 0
+        bgraph = bgraph.numpy()
+    bg = np.asarray(bgraph)
+    if bg.ndim != 2 or bg.shape[0] <= 1:
+        return 0
+    mask = bg > 0
+    has = mask.any(axis=1)
+    d = np.zeros(bg.shape[0], dtype=np.int64)
+    for _ in range(bg.shape[0] + 1):
+        nd = np.where(has, 1 + (d[bg] * mask).max(axis=1), 1)
+        nd[0] = 0
+        if np.array_equal(nd, d):
+            return int(d.max())
+        d = nd
+    return 0            # never settled: a cycle
+
+
 def make_cuda(tensors):
-    """(tree_tensors, graph_tensors) -> int64 device tensors, host ``scope`` list kept last."""
+    """(tree_tensors, graph_tensors) -> int64 device tensors, host ``scope`` list kept last.  While the predecessor
+    table is still host data its longest dependency chain is measured and rides along as an attribute of the device
+    tensor (``ggpm_chain``), which lets the encoder stop the tree-side levels at their fixed point."""
     tree_tensors, graph_tensors = tensors
+    chain = tree_chain_length(tree_tensors[3]) if len(tree_tensors) > 4 else 0
     tree_tensors = [make_tensor(x).long() for x in tree_tensors[:-1]] + [tree_tensors[-1]]
     graph_tensors = [make_tensor(x).long() for x in graph_tensors[:-1]] + [graph_tensors[-1]]
+    if chain and isinstance(tree_tensors[3], torch.Tensor):
+        tree_tensors[3].ggpm_chain = chain
     return tree_tensors, graph_tensors

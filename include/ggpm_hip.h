@@ -302,6 +302,12 @@ typedef struct ggpm_enc_dims {
     int N1t, E1t, Kt_a, Kt_b, Kt_c;      /* motif tree: nodes+1, messages+1, agraph / bgraph / cgraph widths */
     int B;                               /* molecules */
     int rnn_type;                        /* 0 GRU, 1 LSTM */
+    int tree_chain;                      /* longest dependency chain among the motif-tree messages of this batch (message
+                                            u->v depends on the messages w->u, w != v), or 0 if unknown.  The tree is
+                                            acyclic, so after that many steps every message has reached its fixed point:
+                                            the two tree-side levels then run tree_chain + 1 of their depthT steps and
+                                            replicate the last stash slot -- bit-identical to running all of them
+                                            (ggpm/rnn.py:41-50 iterates a fixed depth regardless). */
 } ggpm_enc_dims;
 size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims);
 size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims);

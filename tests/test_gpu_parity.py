@@ -539,6 +539,33 @@ def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
         assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("name", ["cfg_gru_s0", "cfg_lstm_s2", "tiny_gru_s1", "edge_gru_s32"])
+def test_tree_fixed_point_shortcut_is_bit_identical(name):
+    """With the longest dependency chain of the tree messages known (make_cuda measures it on the host), the tree-side
+    levels run chain + 1 of their depthT steps and replicate the last stash slot; outputs and every gradient must be
+    BITWISE what the full depth loop gives (same tensors without the hint)."""
+    from ggpm_amd.nnutils import make_cuda
+    g = Golden(name)
+    res = []
+    for keep_hint in (True, False):
+        model = _build_encoder(g)
+        tree, graph = make_cuda(g.numpy_tensors())
+        chain = getattr(tree[3], "ggpm_chain", 0)
+        assert chain > 0
+        if not keep_hint:
+            del tree[3].ggpm_chain
+        outs = model.encoder.forward_padded(tree, graph)
+        coeffs = [torch.from_numpy(c).to(_dev()) for c in g.loss_coeffs([(o.shape[0], g.H) for o in outs])]
+        sum((c * o[:, :g.H]).sum() for c, o in zip(coeffs, outs)).backward()
+        res.append(([o.detach().clone() for o in outs], {k: v.grad.clone() for k, v in model.encoder.named_parameters()}))
+    if name.startswith("cfg"):
+        assert chain + 1 < g.depthT          # the shortcut really was taken
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_device_prefetcher_feeds_the_encoder():
     """N3: one pinned staging buffer + one async copy per batch on a copy stream; same tensors as make_cuda, and the
     encoder consumes them (results equal to the make_cuda path)."""

@@ -184,3 +184,32 @@ def test_oracle_score_heads_match_reference(name):
     for k, t in p.items():
         if t.grad is not None:
             g.check_grad(k, t.grad.numpy(), 1e-4)
+
+
+def test_tree_chain_length_matches_the_fixed_point_of_the_oracle():
+    """nnutils.tree_chain_length: after `chain` steps of the reference recurrence no tree message changes any more (and
+    it still changes at step `chain`), a table with a cycle reports 0."""
+    import numpy as np
+    from ggpm_amd import synth
+    from ggpm_amd.nnutils import tree_chain_length
+    for seed, motifs in ((0, (2, 6)), (1, (8, 12)), (2, (1, 1)), (3, (1, 3))):
+        specs = synth.random_batch(seed, 5, motifs=motifs, n_motif_vocab=11, n_attach_vocab=33)
+        tree, _ = synth.tensorize(specs)
+        bg = np.asarray(tree[3])
+        chain = tree_chain_length(bg)
+        # brute force: propagate "generation" sets -- message values as random hashes of (own id, predecessor values)
+        rs = np.random.RandomState(seed)
+        x = rs.standard_normal(bg.shape[0])
+        h = np.zeros(bg.shape[0])
+        last_change = 0
+        for t in range(1, bg.shape[0] + 3):
+            nh = np.tanh(x + (h[bg] * (bg > 0)).sum(axis=1))
+            nh[0] = 0
+            if not np.array_equal(nh, h):
+                last_change = t
+            h = nh
+        assert chain == last_change, (seed, chain, last_change)
+    cyc = np.array([[0, 0], [2, 0], [1, 0]])          # 1 <- 2 <- 1
+    assert tree_chain_length(cyc) == 0
+    import torch
+    assert tree_chain_length(torch.from_numpy(bg)) == chain
