@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="diagnostic: every step takes its batch from HOST memory through ggpm_amd.dataloader."
                          "DevicePrefetcher (pinned staging + async copy); the PCIe-inclusive rate, never `value`")
+    ap.add_argument("--no-full-depth", action="store_true",
+                    help="skip the extra timed pass without the tree fixed-point hint (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -268,7 +270,7 @@ def main():
     # tree messages; with it the two tree-side levels stop at their fixed point, bit-identical results): every level
     # runs all `depth` launches.  Reported beside `value`, never instead of it.
     full_elapsed = None
-    if host_iter is None and any(hasattr(t[0][3], "ggpm_chain") for t in dev_batches):
+    if host_iter is None and not a.no_full_depth and any(hasattr(t[0][3], "ggpm_chain") for t in dev_batches):
         hinted = dev_batches
         dev_batches = [(list(tree[:3]) + [tree[3].view_as(tree[3])] + list(tree[4:]), graph) for tree, graph in hinted]
         for i in range(min(a.warmup, 4)):

@@ -86,18 +86,27 @@ class DevicePrefetcher:
         return buf[:total]
 
     def _upload(self, slot: int, tensors):
+        from .nnutils import tree_chain_length
         arrays, layout, total = batch_layout(tensors)
         tscope, gscope = tensors[0][-1], tensors[1][-1]
+        chain = tree_chain_length(tensors[0][3])         # host data here: lets the tree-side levels stop at their fixed point
         host = self._stage(slot, total)
         pack_into(host.numpy(), arrays, layout)          # straight into the (pinned) staging buffer
+
+        def views(flat):
+            tree, graph = unpack_views(flat, layout, tscope, gscope)
+            if chain:
+                tree[3].ggpm_chain = chain
+            return tree, graph
+
         if not self.cuda:
-            return unpack_views(host.clone(), layout, tscope, gscope), None
+            return views(host.clone()), None
         with torch.cuda.stream(self.stream):
             dev = host.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._staging_events[slot] = ev
-        return unpack_views(dev, layout, tscope, gscope), (ev, dev)
+        return views(dev), (ev, dev)
 
     def __iter__(self) -> Iterator:
         pending = []
