@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- molecules/s of the hierarchical encoder training step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rnn GRU|LSTM]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0..4] [--rnn GRU|LSTM]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic random-motif molecules (~40 atoms, motif vocab 500),
-hidden = embed = 300, depthT = depthG = 20, batch 32 per GPU, fp32.  One "step" = zero_grad + HierMPNEncoder
-forward + KL heads + backward (+ gradient all-reduce over RCCL for N > 1) + Adam update on one batch of 32
-molecules whose tensorized index tensors are already resident in HBM.  Rank r consumes its own stream of
-batches (weak scaling: per-GPU work fixed); value = all molecules processed by all ranks / max-over-ranks time.
+Default workload = BASELINE.json configs[1]: synthetic random-motif molecules (~40 atoms, motif vocab 500),
+hidden = embed = 300, depthT = depthG = 20, batch 32 per GPU, fp32, GRU message function (the LSTM run of the same
+workload is reported in the same line under "lstm").  ``--config N`` selects configs[N] of BASELINE.json (CONFIGS
+below).  One "step" = zero_grad + HierMPNEncoder forward + KL heads + backward (+ gradient all-reduce over RCCL for
+N > 1) + Adam update on one batch whose tensorized index tensors are already resident in HBM.  Rank r consumes its own
+stream of batches (weak scaling: per-GPU work fixed); value = all molecules processed by all ranks / max-over-ranks
+time.
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
-  "roofline"     -- the dominant kernel (fused depth step) timed with HIP events on its own stream,
-                    ALGORITHMIC flops per launch / mean launch time vs the fp32 MFMA peak;
-  "cpu_baseline" -- the oracle (padded reference op order, PyTorch CPU) timed on this box's host cores on a
-                    bounded sample of the same batches (rank 0, N = 1 only).
+  "roofline"     -- the dominant kernel (the fused depth step of the ATOM level: one 16-wave workgroup per CU) timed with
+                    HIP events on its own stream, ALGORITHMIC flops per launch / mean launch time vs the fp32 MFMA
+                    peak; the same kernel's launches on the two small tree-side levels are reported beside it
+                    ("tree_levels"), never averaged into it;
+  "cpu_baseline" -- the oracle (padded reference op order, PyTorch CPU) timed on this box's host cores on a bounded
+                    sample of the same batches (rank 0, N = 1 only; BASELINE.md section 3 protocol: 2 warm-up steps,
+                    >= 10 timed, median, all cores and 8 threads, CPU model stated).
 """
 from __future__ import annotations
 
@@ -39,6 +44,23 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBS = 8000.0
 
+# BASELINE.json configs[i] -> concrete synthetic workload (C1..C5).  `gen`: motifs-per-molecule
+# range of ggpm_amd.synth.random_molecule, or "mix" = the chem-trio size mix (synth.SIZE_MIX, true proportions).
+CONFIGS = {
+    0: dict(tag="configs[0]: pretrained_wo_tie_embedding shape on HOPV-15-sized synthetic molecules", rnn="LSTM",
+            hidden=250, depth=20, latent=24, batch=20, vocab=(721, 6214), gen=(6, 14)),
+    1: dict(tag="configs[1]: synthetic random-motif graphs (~40 atoms)", rnn="GRU", hidden=300, depth=20, latent=32,
+            batch=32, vocab=(500, 1500), gen=(8, 12)),
+    2: dict(tag="configs[2]: QM9-shaped synthetic molecules (1-3 motifs, ~9 atoms; data/qm9 is a missing blob)",
+            rnn="GRU", hidden=300, depth=20, latent=32, batch=64, vocab=(500, 1500), gen=(1, 3)),
+    3: dict(tag="configs[3]: pretrained_600_hidden_w_tie_embedding shape, chem-trio size mix, one GPU's shard of 32x8",
+            rnn="LSTM", hidden=600, depth=20, latent=24, batch=32, vocab=(721, 6214), gen="mix"),
+    4: dict(tag="configs[4]: synthetic large polymers (~200 atoms), one GPU's shard", rnn="GRU", hidden=600, depth=30,
+            latent=32, batch=32, vocab=(500, 1500), gen=(46, 58)),
+}
+KERNELS = ["gru_fwd_a", "gru_bwd_a", "lstm_fwd_a", "lstm_bwd_a", "gru_fwd_b", "gru_bwd_b", "lstm_fwd_b", "lstm_bwd_b"]
+LEVEL_TAGS = {1: "atom", 2: "attachment", 3: "motif"}
+
 
 class _Vocab:
     def __init__(self, n):
@@ -61,28 +83,43 @@ def make_args(rnn, hidden, depth, latent, n_motif, n_attach):
     return a
 
 
-def make_batches(n_batches, batch_size, seed0, motifs, n_motif, n_attach):
+def make_batches(n_batches, batch_size, seed0, gen, n_motif, n_attach):
     from ggpm_amd import synth
     out = []
     for i in range(n_batches):
-        specs = synth.random_batch(seed0 + i, batch_size, motifs=motifs, n_motif_vocab=n_motif,
-                                   n_attach_vocab=n_attach)
+        if gen == "mix":
+            specs = synth.size_mix_batch(seed0 + i, batch_size, one_of_each=False, n_motif_vocab=n_motif,
+                                         n_attach_vocab=n_attach)
+        else:
+            specs = synth.random_batch(seed0 + i, batch_size, motifs=tuple(gen), n_motif_vocab=n_motif,
+                                       n_attach_vocab=n_attach)
         out.append(synth.tensorize(specs))
     return out
 
 
-def algorithmic_work(batches, H, depth, gates):
-    """FLOPs_fwd(level) = D*2*G*E*H^2 (+ small terms); fwd+bwd = 3x."""
+def algorithmic_work(batches, H, depth, gates, chains=None):
+    """FLOPs_fwd(level) = D*2*G*E*H^2 (+ small terms); fwd+bwd = 3x.
+
+    -> (full-depth flops per step, executed flops per step, atoms per batch).  "Executed" credits the tree-side levels
+    only with the depth steps the fixed-point shortcut really issues (chain + 1 forward, chain backward steps)."""
     from ggpm_amd import synth
-    fl = 0.0
+    full = execd = 0.0
     atoms = 0
-    for tree, graph in batches:
+    for i, (tree, graph) in enumerate(batches):
         st = synth.batch_stats(tree, graph)
+        c = chains[i] if chains else 0
         for lvl, I, Fd in (("atom", 62, 38), ("tree", H + 20, H), ("tree", H + 20, H)):
             E, N = st[lvl]["E"], st[lvl]["N"]
-            fl += depth * 2.0 * gates * E * H * H + 2.0 * gates * E * I * H + 2.0 * N * (Fd + H) * H
+            gate = 2.0 * gates * E * H * H
+            small = 2.0 * gates * E * I * H + 2.0 * N * (Fd + H) * H
+            full += 3.0 * (depth * gate + small)
+            if lvl == "tree" and 0 < c:
+                execd += (min(depth, c + 1) + 2.0 * min(depth, c)) * gate + 3.0 * small
+            else:
+                execd += 3.0 * (depth * gate + small)
         atoms += st["atom"]["N"]
-    return 3.0 * fl / len(batches), atoms / len(batches)
+    n = len(batches)
+    return full / n, execd / n, atoms / n
 
 
 def host_cores():
@@ -105,7 +142,18 @@ def host_cores():
                 n = min(n, max(1, q // per))
         except Exception:
             pass
-    return max(1, min(n, int(os.environ.get("GGPM_CPU_THREADS", "16"))))
+    return max(1, min(n, int(os.environ.get("GGPM_CPU_THREADS", "64"))))
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def log(msg):
@@ -115,39 +163,219 @@ def log(msg):
 _T0 = time.time()
 
 
-def cpu_baseline(batches, rnn, H, depth, latent, n_motif, n_attach, budget_s=20.0, max_steps=6):
-    """Oracle (reference op order, PyTorch CPU, all host cores) fwd+bwd on the first batches."""
+def cpu_baseline(batches, rnn, H, depth, latent, n_motif, n_attach, budget_s=24.0, warm=2, timed=10):
+    """Oracle (reference op order, PyTorch CPU) fwd+bwd on the first batches; BASELINE.md section 3: 2 warm-up + >= 10
+    timed steps, median, with all host cores and with 8 threads.  Bounded: a thread setting stops early once it has
+    used its share of `budget_s` (large configs), and says so in `sample`."""
     from oracle import ref_encoder as ref
     from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
-    cores = host_cores()
-    torch.set_num_threads(cores)
     sd = seeded_state_dict(encoder_param_shapes(rnn, H, n_motif, n_attach), 0)
     sd.update(seeded_state_dict(vae_head_shapes(H, latent), 7))
     p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
-    times, mols = [], 0
-    t_begin = time.time()
-    for i, (tree, graph) in enumerate(batches[:max_steps + 1]):
-        tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
-        t0 = time.time()
-        outs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
-        _, kl = ref.rsample_kl(p, outs[0])
-        loss = 0.1 * kl + 1e-3 * sum(o.sum() for o in outs)
-        for v in p.values():
-            v.grad = None
+    B = len(batches[0][0][-1])
+    ts = [(ref.to_long_tensors(tree), ref.to_long_tensors(graph)) for tree, graph in batches]
+
+    def run(threads, share):
+        torch.set_num_threads(threads)
+        times, t_begin = [], time.time()
+        for i in range(warm + timed):
+            tt, gt = ts[i % len(ts)]
+            t0 = time.time()
+            outs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
+            _, kl = ref.rsample_kl(p, outs[0])
+            loss = 0.1 * kl + 1e-3 * sum(o.sum() for o in outs)
+            for v in p.values():
+                v.grad = None
+            loss.backward()
+            dt = time.time() - t0
+            if i >= warm or (time.time() - t_begin > share and i >= 1):
+                times.append(dt)
+            if time.time() - t_begin > share and len(times) >= 2:
+                break
+        log("cpu baseline %s, %d threads: %d timed steps, median %.3f s" % (rnn, threads, len(times), np.median(times)))
+        return float(np.median(times)), len(times)
+
+    cores = host_cores()
+    med_all, n_all = run(cores, 0.6 * budget_s)
+    out = {"value": round(B / med_all, 2), "unit": "molecules/s", "cores": cores, "kind": "port",
+           "cpu_model": cpu_model(),
+           "sample": "oracle/ref_encoder.py (reference padded op order, torch CPU) fwd+bwd of batch %d: %d warm-up + %d "
+                     "timed steps, median %.3f s, %d threads" % (B, warm, n_all, med_all, cores)}
+    if cores != 8:
+        med8, n8 = run(min(8, cores), 0.4 * budget_s)
+        out["threads_8"] = {"value": round(B / med8, 2), "cores": min(8, cores), "timed_steps": n8,
+                            "median_step_s": round(med8, 4)}
+    torch.set_num_threads(cores)
+    return out
+
+
+class Workload:
+    """One (config, message function) pair on this rank: model, optimizer, device-resident batches."""
+
+    def __init__(self, cfg, rnn, a, rank, world, dev):
+        from ggpm_amd.nnutils import make_cuda
+        from ggpm_amd.parallel import FlatGradSync, broadcast_parameters
+        from ggpm_amd.property_vae import HierEncoderVAE
+        self.cfg, self.rnn, self.a, self.world, self.dev = cfg, rnn, a, world, dev
+        n_motif, n_attach = cfg["vocab"]
+        # rank r draws the batches r, r+W, ... of the seed-indexed synthetic set (10 000 molecules = 313 batches)
+        self.pool = make_batches(a.pool, cfg["batch"], seed0=1000 + rank * 313, gen=cfg["gen"], n_motif=n_motif,
+                                 n_attach=n_attach)
+        self.dev_batches = [make_cuda(b) for b in self.pool]      # int64 index tensors resident in HBM before timing
+        torch.manual_seed(0)
+        self.model = HierEncoderVAE(make_args(rnn, cfg["hidden"], cfg["depth"], cfg["latent"], n_motif, n_attach)).to(dev)
+        for p in self.model.parameters():                       # vae_train.py:48-53
+            if p.dim() == 1:
+                torch.nn.init.constant_(p, 0)
+            else:
+                torch.nn.init.xavier_normal_(p)
+        broadcast_parameters(self.model)
+        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        self.host_iter = None
+        if a.host_input:
+            import itertools
+            from ggpm_amd.dataloader import DevicePrefetcher
+            self.host_iter = iter(DevicePrefetcher(itertools.cycle(self.pool), device=dev, depth=2))
+
+    def step(self, i):
+        from ggpm_amd.property_vae import rsample
+        m = self.model
+        tree, graph = next(self.host_iter) if self.host_iter is not None else self.dev_batches[i % len(self.dev_batches)]
+        self.sync.zero_grad()
+        hroot, hnode, hinter, hatom = m.encoder.forward_padded(tree, graph)
+        _, kl = rsample(hroot, m.R_mean, m.R_var, perturb=False)
+        loss = 0.1 * kl + 1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() + hatom.sum())
         loss.backward()
-        dt = time.time() - t0
-        log("cpu baseline step %d: %.2f s" % (i, dt))
-        if i > 0:           # first step is warm-up
-            times.append(dt)
-            mols += len(tree[-1])
-        if time.time() - t_begin > budget_s and len(times) >= 2:
-            break
-    if not times:
-        return None
-    return {"value": round(mols / sum(times), 2), "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": "%d fwd+bwd steps of batch %d after 1 warm-up, oracle/ref_encoder.py (reference padded op "
-                      "order, torch CPU %d threads), median step %.3f s" % (len(times), len(batches[0][0][-1]),
-                                                                            cores, float(np.median(times)))}
+        self.sync.all_reduce()
+        self.opt.step()
+        return loss
+
+    def fence(self):
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(self, steps, first):
+        """EXACTLY `steps` steps between two fences; max over ranks.  -> (elapsed s, host enqueue s)"""
+        import torch.distributed as dist
+        self.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(first + i)
+        host = time.perf_counter() - t0
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, host
+
+    def measure(self, lib, rank):
+        a, cfg = self.a, self.cfg
+        H, depth, batch = cfg["hidden"], cfg["depth"], cfg["batch"]
+        log("%s: model + %d batches resident; warm-up" % (self.rnn, len(self.dev_batches)))
+        for i in range(a.warmup):
+            self.step(i)
+            if i == 0:
+                torch.cuda.synchronize()
+                log("first step done")
+        log("warm-up done; timing %d steps" % a.steps)
+        elapsed, host_enqueue = self.timed(a.steps, a.warmup)
+        log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,
+                                                                             1e3 * host_enqueue / a.steps))
+        chains = [int(getattr(t[0][3], "ggpm_chain", 0)) for t in self.dev_batches]
+        # The same K steps once more WITHOUT the fixed-point hint (make_cuda measures the longest dependency chain of
+        # the tree messages; with it the two tree-side levels stop at their fixed point, forward and backward,
+        # bit-identical outputs): every level runs all `depth` launches both ways.  Reported beside `value`.
+        full_elapsed = None
+        if self.host_iter is None and not a.no_full_depth and any(chains):
+            hinted = self.dev_batches
+            self.dev_batches = [(list(tree[:3]) + [tree[3].view_as(tree[3])] + list(tree[4:]), graph) for tree, graph in hinted]
+            for i in range(min(a.warmup, 4)):
+                self.step(i)
+            full_elapsed, _ = self.timed(a.steps, a.warmup)
+            self.dev_batches = hinted
+            log("without the tree fixed-point hint: %.3f ms/step" % (1e3 * full_elapsed / a.steps))
+        gates = 3 if self.rnn == "GRU" else 4
+        fl_full, fl_exec, atoms = algorithmic_work(self.pool, H, depth, gates, chains)
+        mols = a.steps * batch * self.world
+        res = {"ms_per_step": round(1e3 * elapsed / a.steps, 4), "value": round(mols / elapsed, 2),
+               "unit": "molecules/s", "rnn_type": self.rnn,
+               "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 4),
+               "algorithmic_gflop_per_step_per_gpu": round(fl_full / 1e9, 2),
+               "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
+               # executed flops over the measured time: the tree-side levels are credited only with the depth steps
+               # the fixed-point shortcut really issues
+               "step_tflops_executed": round(fl_exec * self.world / (elapsed / a.steps) / 1e12, 3),
+               "atoms_per_molecule": round(atoms / batch, 1)}
+        if full_elapsed is not None:
+            res["tree_fixed_point"] = (
+                "motif-tree messages settle after their longest dependency chain C (%d-%d in these batches): the two "
+                "tree-side levels run C+1 of the %d forward and C of the %d backward steps; outputs bit-identical to the "
+                "full loops, gradients to fp32 summation order (tests/test_gpu_parity.py::"
+                "test_tree_fixed_point_shortcut_is_bit_identical)" % (min(chains), max(chains), depth, depth))
+            res["full_depth_loops"] = {"ms_per_step": round(1e3 * full_elapsed / a.steps, 4),
+                                       "value": round(mols / full_elapsed, 2), "unit": "molecules/s",
+                                       "step_tflops_algorithmic": round(fl_full * self.world / (full_elapsed / a.steps) / 1e12, 3)}
+        if not a.no_roofline:
+            roof = self.roofline(lib)
+            if roof and rank == 0:
+                res["roofline"] = roof
+        return res
+
+    def roofline(self, lib):
+        """Second, instrumented pass over the same steps: HIP events recorded on the launch stream around every fused
+        depth-step launch (not part of `value`), per kernel kind and per level."""
+        from ggpm_amd.property_vae import rsample
+        a, m = self.a, self.model
+
+        def eager_step(i):
+            tree, graph = self.dev_batches[i % len(self.dev_batches)]
+            for p in m.parameters():
+                p.grad = None
+            hroot, hnode, hinter, hatom = m.encoder.forward_padded(tree, graph)
+            _, kl = rsample(hroot, m.R_mean, m.R_var, perturb=False)
+            (0.1 * kl + 1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() + hatom.sum())).backward()
+
+        eager_step(0)
+        torch.cuda.synchronize()
+        lib.ggpm_timing_enable(1)
+        for i in range(min(a.steps, 4)):
+            eager_step(i)
+        torch.cuda.synchronize()
+        lib.ggpm_timing_enable(0)
+        per = {}
+        for tag, lname in LEVEL_TAGS.items():
+            for which, kname in enumerate(KERNELS):
+                n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+                lib.ggpm_timing_collect(which + 8 * tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+                if n.value:
+                    per.setdefault(lname, {})[kname] = {
+                        "launches": n.value, "avg_launch_us": round(1e3 * ms.value / n.value, 3),
+                        "gflop_per_launch": round(fl.value / n.value / 1e9, 4),
+                        "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 3),
+                        "frac": round(fl.value / (ms.value * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                        "total_ms": round(ms.value, 3)}
+        if "atom" not in per:
+            return None
+        kname = max(per["atom"], key=lambda k: per["atom"][k]["total_ms"])      # dominant kernel of the step
+        k = per["atom"][kname]
+        traffic = None
+        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(self.rnn, {}).get(kname)
+        except Exception:
+            pass
+        tree = {lv: per[lv][kname] for lv in ("attachment", "motif") if kname in per.get(lv, {})}
+        return {"kernel": kname, "level": "atom (one 16-wave workgroup per 16 messages, all gate columns)",
+                "bound": "mfma", "achieved": k["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": k["frac"], "traffic": traffic, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
+                "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "tree_levels": tree,
+                "all_depth_kernels": per}
 
 
 def main():
@@ -157,11 +385,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=16,
                     help="untimed steps; 16 = one pass over the pool of pre-tensorized batches, so that every batch shape has "
                          "been seen (allocator blocks, lazily created streams and events) before the timed region")
-    ap.add_argument("--rnn", default="GRU", choices=["GRU", "LSTM"])
-    ap.add_argument("--hidden", type=int, default=300)
-    ap.add_argument("--depth", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs[]")
+    ap.add_argument("--rnn", default=None, choices=["GRU", "LSTM"], help="message function (default: the config's)")
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--latent", type=int, default=None)
     ap.add_argument("--pool", type=int, default=16, help="distinct pre-tensorized batches per rank (cycled)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--host-input", action="store_true",
@@ -169,9 +398,18 @@ def main():
                          "DevicePrefetcher (pinned staging + async copy); the PCIe-inclusive rate, never `value`")
     ap.add_argument("--no-full-depth", action="store_true",
                     help="skip the extra timed pass without the tree fixed-point hint (profiling runs)")
+    ap.add_argument("--no-second-cell", action="store_true",
+                    help="skip the run of the other message function (configs[1] reports GRU and, under \"lstm\", LSTM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k in ("hidden", "depth", "batch", "latent"):
+        if getattr(a, k) is not None:
+            cfg[k] = getattr(a, k)
+    rnn = a.rnn or cfg["rnn"]
+    if a.config == 4:
+        a.pool = min(a.pool, 4)          # ~15 K atom messages per batch: keep tensorizing (host, untimed) short
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,173 +435,59 @@ def main():
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from ggpm_amd import _lib
-    from ggpm_amd.encoder import PreparedBatch
-    from ggpm_amd.nnutils import make_cuda
-    from ggpm_amd.parallel import FlatGradSync, broadcast_parameters
-    from ggpm_amd.property_vae import HierEncoderVAE, rsample
     lib = _lib.load(build_if_missing=False)
 
-    n_motif, n_attach, motifs = 500, 1500, (8, 12)
-    # rank r draws the batches r, r+W, ... of the seed-indexed synthetic set (10 000 molecules = 313 batches)
-    pool = make_batches(a.pool, a.batch, seed0=1000 + rank * 313, motifs=motifs, n_motif=n_motif, n_attach=n_attach)
-    dev_batches = [make_cuda(b) for b in pool]      # int64 index tensors resident in HBM before timing
-
-    torch.manual_seed(0)
-    model = HierEncoderVAE(make_args(a.rnn, a.hidden, a.depth, a.latent, n_motif, n_attach)).to(dev)
-    for p in model.parameters():                       # vae_train.py:48-53
-        if p.dim() == 1:
-            torch.nn.init.constant_(p, 0)
-        else:
-            torch.nn.init.xavier_normal_(p)
-    broadcast_parameters(model)
-    H = a.hidden
-    sync = FlatGradSync(model.parameters(), encoder=model.encoder)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-
-    host_iter = None
-    if a.host_input:
-        import itertools
-        from ggpm_amd.dataloader import DevicePrefetcher
-        host_iter = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, depth=2))
-
-    def step(i):
-        tree, graph = next(host_iter) if host_iter is not None else dev_batches[i % len(dev_batches)]
-        sync.zero_grad()
-        hroot, hnode, hinter, hatom = model.encoder.forward_padded(tree, graph)
-        _, kl = rsample(hroot, model.R_mean, model.R_var, perturb=False)
-        loss = 0.1 * kl + 1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() + hatom.sum())
-        loss.backward()
-        sync.all_reduce()
-        opt.step()
-        return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    log("model + %d batches resident; warm-up" % len(dev_batches))
-    for i in range(a.warmup):
-        step(i)
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
-    sync.check_views()
-    fence()
-    log("warm-up done; timing %d steps" % a.steps)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    host_enqueue = time.perf_counter() - t0     # host time to enqueue K steps (diagnostic: host- vs GPU-bound)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,
-                                                                         1e3 * host_enqueue / a.steps))
-
-    # The same K steps once more WITHOUT the fixed-point hint (make_cuda measures the longest dependency chain of the
-    # tree messages; with it the two tree-side levels stop at their fixed point, bit-identical results): every level
-    # runs all `depth` launches.  Reported beside `value`, never instead of it.
-    full_elapsed = None
-    if host_iter is None and not a.no_full_depth and any(hasattr(t[0][3], "ggpm_chain") for t in dev_batches):
-        hinted = dev_batches
-        dev_batches = [(list(tree[:3]) + [tree[3].view_as(tree[3])] + list(tree[4:]), graph) for tree, graph in hinted]
-        for i in range(min(a.warmup, 4)):
-            step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            step(a.warmup + i)
-        fence()
-        full_elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([full_elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            full_elapsed = float(t.item())
-        dev_batches = hinted
-        log("without the tree fixed-point hint: %.3f ms/step" % (1e3 * full_elapsed / a.steps))
-    flops_step, atoms = algorithmic_work(pool, H, a.depth, 3 if a.rnn == "GRU" else 4)
-    mols = a.steps * a.batch * world
+    main_wl = Workload(cfg, rnn, a, rank, world, dev)
+    m = main_wl.measure(lib, rank)
+    n_motif, n_attach = cfg["vocab"]
     result = {
-        "metric": "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32) -- HierMPNEncoder fwd+bwd target row",
-        "value": round(mols / elapsed, 2), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True,
+        "metric": "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32) -- HierMPNEncoder fwd+bwd target row "
+                  "(encoder + KL heads + optimizer)",
+        "value": m["value"], "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" + (" (host-resident batches, PCIe-inclusive diagnostic)" if a.host_input else ""),
-        "config": {"workload": "BASELINE configs[1]: synthetic random-motif graphs, %.1f atoms/molecule, motif vocab "
-                               "%d/%d, hidden=%d depth=%d batch=%d per GPU, %s cell; step = zero_grad + encoder "
-                               "fwd + KL + bwd%s + Adam" % (atoms / a.batch, n_motif, n_attach, H, a.depth, a.batch,
-                                                             a.rnn, " + RCCL all-reduce" if world > 1 else ""),
-                   "rnn_type": a.rnn, "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                   "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2)},
-        "step_tflops_algorithmic": round(flops_step * world / (elapsed / a.steps) / 1e12, 3),
+        "config": {"workload": "BASELINE %s: %.1f atoms/molecule, motif vocab %d/%d, hidden=%d depth=%d latent=%d "
+                               "batch=%d per GPU, %s cell; step = zero_grad + encoder fwd + KL + bwd%s + Adam"
+                               % (cfg["tag"], m["atoms_per_molecule"], n_motif, n_attach, cfg["hidden"], cfg["depth"],
+                                  cfg["latent"], cfg["batch"], rnn, " + RCCL all-reduce" if world > 1 else ""),
+                   "baseline_config_index": a.config, "rnn_type": rnn, "global_batch": cfg["batch"] * world,
+                   "parallelism": "dp%d" % world,
+                   "algorithmic_gflop_per_step_per_gpu": m["algorithmic_gflop_per_step_per_gpu"],
+                   "executed_gflop_per_step_per_gpu": m["executed_gflop_per_step_per_gpu"]},
+        "host_enqueue_ms_per_step": m["host_enqueue_ms_per_step"],
+        "step_tflops_executed": m["step_tflops_executed"],
     }
-    chains = [getattr(t[0][3], "ggpm_chain", 0) for t in dev_batches]
-    if full_elapsed is not None:
-        result["config"]["tree_fixed_point"] = (
-            "motif-tree messages settle after their longest dependency chain (%d-%d steps in these batches); the two "
-            "tree-side levels run chain+1 of the %d steps and replicate the last stash slot, outputs and gradients "
-            "bit-identical to the full loops (tests/test_gpu_parity.py::test_tree_fixed_point_shortcut_is_bit_identical)"
-            % (min(chains), max(chains), a.depth))
-        result["full_depth_loops"] = {"ms_per_step": round(1e3 * full_elapsed / a.steps, 4),
-                                      "value": round(mols / full_elapsed, 2), "unit": "molecules/s"}
+    for k in ("full_depth_loops", "roofline"):
+        if k in m:
+            result[k] = m[k]
+    if "tree_fixed_point" in m:
+        result["config"]["tree_fixed_point"] = m["tree_fixed_point"]
 
-    # ---- roofline of the dominant kernel: a second, instrumented pass over the same steps (HIP events
-    # recorded on the launch stream around every fused depth-step launch; not part of `value`).
-    if not a.no_roofline:
-        def eager_step(i):      # instrumented launches are issued eagerly (HIP events bracket each one)
-            tree, graph = dev_batches[i % len(dev_batches)]
-            for p in model.parameters():
-                p.grad = None
-            hroot, hnode, hinter, hatom = model.encoder.forward_padded(tree, graph)
-            _, kl = rsample(hroot, model.R_mean, model.R_var, perturb=False)
-            (0.1 * kl + 1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() + hatom.sum())).backward()
-
-        eager_step(0)
-        torch.cuda.synchronize()
-        lib.ggpm_timing_enable(1)
-        nprobe = min(a.steps, 4)
-        for i in range(nprobe):
-            eager_step(i)
-        torch.cuda.synchronize()
-        lib.ggpm_timing_enable(0)
-        names = ["gru_fwd_a", "gru_bwd_a", "lstm_fwd_a", "lstm_bwd_a", "gru_fwd_b", "gru_bwd_b", "lstm_fwd_b",
-                 "lstm_bwd_b"]
-        per_kernel, best = {}, None
-        for which, kname in enumerate(names):
-            n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-            lib.ggpm_timing_collect(which, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
-            if n.value:
-                per_kernel[kname] = {"launches": n.value, "avg_launch_us": round(1e3 * ms.value / n.value, 3),
-                                     "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 3)}
-                if best is None or ms.value > best[2]:
-                    best = (kname, n.value, ms.value, fl.value)
-        if best and rank == 0:
-            kname, n, ms, fl = best
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    traffic = json.load(f).get(a.rnn, {}).get(kname)
-            except Exception:
-                pass
-            result["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3),
-                                  "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                                  "launches": n, "avg_launch_us": round(1e3 * ms / n, 3),
-                                  "flops_per_launch_avg": round(fl / n, 1), "all_depth_kernels": per_kernel}
+    cpu_runs = [(rnn, main_wl.pool)]
+    # the other message function on the same workload, in the same line (all 32 shipped model configs use LSTM)
+    if a.config == 1 and a.rnn is None and not a.no_second_cell and not a.host_input:
+        del main_wl
+        torch.cuda.empty_cache()
+        other = Workload(cfg, "LSTM", a, rank, world, dev)
+        mo = other.measure(lib, rank)
+        result["lstm"] = {k: mo[k] for k in ("ms_per_step", "value", "unit", "host_enqueue_ms_per_step",
+                                             "algorithmic_gflop_per_step_per_gpu", "step_tflops_executed",
+                                             "full_depth_loops", "roofline") if k in mo}
+        cpu_runs.append(("LSTM", other.pool))
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        log("roofline pass done; cpu baseline on %d threads" % host_cores())
-        try:
-            result["cpu_baseline"] = cpu_baseline(pool, a.rnn, H, a.depth, a.latent, n_motif, n_attach)
-        except Exception as exc:          # the baseline is a reported number, never a reason to lose the line
-            result["cpu_baseline"] = {"error": repr(exc)}
+        budget = 24.0 / len(cpu_runs)
+        for cell, pool in cpu_runs:
+            log("cpu baseline (%s) on %d threads" % (cell, host_cores()))
+            try:
+                cb = cpu_baseline(pool, cell, cfg["hidden"], cfg["depth"], cfg["latent"], n_motif, n_attach, budget_s=budget)
+            except Exception as exc:          # the baseline is a reported number, never a reason to lose the line
+                cb = {"error": repr(exc)}
+            if cell == rnn:
+                result["cpu_baseline"] = cb
+            else:
+                result["lstm"]["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():

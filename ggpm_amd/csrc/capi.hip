@@ -21,14 +21,20 @@ extern "C" int ggpm_padded_hidden(int H) { return ggpm_round_up(H, 16); }
 // ---------------------------------------------------------------- timing sink (debug/bench only)
 namespace {
 struct Span { hipEvent_t a, b; double flops; };
-constexpr int NCLASS = 8;
+constexpr int NKIND = 8, NTAG = 4, NCLASS = NKIND * NTAG;
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Span> g_spans[NCLASS];
+thread_local int g_tag = 0;
 }  // namespace
+
+// The whole-encoder drivers tag the launches of a level (1 atom, 2 attachment, 3 motif level; 0 = untagged) so that the
+// bench can report the atom-level launch (one workgroup per CU, MFMA bound) apart from the small latency-bound levels.
+void ggpm_timing_tag(int tag) { g_tag = (tag >= 0 && tag < NTAG) ? tag : 0; }
 
 void ggpm_timing_begin(int which, hipStream_t s, double flops) {
     if (!g_on) return;
+    which += NKIND * g_tag;
     std::lock_guard<std::mutex> lk(g_mu);
     Span sp;
     sp.flops = flops;
@@ -39,6 +45,7 @@ void ggpm_timing_begin(int which, hipStream_t s, double flops) {
 
 void ggpm_timing_end(int which, hipStream_t s) {
     if (!g_on) return;
+    which += NKIND * g_tag;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_spans[which].empty()) (void)hipEventRecord(g_spans[which].back().b, s);
 }

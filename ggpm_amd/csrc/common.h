@@ -68,7 +68,17 @@ typedef ggpm_gemm_problem GgpmGemmProblem;
 // the caller then replicates the last computed slot of every stash array (encoder.hip).  Consumed by one call.
 void ggpm_forward_run_depth(int run_depth);
 int ggpm_take_run_depth();
+// The same acyclic structure makes the Jacobian of a tree level's recurrence nilpotent: with a longest dependency chain
+// of C messages, d(h^{D-k}) is exactly zero for k >= C, so the backward of such a level only has to run its steps
+// t = D .. lo with lo = max(1, D - C + 1); every skipped launch would compute exact zeros and every skipped stash slot
+// would add exact zeros to the weight-gradient contractions.  The next dense level backward / weight-gradient call of
+// this thread stops at step `lo` (<= 1: all steps).  Consumed by one call each.
+void ggpm_backward_lo_depth(int lo);
+int ggpm_take_backward_lo();
+void ggpm_wgrad_lo_depth(int lo);
+int ggpm_take_wgrad_lo();
 
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
+void ggpm_timing_tag(int tag);       // 1 atom, 2 attachment, 3 motif level, 0 untagged; collected as which + 8 * tag
 void ggpm_timing_begin(int which, hipStream_t s, double flops);
 void ggpm_timing_end(int which, hipStream_t s);

@@ -190,16 +190,28 @@ inline int run_steps(const Dims& d, int level, int depth) {
     return d.tree_chain + 1;
 }
 
-int replicate_tail(const Dims& d, int E1, int depth, int run, const LevelSaved& L, ggpm_stream_t s) {
+// first step the backward of a tree-side level has to run: lo = max(1, D - chain + 1) (common.h: below it d(h^t) is
+// exactly zero); 1 = all steps
+inline int backward_lo(const Dims& d, int level, int depth) {
+    static const bool off = getenv("GGPM_TREE_FIXED_POINT") && atoi(getenv("GGPM_TREE_FIXED_POINT")) == 0;
+    if (off || level == 2 || d.tree_chain <= 0) return 1;
+    const int lo = depth - d.tree_chain + 1;
+    return lo < 1 ? 1 : lo;
+}
+
+int replicate_tail(const Dims& d, int E1, int depth, int run, int level, const LevelSaved& L, ggpm_stream_t s) {
     if (run >= depth) return GGPM_OK;
     const size_t slot = (size_t)E1 * d.Hp, ds = (size_t)depth * slot;
+    const int blo = backward_lo(d, level, depth);         // the backward only reads state slots >= blo, stash slots >= blo - 1
     ReplicateArgs r = {};
     int n = 0;
-    auto add = [&](float* base, int src, int lo, int hi) { r.base[n] = base; r.src[n] = src; r.lo[n] = lo; r.hi[n] = hi; ++n; };
-    add(L.Hs, run, run + 1, depth);                       // h^run == h^t for every later t
-    if (L.Cs) add(L.Cs, run, run + 1, depth);
-    add(L.Qs, run, run + 1, depth - 1);
-    for (int k = 0; k < 5; ++k) add(L.St + k * ds, run - 1, run, depth - 1);     // stash slot of step t is t - 1
+    auto add = [&](float* base, int src, int lo, int hi) {
+        r.base[n] = base; r.src[n] = src; r.lo[n] = lo > src ? lo : src + 1; r.hi[n] = hi; ++n;
+    };
+    add(L.Hs, run, blo, depth);                           // h^run == h^t for every later t
+    if (L.Cs) add(L.Cs, run, blo, depth);
+    add(L.Qs, run, blo, depth - 1);
+    for (int k = 0; k < 5; ++k) add(L.St + k * ds, run - 1, blo - 1, depth - 1);     // stash slot of step t is t - 1
     r.slot4 = slot / 4;
     dim3 grid((unsigned)ggpm_ceil_div((int)r.slot4, 256 * 4), n);
     replicate_slots_k<<<grid, 256, 0, (hipStream_t)s>>>(r);
@@ -211,6 +223,7 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp;
     const int run = run_steps(d, level, depth);
+    struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         const float* b[4] = {P[lq(level, Q_BI)], P[lq(level, Q_BOG)], P[lq(level, Q_BU)], P[lq(level, Q_BF)]};
@@ -222,7 +235,7 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
         CK(ggpm_lstm_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H,
                              W[2] + I, I + H, W[3] + I, I + H, pred.rowptr, pred.col, L.Hs, L.Cs, L.Qs, L.St, L.St + dsl,
                              L.St + 2 * dsl, L.St + 3 * dsl, L.St + 4 * dsl, L.wpack, 1, s));
-        CK(replicate_tail(d, E1, depth, run, L, s));
+        CK(replicate_tail(d, E1, depth, run, level, L, s));
         CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
         return GGPM_OK;
     }
@@ -236,7 +249,7 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
     CK(ggpm_gru_forward_tab(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
                             P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, use_tables() ? pred.tab : nullptr,
                             L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
-    CK(replicate_tail(d, E1, depth, run, L, s));
+    CK(replicate_tail(d, E1, depth, run, level, L, s));
     CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
     return GGPM_OK;
 }
@@ -451,10 +464,13 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                    float* dx, int lddx, BwdWork& w, Streams& st, int overlap_wgrads = 0) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
+    const int blo = backward_lo(d, level, depth);
+    struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         float* dW[4] = {G[lq(level, Q_WI)], G[lq(level, Q_WOG)], G[lq(level, Q_WU)], G[lq(level, Q_WF)]};
         float* db[4] = {G[lq(level, Q_BI)], G[lq(level, Q_BOG)], G[lq(level, Q_BU)], G[lq(level, Q_BF)]};
+        ggpm_backward_lo_depth(blo);
         CK(ggpm_lstm_backward(E1, H, depth, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H, W[2] + I, I + H, W[3] + I, I + H,
                               pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Cs, L.Qs, L.St, L.St + ds,
                               L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dX + 3 * slot,
@@ -466,6 +482,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             CK(ggpm_gemm_ksegments(0, E1, I, 4, A, lda, W, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
         }
         CK(st.side_after_main());
+        ggpm_wgrad_lo_depth(blo);
         CK(ggpm_lstm_weight_grads(E1, H, depth, L.Hs, L.St, level_work, w.level_work_bytes, dW[0] + I, I + H, dW[1] + I,
                                   I + H, dW[2] + I, I + H, dW[3] + I, I + H, st.w()));
         if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
@@ -513,6 +530,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             (void)hipStreamWaitEvent((hipStream_t)st.side, ev, 0);
         }
     } else {
+        ggpm_backward_lo_depth(blo);
         CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
                                  pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
                                  L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
@@ -527,6 +545,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         CK(ggpm_gemm_ksegments(0, E1, I, 3, A, lda, B, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
     }
     CK(st.side_after_main());
+    if (!overlap) ggpm_wgrad_lo_depth(blo);
     if (!overlap)
         CK(ggpm_gru_weight_grads(E1, H, depth, L.Hs, L.St, L.St + ds, level_work, w.level_work_bytes, dWz + I, I + H, dUr,
                                  H, G[lp(level, L_BU)], dWh + I, I + H, st.w()));

@@ -614,9 +614,13 @@ __global__ void sparse_init_state(const float* __restrict__ h_in, const unsigned
 }
 }  // namespace
 
-namespace { thread_local int g_run_depth = 0; }
+namespace { thread_local int g_run_depth = 0, g_bwd_lo = 0, g_wgrad_lo = 0; }
 void ggpm_forward_run_depth(int run_depth) { g_run_depth = run_depth; }
 int ggpm_take_run_depth() { const int v = g_run_depth; g_run_depth = 0; return v; }
+void ggpm_backward_lo_depth(int lo) { g_bwd_lo = lo; }
+int ggpm_take_backward_lo() { const int v = g_bwd_lo; g_bwd_lo = 0; return v; }
+void ggpm_wgrad_lo_depth(int lo) { g_wgrad_lo = lo; }
+int ggpm_take_wgrad_lo() { const int v = g_wgrad_lo; g_wgrad_lo = 0; return v; }
 
 static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
                             const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
@@ -731,7 +735,7 @@ extern "C" size_t ggpm_gru_backward_workspace_bytes(int E1, int H, int depth) {
 
 static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
                                  float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
-                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, ggpm_stream_t stream);
+                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, int lo, ggpm_stream_t stream);
 
 // depths per chunk of the overlapped weight-gradient contractions, and a small pool of re-recordable events
 constexpr int GGPM_WGRAD_CHUNK = 5;
@@ -791,7 +795,10 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     int chunk_hi = depth, n_ev = 0;
     bool first_chunk = true, dur_started = false;
-    for (int t = depth; t >= 1; --t) {
+    // tree-side levels: d(h^t) vanishes below step `lo` (nilpotent Jacobian, common.h); sparse / overlapped runs go all the way
+    int lo = ggpm_take_backward_lo();
+    if (lo < 1 || lo > depth || frozen || side_stream) lo = 1;
+    for (int t = depth; t >= lo; --t) {
         GruBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
         a.Xr = Xr;
@@ -808,7 +815,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
         a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
-        launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
+        launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);     // (the dS/dG launch of step lo > 1 still forms dXr)
         if (side_stream && !frozen) {
             // Overlapped weight gradients: the stash slots of the depths finished so far are final, so their share of
             // the three tall contractions runs on the second stream beside the rest of this (latency-bound) loop.
@@ -869,7 +876,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     }
     if (!weight_grads) return GGPM_OK;
     return gru_weight_grads_impl(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
-                                 ld_dwh, frozen != nullptr, stream);
+                                 ld_dwh, frozen != nullptr, lo, stream);
 }
 
 extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
@@ -938,10 +945,11 @@ extern "C" int ggpm_gru_sparse_backward(int E1, int H, int depth, const unsigned
 // stream while the next level's (latency-bound) depth loop occupies the main one.
 static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,
                                  float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
-                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, ggpm_stream_t stream) {
+                                 float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, int lo, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !Gs || !work || !dWz_h || !dUr || !dbu || !dWh_h)
         return GGPM_ERR_ARG;
+    if (lo < 1 || lo > depth || with_slot0) lo = 1;       // backward steps depth .. lo ran (stash slots lo-1 .. depth-1)
     if (work_bytes < ggpm_gru_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
@@ -954,16 +962,17 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
-    const int KD = depth * E1;
+    const int KD = (depth - lo + 1) * E1;
+    const size_t o1 = (size_t)(lo - 1) * slot;
     int rc;
     // the two or three contractions in ONE launch and one reduce (they share the split-K workspace)
-    ggpm_gemm_problem gp[3] = {{DMP, Hp, Gs, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
+    ggpm_gemm_problem gp[3] = {{DMP + o1, Hp, Gs + o1, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DZP + o1, Hp, Ss + o1, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
                                {nullptr, Hp, nullptr, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0}};
     int Ks[3] = {KD, KD, 0};
-    if (depth > 1 || with_slot0) {
+    if (depth > lo || with_slot0) {
         // dq^t pairs with h^t; the dense level never produces dq^0 (h^0 = 0), sparse_forward does
-        const int first_slot = with_slot0 ? 0 : 1;
+        const int first_slot = with_slot0 ? 0 : lo;
         const int KQ = (depth - first_slot) * E1;
         const float* dq0 = DQ + (size_t)first_slot * slot;
         gp[2].A = dq0;
@@ -987,5 +996,5 @@ extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, 
                                      float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr,
                                      int ld_dur, float* dbu, float* dWh_h, int ld_dwh, ggpm_stream_t stream) {
     return gru_weight_grads_impl(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h,
-                                 ld_dwh, false, stream);
+                                 ld_dwh, false, ggpm_take_wgrad_lo(), stream);
 }

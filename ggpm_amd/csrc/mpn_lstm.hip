@@ -637,7 +637,7 @@ extern "C" size_t ggpm_lstm_backward_workspace_bytes(int E1, int H, int depth) {
 
 static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
                                   size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h,
-                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, ggpm_stream_t stream);
+                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, int lo, ggpm_stream_t stream);
 
 static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
                                   const float* Wo_h, int ld_wo, const float* Wu_h, int ld_wu, const float* Wf_h,
@@ -688,7 +688,10 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
-    for (int t = depth; t >= 1; --t) {
+    // tree-side levels: d(h^t), d(c^t) vanish below step `lo` (nilpotent Jacobian, common.h)
+    int lo = ggpm_take_backward_lo();
+    if (lo < 1 || lo > depth || frozen) lo = 1;
+    for (int t = depth; t >= lo; --t) {
         LstmBwdArgs a;
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
         a.Xf = Xf;
@@ -722,7 +725,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
 
     if (!weight_grads) return GGPM_OK;
     return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
-                                  dWf_h, ld_dwf, frozen != nullptr, stream);
+                                  dWf_h, ld_dwf, frozen != nullptr, lo, stream);
 }
 
 extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,
@@ -762,10 +765,11 @@ extern "C" int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigne
 // Weight gradients of the LSTM message function from the stashes ggpm_lstm_backward left in `work`.
 static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,
                                   size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h,
-                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, ggpm_stream_t stream) {
+                                  int ld_dwu, float* dWf_h, int ld_dwf, bool with_slot0, int lo, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !work || !dWi_h || !dWo_h || !dWu_h || !dWf_h)
         return GGPM_ERR_ARG;
+    if (lo < 1 || lo > depth || with_slot0) lo = 1;       // backward steps depth .. lo ran (stash slots lo-1 .. depth-1)
     if (work_bytes < ggpm_lstm_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
@@ -778,16 +782,17 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
     w += 6 * slot + 4 * HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
-    const int KD = depth * E1;
+    const int KD = (depth - lo + 1) * E1;
+    const size_t o1 = (size_t)(lo - 1) * slot;
     int rc;
     // the three or four contractions in ONE launch and one reduce (they share the split-K workspace)
-    ggpm_gemm_problem gp[4] = {{DI, Hp, Ss, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DO, Hp, Ss, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DU, Hp, Ss, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
+    ggpm_gemm_problem gp[4] = {{DI + o1, Hp, Ss + o1, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DO + o1, Hp, Ss + o1, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {DU + o1, Hp, Ss + o1, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
                                {nullptr, Hp, nullptr, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0}};
     int Ks[4] = {KD, KD, KD, 0};
-    if (depth > 1 || with_slot0) {
-        const int first_slot = with_slot0 ? 0 : 1;     // dqf^t pairs with h^t; slot 0 exists for sparse_forward only
+    if (depth > lo || with_slot0) {
+        const int first_slot = with_slot0 ? 0 : lo;    // dqf^t pairs with h^t; slot 0 exists for sparse_forward only
         gp[3].A = DQ + (size_t)first_slot * slot;
         gp[3].B = Hs + (size_t)first_slot * slot;
         Ks[3] = (depth - first_slot) * E1;
@@ -806,5 +811,5 @@ extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs,
                                       size_t work_bytes, float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo,
                                       float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, ggpm_stream_t stream) {
     return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
-                                  dWf_h, ld_dwf, false, stream);
+                                  dWf_h, ld_dwf, false, ggpm_take_wgrad_lo(), stream);
 }

@@ -91,21 +91,32 @@ class _HierEncoder(torch.autograd.Function):
                                             P(roots), P(saved), saved_bytes, P(hroot), P(hnode), P(hinter), P(hatom),
                                             F_._stream(), side_p), "encoder_forward")
         if any(ctx.needs_input_grad):
-            ctx.dims, ctx.saved_arena, ctx.roots, ctx.params = dims, saved, roots, params
-            ctx.grad_sink = grad_sink
-            ctx.outs = (hroot, hnode, hinter, hatom)
+            # everything the backward reads goes through save_for_backward: autograd then owns the arena and the
+            # outputs (no ctx -> output -> grad_fn -> ctx cycle that would keep a 128 MiB-rounded arena alive after a
+            # forward without backward) and a second backward raises autograd's own "backward through the graph a
+            # second time" error instead of failing on a cleared attribute
+            ctx.save_for_backward(saved, roots, hroot, hnode, hinter, hatom, *params)
+            ctx.dims, ctx.grad_sink = dims, grad_sink
         return hroot, hnode, hinter, hatom
 
     @staticmethod
     def backward(ctx, d_hroot, d_hnode, d_hinter, d_hatom):
         lib = _lib.load()
-        dims, saved, roots, params = ctx.dims, ctx.saved_arena, ctx.roots, ctx.params
-        hroot, hnode, hinter, hatom = ctx.outs
+        dims = ctx.dims
+        saved, roots, hroot, hnode, hinter, hatom, *params = ctx.saved_tensors
         dev = saved.device
         sink = ctx.grad_sink() if ctx.grad_sink is not None else None
         if sink is not None and not sink.accepts(params):
             sink = None
-        if sink is not None:            # data parallel: write straight into the flat all-reduce buffer (no pack copy)
+        # The driver OVERWRITES every gradient element.  If a parameter's .grad already is its slice of the flat
+        # buffer, an earlier encoder backward of this step (gradient accumulation, the encoder called twice) has
+        # written there: run into a scratch buffer and add it on top, so that nothing is lost.
+        accumulate = sink is not None and any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                              for p, v in zip(params, sink.encoder_views))
+        if accumulate and sink.wants_early_bucket():
+            raise RuntimeError("GGPM_BUCKETED_ALLREDUCE=1 starts reducing the encoder's gradients inside its backward and "
+                               "cannot accumulate a second encoder backward in the same step")
+        if sink is not None and not accumulate:      # data parallel: write straight into the flat all-reduce buffer
             flat, grads = sink.flat, sink.encoder_views
         else:
             flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
@@ -137,7 +148,9 @@ class _HierEncoder(torch.autograd.Function):
             run(2)
         else:
             run(0)
-        ctx.saved_arena = ctx.outs = None
+        if accumulate:
+            torch._foreach_add_(list(sink.encoder_views), grads)
+            return (None,) * (5 + len(params))
         if sink is not None:
             # hand the gradients over in place: returning the buffer's own views would make autograd clone each one
             for p, v in zip(params, grads):

@@ -105,10 +105,6 @@ class FlatGradSync:
         for p in self.params:
             p.grad = None
 
-    def check_views(self) -> None:
-        """Kept for API compatibility: gradients are (re)pointed at the flat buffer by all_reduce()."""
-        return None
-
     def pack(self, start: int = 0) -> None:
         grads, views = [], []
         for p, v in zip(self.params[start:], self.views[start:]):

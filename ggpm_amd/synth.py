@@ -191,6 +191,31 @@ def random_batch(seed: int, batch_size: int, **kw) -> List[MolSpec]:
     return [random_molecule(rng, **kw) for _ in range(batch_size)]
 
 
+# Size classes of the chem-trio training set (BASELINE configs[3]; thesis tables 4.1 / 4.3 via SURVEY.md section 8d):
+# (motif-count range, molecules in the training split).  QM9: ~9 atoms; HOPV-15: 42.8 +- 13.8 atoms; curated OPV: 98.7 +- 46.6.
+SIZE_MIX = (((1, 3), 120000), ((6, 14), 245), ((12, 36), 23))
+
+
+def size_mix_batch(seed: int, batch_size: int, one_of_each: bool = True, **kw) -> List[MolSpec]:
+    """A batch drawn from the chem-trio size mix.  ``one_of_each`` puts one HOPV-like and one OPV-like molecule into
+    every batch (the parity tests want the ragged case; at the true proportions 99.8 % of the batches are QM9-only)."""
+    rng = random.Random(seed)
+    total = float(sum(w for _, w in SIZE_MIX))
+    out: List[MolSpec] = []
+    for i in range(batch_size):
+        if one_of_each and i in (batch_size // 3, 2 * batch_size // 3):
+            cls = 1 if i == batch_size // 3 else 2
+        else:
+            u, cls, acc = rng.random() * total, 0, 0.0
+            for k, (_, w) in enumerate(SIZE_MIX):
+                acc += w
+                if u < acc:
+                    cls = k
+                    break
+        out.append(random_molecule(rng, motifs=SIZE_MIX[cls][0], **kw))
+    return out
+
+
 def _pad(rows: List[List[int]]) -> np.ndarray:
     """create_pad_tensor (reference ggpm/nnutils.py:105-110): width max_len + 1, zero padded."""
     width = max(len(r) for r in rows) + 1

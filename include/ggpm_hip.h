@@ -348,8 +348,10 @@ int ggpm_persistent_timeout(uint32_t* sync, ggpm_stream_t stream);
  * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own
  * stream; ggpm_timing_collect() synchronises those events and returns launches / total milliseconds /
  * algorithmic flops for kernel class `which` (0 gru_fwd_a, 1 gru_bwd_a, 2 lstm_fwd_a, 3 lstm_bwd_a,
- * 4 gru_fwd_b, 5 gru_bwd_b, 6 lstm_fwd_b, 7 lstm_bwd_b). Used by bench.py for roofline.achieved; off by
- * default (no events, no overhead). */
+ * 4 gru_fwd_b, 5 gru_bwd_b, 6 lstm_fwd_b, 7 lstm_bwd_b) + 8 * level tag (0 launches issued through the per-op
+ * entry points, 1 atom level, 2 attachment level, 3 motif level of ggpm_encoder_forward / _backward), so that the
+ * atom-level launch (one workgroup per CU, MFMA bound) is reported apart from the small latency-bound levels.
+ * Used by bench.py for roofline.achieved; off by default (no events, no overhead). */
 int ggpm_timing_enable(int on);
 int ggpm_timing_collect(int which, int* launches, double* total_ms, double* flops);
 

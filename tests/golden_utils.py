@@ -100,6 +100,35 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
+def elem_rel_err(a, b, floor=1e-6):
+    """SURVEY.md section 8(d)'s per-element form: max_i |a_i - b_i| / max(|b_i|, floor * ||b||_inf).
+
+    With the survey's floor of 1e-6 a 1e-4 bound asks elements a millionth of the tensor's scale to carry four correct
+    digits, i.e. an absolute error of 1e-10 of the scale -- below fp32's own resolution (6e-8) of the sums those
+    elements come from.  The reference cannot meet that against itself: its fp32 run differs from its fp64 run by up
+    to 3.5e-2 in this measure on the committed fixtures (``test_per_element_criterion_is_calibrated``, CPU).  The
+    tests therefore apply the per-element form with ``ELEM_FLOOR`` (elements above 1 % of the tensor's scale are
+    checked individually, the rest against 1 % of the scale) next to the norm-wise bar."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), floor * max(float(np.abs(b).max()), 1e-300))
+    return float((np.abs(a - b) / den).max())
+
+
+ELEM_FLOOR = 1e-2
+ELEM_TOL = 1e-3      # bound on elem_rel_err(., ., ELEM_FLOOR); the reference's fp32 vs fp64 runs reach 3.5e-4
+
+
+def assert_close(a, b, what, tol=1e-4, elem_tol=ELEM_TOL):
+    """The 1e-4 norm-wise bar of BASELINE.json plus the per-element form of SURVEY section 8(d) (see elem_rel_err)."""
+    e = rel_err(a, b)
+    assert e < tol, "%s: norm-wise rel err %.3e" % (what, e)
+    if np.abs(np.asarray(b)).max() > 0:
+        pe = elem_rel_err(a, b, ELEM_FLOOR)
+        assert pe < elem_tol, "%s: per-element rel err %.3e (floor %g)" % (what, pe, ELEM_FLOOR)
+    return e
+
+
 def sparse_inputs(E1, I, H, ms, K, seed):
     """Seeded inputs of a sparse_forward call (shared with the tests): state, subset, its inputs and predecessors."""
     rs = np.random.RandomState(seed)
