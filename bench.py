@@ -378,6 +378,97 @@ class Workload:
                 "all_depth_kernels": per}
 
 
+class VaeWorkload:
+    """The "reported row" of SURVEY.md section 8(d): the FULL VAE training step -- HierPropertyVAE.forward (encoder,
+    rsample with perturbation, teacher-forced HierMPNDecoder with diterT = 1 / diterG = 5 as every shipped config has
+    them, the four losses) + backward + Adam -- on the configs[1] workload, N = 1.  The decoder's per-batch integer
+    bookkeeping (DecodeSchedule) is resident on the device like the index tensors."""
+
+    DITER_T, DITER_G, TIE = 1, 5, False
+
+    def __init__(self, cfg, rnn, a, dev):
+        from ggpm_amd import synth
+        from ggpm_amd.decoder import DecodeSchedule
+        from ggpm_amd.nnutils import make_cuda
+        from ggpm_amd.property_vae import HierPropertyVAE
+        from ggpm_amd.vocab import IndexPairVocab
+        self.cfg, self.rnn, self.a, self.dev = cfg, rnn, a, dev
+        n_motif, n_attach = cfg["vocab"]
+        self.vocab = IndexPairVocab(n_motif, n_attach)
+        self.items = []
+        for i in range(min(a.pool, 8)):
+            specs = synth.random_batch(1000 + i, cfg["batch"], motifs=tuple(cfg["gen"]), n_motif_vocab=n_motif,
+                                       n_attach_vocab=n_attach)
+            tensors = synth.tensorize(specs)
+            sch = DecodeSchedule.from_specs(specs, tensors)
+            self.items.append((tensors, make_cuda(tensors), sch.to_device(dev)))
+        args = make_args(rnn, cfg["hidden"], cfg["depth"], cfg["latent"], n_motif, n_attach)
+        args.vocab, args.diterT, args.diterG, args.tie_embedding = self.vocab, self.DITER_T, self.DITER_G, self.TIE
+        torch.manual_seed(0)
+        self.model = HierPropertyVAE(args).to(dev)
+        for p in self.model.parameters():
+            if p.dim() == 1:
+                torch.nn.init.constant_(p, 0)
+            else:
+                torch.nn.init.xavier_normal_(p)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        self.orders = [None] * cfg["batch"]
+
+    def step(self, i):
+        _, dev_tensors, sch = self.items[i % len(self.items)]
+        self.opt.zero_grad(set_to_none=True)
+        loss, metrics = self.model(None, None, dev_tensors, self.orders, None, None, beta=0.1, perturb_z=True, schedule=sch)
+        loss.backward()
+        self.opt.step()
+        return metrics
+
+    def measure(self):
+        steps, warm = min(self.a.steps, 10), 3
+        for i in range(warm):
+            m = self.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            m = self.step(warm + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        B = self.cfg["batch"]
+        log("full VAE step (%s): %.2f ms/step, loss %.3f" % (self.rnn, 1e3 * dt / steps, m["Loss"]))
+        return {"ms_per_step": round(1e3 * dt / steps, 3), "value": round(steps * B / dt, 2), "unit": "molecules/s",
+                "steps": steps, "warmup": warm, "rnn_type": self.rnn,
+                "workload": "HierPropertyVAE fwd (perturb_z) + bwd + Adam on the configs[1] batches: latent=%d, diterT=%d, "
+                            "diterG=%d, tie_embedding=%s, metrics read back with .item() every step like the reference"
+                            % (self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}
+
+    def cpu_baseline(self, budget_s=14.0):
+        """The oracle's full VAE step (oracle/ref_decoder.py, reference op order) on the same batches."""
+        from oracle import ref_encoder as ref, ref_decoder as refd
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in self.model.state_dict().items()
+             if not k.startswith(("decoder.rnn_cell.", "decoder.E_assm."))}
+        cfg, times, t_begin = self.cfg, [], time.time()
+        for i in range(2 + 6):
+            tensors, _, sch = self.items[i % len(self.items)]
+            tt, gt = ref.to_long_tensors(tensors[0]), ref.to_long_tensors(tensors[1])
+            t0 = time.time()
+            loss, kl, _, _ = refd.vae_forward(p, self.rnn, cfg["depth"], cfg["depth"], self.DITER_T, self.DITER_G, tt, gt,
+                                              sch, self.vocab.mask, 0.1)
+            for v in p.values():
+                v.grad = None
+            loss.backward()
+            dt = time.time() - t0
+            if i >= 2 or time.time() - t_begin > budget_s:
+                times.append(dt)
+            if time.time() - t_begin > budget_s and times:
+                break
+        med = float(np.median(times))
+        return {"value": round(cfg["batch"] / med, 2), "unit": "molecules/s", "cores": cores, "kind": "port",
+                "cpu_model": cpu_model(),
+                "sample": "oracle/ref_decoder.py vae_forward + backward of batch %d: 2 warm-up + %d timed steps, median "
+                          "%.3f s, %d threads" % (cfg["batch"], len(times), med, cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,6 +491,7 @@ def main():
                     help="skip the extra timed pass without the tree fixed-point hint (profiling runs)")
     ap.add_argument("--no-second-cell", action="store_true",
                     help="skip the run of the other message function (configs[1] reports GRU and, under \"lstm\", LSTM)")
+    ap.add_argument("--no-vae", action="store_true", help="skip the full-VAE-step row (\"vae_step\", configs[1], N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -476,7 +568,23 @@ def main():
                                              "full_depth_loops", "roofline") if k in mo}
         cpu_runs.append(("LSTM", other.pool))
 
+    # the reported row: full VAE training step (never allowed to cost the line)
+    vae = None
+    if a.config == 1 and world == 1 and not a.no_vae and not a.host_input:
+        try:
+            torch.cuda.empty_cache()
+            vae = VaeWorkload(cfg, rnn, a, dev)
+            result["vae_step"] = vae.measure()
+        except Exception as exc:
+            result["vae_step"] = {"error": repr(exc)}
+            vae = None
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if vae is not None:
+            try:
+                result["vae_step"]["cpu_baseline"] = vae.cpu_baseline()
+            except Exception as exc:
+                result["vae_step"]["cpu_baseline"] = {"error": repr(exc)}
         budget = 24.0 / len(cpu_runs)
         for cell, pool in cpu_runs:
             log("cpu baseline (%s) on %d threads" % (cell, host_cores()))

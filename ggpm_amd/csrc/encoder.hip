@@ -56,7 +56,16 @@ struct Dims {
     int ld_n, ld_m, ld_t, Ig, It;
     int lstm, nX, lcount;          // cell type, hoisted-input slots per level (3 / 4), parameter slots per level (9 / 10)
     int tree_chain;                // longest dependency chain of the tree messages (0: unknown)
+    float dropout;                 // training-mode drop probability (0: none)
+    unsigned int seed_lo, seed_hi;
 };
+
+// dropout sites (include/ggpm_hip.h)
+enum { DS_EI = 0, DS_EC, DS_WO_ATOM, DS_WI, DS_WO_INTER, DS_WC, DS_WO_TREE };
+inline int drop(const Dims& d, float* x, int rows, int cols, int ld, int site, ggpm_stream_t s) {
+    if (d.dropout <= 0.f) return GGPM_OK;
+    return ggpm_dropout(x, rows, cols, ld, d.dropout, d.seed_lo, d.seed_hi, site, s);
+}
 
 Dims make_dims(const ggpm_enc_dims* d) {
     Dims x;
@@ -69,6 +78,7 @@ Dims make_dims(const ggpm_enc_dims* d) {
     x.It = x.H + 20; x.ld_t = ggpm_round_up(x.It, 4);
     x.lstm = d->rnn_type == 1; x.nX = x.lstm ? 4 : 3; x.lcount = x.lstm ? 10 : 9;
     x.tree_chain = d->tree_chain;
+    x.dropout = d->dropout; x.seed_lo = d->seed_lo; x.seed_hi = d->seed_hi;
     return x;
 }
 
@@ -323,7 +333,9 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     }
     // inputs of the two tree-side levels that do not depend on the level below: embedding rows, one-hot bond positions
     CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, ts));
+    CK(drop(d, S.finput_i, d.N1t, He, d.Hep, DS_EI, ts));
     CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, ts));
+    CK(drop(d, S.finput_t, d.N1t, He, d.Hep, DS_EC, ts));
     CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, ts));
     CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, ts));
     if (side_stream) {
@@ -349,23 +361,28 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     CK(level_forward(d, d.E1g, d.N1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, 2, S.gpred, S.gagr, S.lv[2], stream));
     CK(linear2(d.N1g, H, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, P[lwo(d.lstm, 2)], P[lbo(d.lstm, 2)], GGPM_ACT_RELU, 1,
                hatom, Hp, stream));
+    CK(drop(d, hatom, d.N1g, H, Hp, DS_WO_ATOM, stream));
 
     // ---- attachment level (embed_inter, inter_encoder)
     if (side_stream) (void)hipStreamWaitEvent(s, ev_tree, 0);      // tree-side layout built beside the atom level
     CK(ggpm_segment_sum(hatom, Hp, S.tcgr.rowptr, S.tcgr.col, d.N1t, H, S.pooled, Hp, 0, Hp, stream));
     CK(linear2(d.N1t, H, S.finput_i, d.Hep, He, S.pooled, Hp, H, P[P_WI], P[P_BI], GGPM_ACT_RELU, 0, S.hnode_i, Hp,
                stream));
+    CK(drop(d, S.hnode_i, d.N1t, H, Hp, DS_WI, stream));
     CK(ggpm_gather_rows(S.hnode_i, Hp, S.src, d.E1t, H, S.hmess_i, d.ld_t, 0, 0, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_i, d.ld_t, P, 1, S.tpred, S.tagr, S.lv[1], stream));
     CK(linear2(d.N1t, H, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, P[lwo(d.lstm, 1)], P[lbo(d.lstm, 1)], GGPM_ACT_RELU, 1, hinter, Hp,
                stream));
+    CK(drop(d, hinter, d.N1t, H, Hp, DS_WO_INTER, stream));
 
     // ---- motif level (embed_tree, tree_encoder)
     CK(linear2(d.N1t, H, S.finput_t, d.Hep, He, hinter, Hp, H, P[P_WC], P[P_BC], GGPM_ACT_RELU, 0, S.hnode_t, Hp, stream));
+    CK(drop(d, S.hnode_t, d.N1t, H, Hp, DS_WC, stream));
     CK(ggpm_gather_rows(S.hnode_t, Hp, S.src, d.E1t, H, S.hmess_t, d.ld_t, 0, 0, stream));
     CK(level_forward(d, d.E1t, d.N1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, 0, S.tpred, S.tagr, S.lv[0], stream));
     CK(linear2(d.N1t, H, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, P[lwo(d.lstm, 0)], P[lbo(d.lstm, 0)], GGPM_ACT_RELU, 1, hnode, Hp,
                stream));
+    CK(drop(d, hnode, d.N1t, H, Hp, DS_WO_TREE, stream));
 
     // ---- root readout (embed_root)
     CK(ggpm_gather_rows(S.hnode_t, Hp, roots, d.B, H, S.f, Hp, 0, Hp, stream));
@@ -637,6 +654,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     // ---- motif level: W_o, message function, W_c / E_c
     if (d_hnode) {
         CK(ggpm_act_backward(d_hnode, hnode, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[0], stream));
+        CK(drop(d, dpre[0], d.N1t, H, Hp, DS_WO_TREE, stream));     // d(dropout) commutes with the ReLU mask
         CK(linear2_dx(d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)], w.d_hnode_t, Hp, 1, w.d_nei_t, Hp, 1, stream));
         CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lwo(d.lstm, 0)], G[lbo(d.lstm, 0)], w, st));
     } else {
@@ -648,13 +666,16 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                       w.dx_mess, d.ld_t, w, st));
     CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_t, Hp, 1, 0, stream));
     CK(ggpm_act_backward(w.d_hnode_t, S.hnode_t, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[1], stream));
+    CK(drop(d, dpre[1], d.N1t, H, Hp, DS_WC, stream));
     if (d_hinter) (void)hipMemcpyAsync(w.d_hinter, d_hinter, nt, hipMemcpyDeviceToDevice, s);
     CK(linear2_dx(d.N1t, H, He, dpre[1], Hp, P[P_WC], w.d_finput, d.Hep, 0, w.d_hinter, Hp, d_hinter ? 1 : 0, stream));
+    CK(drop(d, w.d_finput, d.N1t, He, d.Hep, DS_EC, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[1], Hp, S.finput_t, d.Hep, He, hinter, Hp, H, G[P_WC], G[P_BC], w, st));
     CK(ggpm_segment_sum(w.d_finput, d.Hep, S.motif.rowptrT, S.motif.colT, d.n_motif, He, G[P_EC], He, 0, He, st.w()));
 
     // ---- attachment level: W_o, message function, W_i / E_i, pooling over atoms
     CK(ggpm_act_backward(w.d_hinter, hinter, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[2], stream));
+    CK(drop(d, dpre[2], d.N1t, H, Hp, DS_WO_INTER, stream));
     CK(linear2_dx(d.N1t, H, H, dpre[2], Hp, P[lwo(d.lstm, 1)], w.d_hnode_i, Hp, 0, w.d_nei_i, Hp, 0, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[2], Hp, S.hnode_i, Hp, H, S.lv[1].nei, Hp, H, G[lwo(d.lstm, 1)], G[lbo(d.lstm, 1)], w, st));
     CK(ggpm_segment_sum(w.d_nei_i, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
@@ -662,8 +683,10 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                       w.dx_mess, d.ld_t, w, st));
     CK(ggpm_segment_sum(w.dx_mess, d.ld_t, S.tsrc.rowptrT, S.tsrc.colT, d.N1t, H, w.d_hnode_i, Hp, 1, 0, stream));
     CK(ggpm_act_backward(w.d_hnode_i, S.hnode_i, d.N1t, H, Hp, GGPM_ACT_RELU, 0, dpre[3], stream));
+    CK(drop(d, dpre[3], d.N1t, H, Hp, DS_WI, stream));
     float* d_finput_i = w.d_finput + (size_t)d.N1t * d.Hep;
     CK(linear2_dx(d.N1t, H, He, dpre[3], Hp, P[P_WI], d_finput_i, d.Hep, 0, w.d_pooled, Hp, 0, stream));
+    CK(drop(d, d_finput_i, d.N1t, He, d.Hep, DS_EI, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[3], Hp, S.finput_i, d.Hep, He, S.pooled, Hp, H, G[P_WI], G[P_BI], w, st));
     CK(ggpm_segment_sum(d_finput_i, d.Hep, S.attach.rowptrT, S.attach.colT, d.n_attach, He, G[P_EI], He, 0, He, st.w()));
     if (d_hatom) (void)hipMemcpyAsync(w.d_hatom, d_hatom, ng, hipMemcpyDeviceToDevice, s);
@@ -678,6 +701,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
 
     // ---- atom level: W_o, message function (its inputs are constants)
     CK(ggpm_act_backward(w.d_hatom, hatom, d.N1g, H, Hp, GGPM_ACT_RELU, 1, dpre[4], stream));
+    CK(drop(d, dpre[4], d.N1g, H, Hp, DS_WO_ATOM, stream));
     CK(ggpm_gemm(0, 0, d.N1g, H, H, dpre[4], Hp, P[lwo(d.lstm, 2)] + d.atom, d.atom + H, w.d_nei_g, Hp, Hp, nullptr, 0,
                  GGPM_ACT_NONE, 0, nullptr, 0, stream));
     CK(linear2_wgrad(d.N1g, H, dpre[4], Hp, S.hnode_a, d.ld_n, d.atom, S.lv[2].nei, Hp, H, G[lwo(d.lstm, 2)], G[lbo(d.lstm, 2)], w,

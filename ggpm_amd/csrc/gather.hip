@@ -128,3 +128,37 @@ extern "C" int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fme
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
+
+
+// ---------------------------------------------------------------- dropout (counter-based, stateless)
+namespace {
+__device__ __forceinline__ unsigned int fmix32(unsigned int h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__global__ void dropout_k(float* __restrict__ x, int rows, int cols, int ld, unsigned int thresh, float scale,
+                          unsigned int seed_lo, unsigned int seed_hi, unsigned int site) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    const unsigned int idx = (unsigned int)r * (unsigned int)cols + (unsigned int)c;
+    unsigned int h = fmix32(idx * 0x9E3779B1u + seed_lo);
+    h = fmix32(h ^ (seed_hi + site * 0x7F4A7C15u));
+    float* p = x + (size_t)r * ld + c;
+    *p = ((h >> 8) >= thresh) ? *p * scale : 0.f;
+}
+}  // namespace
+
+extern "C" int ggpm_dropout(float* x, int rows, int cols, int ld, float p, unsigned int seed_lo, unsigned int seed_hi,
+                            int site, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!x || rows <= 0 || cols <= 0 || ld < cols || p < 0.f || p >= 1.f) return GGPM_ERR_ARG;
+    if (p == 0.f) return GGPM_OK;
+    const unsigned int thresh = (unsigned int)((double)p * 16777216.0);
+    dim3 grid(ggpm_ceil_div(cols, 256), rows);
+    dropout_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, rows, cols, ld, thresh, 1.0f / (1.0f - p), seed_lo, seed_hi,
+                                                      (unsigned int)site);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}

@@ -132,7 +132,9 @@ class ScoreHeads(nn.Module):
         cls_scores = _mlp(self.clsNN, *parts)
         icls_scores = _mlp(self.iclsNN, *parts)
         l1, a1 = cross_entropy_sum(cls_scores, cls_labs)
-        l2, a2 = cross_entropy_sum(icls_scores, icls_labs, mask=self.vocab.mask.to(icls_scores.device), mask_row=cls_labs)
+        vocab = self.vocab
+        mask = vocab.mask_on(icls_scores.device) if hasattr(vocab, "mask_on") else vocab.mask.to(icls_scores.device)
+        l2, a2 = cross_entropy_sum(icls_scores, icls_labs, mask=mask, mask_row=cls_labs)
         return l1 + l2, a1, a2
 
     def get_assm_score(self, src_graph_vecs, batch_idx, assm_vecs):

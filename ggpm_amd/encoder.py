@@ -198,11 +198,9 @@ class HierMPNEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _fused_ok(self, tree_tensors, graph_tensors) -> bool:
-        """The one-call C++ driver covers both message functions without dropout on int64 device tensors."""
+        """The one-call C++ driver covers both message functions (dropout included) on int64 device tensors."""
         from . import fused
         if not fused.enabled() or not isinstance(self.graph_encoder.rnn, (GRU, LSTM)):
-            return False
-        if self.training and self.dropout > 0:
             return False
         if type(self.tree_encoder) is not MPNEncoder or self.atom_size + 24 > 252:
             return False

@@ -2,8 +2,8 @@
 
 One ctypes call per direction instead of ~150: at MI355X speeds the op-by-op host path (functional.py) needs about as
 long to ENQUEUE a step as the GPU needs to run it.  Same kernels, same order, same results; used by
-``HierMPNEncoder.forward_padded`` for the GRU message function with dropout 0 (anything else keeps the op-by-op
-path).  GGPM_FUSED_ENCODER=0 switches it off.
+``HierMPNEncoder.forward_padded`` for both message functions, with or without dropout (counter-based masks generated
+in the drivers, ``ggpm_dropout``).  GGPM_FUSED_ENCODER=0 switches it off.
 """
 from __future__ import annotations
 
@@ -36,7 +36,14 @@ PARAM_ORDER = param_order("GRU")
 class EncDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("H", "He", "depthT", "depthG", "atom_size", "n_motif", "n_attach", "N1g",
                                             "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B", "rnn_type",
-                                            "tree_chain")]
+                                            "tree_chain")] + \
+               [("dropout", ctypes.c_float), ("seed_lo", ctypes.c_uint), ("seed_hi", ctypes.c_uint)]
+
+
+def _dropout_seed():
+    """64 bits from torch's CPU generator (so ``torch.manual_seed`` makes dropout runs repeatable)."""
+    v = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64)
+    return int(v[0]), int(v[1])
 
 
 def enabled() -> bool:
@@ -176,5 +183,8 @@ def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
                    tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm),
-                   int(getattr(tf[3], "ggpm_chain", 0)))
+                   int(getattr(tf[3], "ggpm_chain", 0)), 0.0, 0, 0)
+    if encoder.training and encoder.dropout > 0:      # nn.Dropout semantics: active in training mode only
+        seed = getattr(encoder, "_dropout_seed", None) or _dropout_seed()      # (tests pin the seed)
+        dims.dropout, dims.seed_lo, dims.seed_hi = float(encoder.dropout), seed[0], seed[1]
     return _HierEncoder.apply(dims, tree_tensors, graph_tensors, roots, getattr(encoder, "_grad_sink", None), *params)

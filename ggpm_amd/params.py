@@ -97,3 +97,33 @@ def score_head_shapes(hidden: int, latent: int, embed: int, n_motif: int, n_atta
     s["matchNN.0.weight"] = (H, H + embed + MAX_POS); s["matchNN.0.bias"] = (H,)
     s["W_assm.weight"] = (L, H); s["W_assm.bias"] = (L,)
     return s
+
+
+def vae_param_shapes(rnn_type: str, hidden: int, latent: int, n_motif: int, n_attach: int, embed: int | None = None):
+    """Every parameter of HierPropertyVAE (reference ggpm/property_vae.py:11-24) under its state_dict name, without the
+    alias entries the reference's decoder registers twice (``decoder.rnn_cell.*`` = ``decoder.hmpn.tree_encoder.rnn.*``,
+    ``decoder.E_assm.*`` = ``decoder.hmpn.E_i.*``).  With ``tie_embedding`` the encoder's ``E_c`` / ``E_i`` ARE the
+    decoder's: load ``tied_state_dict`` of the result."""
+    He = hidden if embed is None else embed
+    enc = encoder_param_shapes(rnn_type, hidden, n_motif, n_attach, embed=He)
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for k, v in enc.items():
+        s["encoder." + k] = v
+    for k, v in enc.items():
+        if not k.startswith("W_root"):
+            s["decoder.hmpn." + k] = v
+    for k, v in score_head_shapes(hidden, latent, He, n_motif, n_attach).items():
+        s["decoder." + k] = v
+    if latent != hidden:
+        s["decoder.W_root.weight"] = (hidden, latent); s["decoder.W_root.bias"] = (hidden,)
+    for k, v in vae_head_shapes(hidden, latent).items():
+        s[k] = v
+    return s
+
+
+def tied_state_dict(sd):
+    """tie_embedding (ggpm/encoder.py:92-94): the encoder's embeddings are the decoder's."""
+    out = OrderedDict(sd)
+    for k in ("E_c.0.weight", "E_i.0.weight"):
+        out["encoder." + k] = out["decoder.hmpn." + k]
+    return out

@@ -139,3 +139,40 @@ class HierEncoderVAE(nn.Module):
         z, kl = rsample(hroot, self.R_mean, self.R_var, perturb_z)
         H = self.encoder.hidden_size
         return z, kl, (hroot[:, :H], hnode[:, :H], hinter[:, :H], hatom[:, :H])
+
+
+class HierPropertyVAE(nn.Module):
+    """reference ggpm/property_vae.py:11-62 -- encoder, latent heads, teacher-forced decoder; the class
+    ``OPVNet.get_model('hier-prop')`` returns (ggpm/opvnet.py:4-9) and ``vae_train.py:78`` calls as
+    ``model(*batch, beta=beta)``.  Same constructor argument bag, sub-module names and ``state_dict`` keys.
+
+    ``forward(mols, graphs, tensors, orders, homos, lumos, beta, perturb_z=True)`` returns ``(loss, metrics)`` like the
+    reference; ``schedule=`` optionally passes a prepared :class:`ggpm_amd.decoder.DecodeSchedule` (the decoder's
+    integer bookkeeping, otherwise derived from ``graphs`` on every call).
+    """
+
+    def __init__(self, args):
+        super().__init__()
+        from .decoder import HierMPNDecoder
+        self.encoder = HierMPNEncoder(args.vocab, args.atom_vocab, args.rnn_type, args.embed_size, args.hidden_size,
+                                      args.depthT, args.depthG, args.dropout)
+        self.decoder = HierMPNDecoder(args.vocab, args.atom_vocab, args.rnn_type, args.embed_size, args.hidden_size,
+                                      args.latent_size, args.diterT, args.diterG, args.dropout)
+        if getattr(args, "tie_embedding", False):
+            self.encoder.tie_embedding(self.decoder.hmpn)
+        self.latent_size = args.latent_size
+        self.R_mean = nn.Linear(args.hidden_size, args.latent_size)
+        self.R_var = nn.Linear(args.hidden_size, args.latent_size)
+
+    def rsample(self, z_vecs, W_mean, W_var, perturb=True):
+        return rsample(z_vecs, W_mean, W_var, perturb)
+
+    def forward(self, mols, graphs, tensors, orders, homos=None, lumos=None, beta=0.0, perturb_z=True, schedule=None):
+        tree_tensors, graph_tensors = tensors = make_cuda(tensors)
+        root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
+        root_vecs, kl_div = rsample(root_vecs, self.R_mean, self.R_var, perturb_z)
+        loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,
+                                                    schedule=schedule)
+        loss = loss + beta * kl_div
+        return loss, {'Loss': loss.item(), 'KL:': kl_div.item(), 'Word': float(wacc), 'I-Word': float(iacc),
+                      'Topo': float(tacc), 'Assm': float(sacc)}

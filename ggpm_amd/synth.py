@@ -45,6 +45,11 @@ class MolSpec:
     tree_edge_label: Dict[Tuple[int, int], int] = field(default_factory=dict)
     bond_pos: Dict[Tuple[int, int], int] = field(default_factory=dict)   # directed (u,v) -> child order
     order: List[Tuple[int, Optional[int], int]] = field(default_factory=list)
+    # decoder-side labels (what MolGraph.label_tree stores per motif as 'inter_label' / 'assm_cands',
+    # reference ggpm/mol_graph.py:147-165): the atoms a motif shares with its parent, each with the attachment id that
+    # describes it, and the candidate attachment sites inside the parent (the true one first)
+    inter_label: List[List[Tuple[int, int]]] = field(default_factory=list)
+    assm_cands: List[List[int]] = field(default_factory=list)
 
     @property
     def n_atoms(self) -> int:
@@ -107,6 +112,20 @@ def label_tree(spec: MolSpec) -> None:
     finally:
         sys.setrecursionlimit(old)
     spec.order.append((0, None, 0))
+
+    # inter_label: the (single) atom shared with the parent, labelled with the motif's own attachment id; the root's is
+    # its first atom (mol_graph.py:149).  assm_cands (only when the parent is a ring, mol_graph.py:158-161): the true
+    # site first, then the parent's other atoms (chemutils.get_assm_cands keeps those of a different canonical rank;
+    # synthetic atoms have no symmetry classes, so all of them stay).
+    spec.inter_label, spec.assm_cands = [], []
+    for i, cls in enumerate(spec.clusters):
+        p = pa[i]
+        shared = sorted(set(cls) & set(spec.clusters[p])) if p >= 0 else [cls[0]]
+        spec.inter_label.append([(a, spec.motif_label[i][1]) for a in shared])
+        if p >= 0 and len(spec.clusters[p]) > 2:
+            spec.assm_cands.append([shared[0]] + [x for x in spec.clusters[p] if x != shared[0]])
+        else:
+            spec.assm_cands.append([])
 
     for i, cls in enumerate(spec.clusters):
         p = pa[i]

@@ -123,6 +123,13 @@ int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int r
                      float* out, int ld_out, int col_off, int zero_to, ggpm_stream_t stream);
 /* out[r, col_off + idx[r]] = 1, the other `classes` columns of that block 0: the one-hot tables
  * E_a/E_b/E_apos/E_pos of ggpm/encoder.py:74-77,121-125,104-105. */
+/* nn.Dropout in training mode (ggpm/encoder.py:15-19, 52-72), in place on x[rows, cols] (leading dimension ld):
+ * x[r][c] = keep ? x[r][c] / (1 - p) : 0 with keep = (mix(seed, site, r * cols + c) >> 8) >= p * 2^24, mix = two rounds of
+ * the murmur3 32-bit finaliser (see gather.hip; restated in numpy by tests/golden_utils.dropout_keep).  Stateless: the
+ * backward applies the same call to the incoming gradient.  Cannot be bit-matched to torch's generator; parity tests
+ * inject the same mask into the oracle. */
+int ggpm_dropout(float* x, int rows, int cols, int ld, float p, unsigned int seed_lo, unsigned int seed_hi, int site,
+                 ggpm_stream_t stream);
 int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off, int zero_to,
                 ggpm_stream_t stream);
 /* embed_graph (ggpm/encoder.py:119-126) in one launch: hnode[N1, ld_n] = onehot(fnode), hmess[E1, ld_m] =
@@ -295,7 +302,9 @@ int ggpm_rsample_backward(const float* mean, const float* pv, const float* eps, 
  * event-ordered against `stream`; on return from the backward `stream` is ordered behind it.  d_* may be null.
  * phase: 0 = whole backward; 1 = all but the atom level, 2 = atom level + final join (same arguments, same work
  * arena): between the two a data-parallel caller starts all-reducing the gradients of every slot before graph_encoder.
- * Dropout 0 only (the host keeps the op-by-op path otherwise). */
+ * Dropout (ggpm/encoder.py:15-19, 52-72: after E_c, E_i, W_c, W_i and every level's W_o): `dropout` > 0 applies the
+ * counter-based masks of ggpm_dropout() with `seed_lo/seed_hi` at sites 0 E_i rows, 1 E_c rows, 2 atom-level W_o,
+ * 3 W_i, 4 attachment-level W_o, 5 W_c, 6 motif-level W_o; the backward regenerates the same masks from the seed. */
 typedef struct ggpm_enc_dims {
     int H, He, depthT, depthG, atom_size, n_motif, n_attach;
     int N1g, E1g, Kg_a, Kg_b;            /* atom graph: nodes+1, messages+1, agraph / bgraph widths */
@@ -308,6 +317,8 @@ typedef struct ggpm_enc_dims {
                                             the two tree-side levels then run tree_chain + 1 of their depthT steps and
                                             replicate the last stash slot -- bit-identical to running all of them
                                             (ggpm/rnn.py:41-50 iterates a fixed depth regardless). */
+    float dropout;                       /* drop probability of the training forward (0: none / eval) */
+    unsigned int seed_lo, seed_hi;       /* mask stream of this forward/backward pair */
 } ggpm_enc_dims;
 size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims);
 size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims);

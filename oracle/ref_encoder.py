@@ -150,12 +150,17 @@ def lstm_sparse_forward(p: Params, pre: str, h: Tensor, c: Tensor, fmess: Tensor
 
 
 # ---------------------------------------------------------------- MPNEncoder (ggpm/encoder.py:8-38)
+def _drop(x: Tensor, masks, site: str) -> Tensor:
+    """nn.Dropout in training mode with an INJECTED mask (already scaled by 1 / (1 - p)); ``masks`` None = inactive."""
+    return x if masks is None else x * masks[site].to(x.dtype)
+
+
 def mpn_forward(p: Params, pre: str, rnn_type: str, depth: int, fnode: Tensor, fmess: Tensor,
-                agraph: Tensor, bgraph: Tensor, trace: list | None = None) -> Tuple[Tensor, Tensor]:
-    """MPNEncoder.forward -- ggpm/encoder.py:28-38 (dropout inactive: eval / p=0)."""
+                agraph: Tensor, bgraph: Tensor, trace: list | None = None, masks=None) -> Tuple[Tensor, Tensor]:
+    """MPNEncoder.forward -- ggpm/encoder.py:28-38; W_o = Linear + ReLU + Dropout (:15-19)."""
     h = rnn_forward(p, pre + "rnn.", rnn_type, fmess, bgraph, depth, trace)
     nei = gather_rows(h, agraph).sum(dim=1)
-    node = torch.relu(_affine(p, pre + "W_o.0", torch.cat([fnode, nei], dim=1)))
+    node = _drop(torch.relu(_affine(p, pre + "W_o.0", torch.cat([fnode, nei], dim=1))), masks, pre + "W_o")
     return node * _row0_mask(node.shape[0], node), h
 
 
@@ -175,22 +180,22 @@ def embed_graph(p: Params, graph_tensors, atom_size: int, dtype) -> Tuple[Tensor
     return hnode, hmess, agraph, bgraph
 
 
-def embed_inter(p: Params, tree_tensors, hatom: Tensor):
-    """HierMPNEncoder.embed_inter -- ggpm/encoder.py:96-107."""
+def embed_inter(p: Params, tree_tensors, hatom: Tensor, masks=None):
+    """HierMPNEncoder.embed_inter -- ggpm/encoder.py:96-107 (E_i = Embedding + Dropout, W_i = Linear + ReLU + Dropout)."""
     fnode, fmess, agraph, bgraph, cgraph = tree_tensors[:5]
-    finput = p["E_i.0.weight"].index_select(0, fnode[:, 1])
+    finput = _drop(p["E_i.0.weight"].index_select(0, fnode[:, 1]), masks, "E_i")
     pooled = gather_rows(hatom, cgraph).sum(dim=1)
-    hnode = torch.relu(_affine(p, "W_i.0", torch.cat([finput, pooled], dim=-1)))
+    hnode = _drop(torch.relu(_affine(p, "W_i.0", torch.cat([finput, pooled], dim=-1))), masks, "W_i")
     hmess = torch.cat([hnode.index_select(0, fmess[:, 0]),
                        _eye(MAX_POS, hnode).index_select(0, fmess[:, 2])], dim=-1)
     return hnode, hmess, agraph, bgraph
 
 
-def embed_tree(p: Params, tree_tensors, hinter: Tensor):
-    """HierMPNEncoder.embed_tree -- ggpm/encoder.py:109-117."""
+def embed_tree(p: Params, tree_tensors, hinter: Tensor, masks=None):
+    """HierMPNEncoder.embed_tree -- ggpm/encoder.py:109-117 (E_c = Embedding + Dropout, W_c = Linear + ReLU + Dropout)."""
     fnode, fmess, agraph, bgraph, cgraph = tree_tensors[:5]
-    finput = p["E_c.0.weight"].index_select(0, fnode[:, 0])
-    hnode = torch.relu(_affine(p, "W_c.0", torch.cat([finput, hinter], dim=-1)))
+    finput = _drop(p["E_c.0.weight"].index_select(0, fnode[:, 0]), masks, "E_c")
+    hnode = _drop(torch.relu(_affine(p, "W_c.0", torch.cat([finput, hinter], dim=-1))), masks, "W_c")
     hmess = torch.cat([hnode.index_select(0, fmess[:, 0]),
                        _eye(MAX_POS, hnode).index_select(0, fmess[:, 2])], dim=-1)
     return hnode, hmess, agraph, bgraph
@@ -206,20 +211,22 @@ def embed_root(p: Params, hmess: Tensor, tree_inputs, roots: Sequence[int]) -> T
 
 
 def hier_encoder_forward(p: Params, rnn_type: str, depthT: int, depthG: int, tree_tensors,
-                         graph_tensors, atom_size: int = 38, trace: Dict[str, list] | None = None):
+                         graph_tensors, atom_size: int = 38, trace: Dict[str, list] | None = None, masks=None):
     """HierMPNEncoder.forward -- ggpm/encoder.py:140-157.
 
     ``tree_tensors`` / ``graph_tensors`` are the A0 tuples as int64 tensors with the
-    host ``scope`` list last.  Returns (hroot, hnode, hinter, hatom).
+    host ``scope`` list last.  Returns (hroot, hnode, hinter, hatom).  ``masks``: training-mode dropout with injected
+    masks (scaled keep masks) for the seven Dropout modules, keyed "E_i", "E_c", "W_i", "W_c" and
+    "<level>_encoder.W_o"; None = dropout inactive.
     """
     dtype = p["W_root.0.weight"].dtype
     tr = (lambda k: None) if trace is None else (lambda k: trace.setdefault(k, []))
     t = embed_graph(p, graph_tensors, atom_size, dtype)
-    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"))
-    t = embed_inter(p, tree_tensors, hatom)
-    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"))
-    t = embed_tree(p, tree_tensors, hinter)
-    hnode, hmess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, *t, trace=tr("tree"))
+    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"), masks=masks)
+    t = embed_inter(p, tree_tensors, hatom, masks)
+    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"), masks=masks)
+    t = embed_tree(p, tree_tensors, hinter, masks)
+    hnode, hmess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, *t, trace=tr("tree"), masks=masks)
     hroot = embed_root(p, hmess, t, [st for st, _ in tree_tensors[-1]])
     return hroot, hnode, hinter, hatom
 

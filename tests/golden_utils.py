@@ -15,7 +15,7 @@ N_PROBE = 64
 def case_names(prefix="", motif=False):
     """HierMPNEncoder fixtures by default; ``motif=True`` lists the MotifEncoder fixtures instead."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    names = [n for n in names if not n.startswith(("sparse_", "inc_", "heads_"))]   # those fixtures have their own tests
+    names = [n for n in names if not n.startswith(("sparse_", "inc_", "heads_", "vae_", "attach_"))]   # own tests
     return [n for n in names if n.startswith("motif_") == motif]
 
 
@@ -106,9 +106,11 @@ def elem_rel_err(a, b, floor=1e-6):
     With the survey's floor of 1e-6 a 1e-4 bound asks elements a millionth of the tensor's scale to carry four correct
     digits, i.e. an absolute error of 1e-10 of the scale -- below fp32's own resolution (6e-8) of the sums those
     elements come from.  The reference cannot meet that against itself: its fp32 run differs from its fp64 run by up
-    to 3.5e-2 in this measure on the committed fixtures (``test_per_element_criterion_is_calibrated``, CPU).  The
-    tests therefore apply the per-element form with ``ELEM_FLOOR`` (elements above 1 % of the tensor's scale are
-    checked individually, the rest against 1 % of the scale) next to the norm-wise bar."""
+    to 3.5e-2 in this measure on the committed fixtures (``test_per_element_criterion_is_calibrated``, CPU), and with
+    a floor of 1 % of the scale still by 5e-4 on outputs and 3e-3 on gradients at configs[1] size
+    (profiles/r02_parity_report_*.txt).  The tests therefore apply the per-element form RELATIVE TO THAT NOISE:
+    ``assert_close(a, b32, what, b64=...)`` demands that no element of the HIP result is further from the fp64 answer
+    than ELEM_SLACK times what the reference's own fp32 run is (floor ELEM_FLOOR), next to the norm-wise 1e-4 bar."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     den = np.maximum(np.abs(b), floor * max(float(np.abs(b).max()), 1e-300))
@@ -116,17 +118,44 @@ def elem_rel_err(a, b, floor=1e-6):
 
 
 ELEM_FLOOR = 1e-2
-ELEM_TOL = 1e-3      # bound on elem_rel_err(., ., ELEM_FLOOR); the reference's fp32 vs fp64 runs reach 3.5e-4
+ELEM_SLACK = 4.0
+ELEM_TOL = 1e-3      # the reference's fp32 vs fp64 outputs reach 5e-4 in this measure
 
 
-def assert_close(a, b, what, tol=1e-4, elem_tol=ELEM_TOL):
-    """The 1e-4 norm-wise bar of BASELINE.json plus the per-element form of SURVEY section 8(d) (see elem_rel_err)."""
+def assert_close(a, b, what, tol=1e-4, elem_tol=ELEM_TOL, b64=None):
+    """``a`` (HIP) against ``b`` (the reference / oracle in fp32): the norm-wise 1e-4 bar of BASELINE.json, plus the
+    per-element form of SURVEY section 8(d) (see elem_rel_err): against the fp64 run ``b64`` when given -- at most
+    ELEM_SLACK x the fp32 reference's own per-element distance to fp64 (never asked to be below ELEM_TOL: column sums
+    of ~1e4 terms with cancellation land anywhere within a few 1e-4 of each other, HIP or reference) -- else against
+    ``b`` with the absolute bound ``elem_tol`` (None: skipped)."""
     e = rel_err(a, b)
     assert e < tol, "%s: norm-wise rel err %.3e" % (what, e)
-    if np.abs(np.asarray(b)).max() > 0:
+    if np.abs(np.asarray(b)).max() == 0:
+        return e
+    if b64 is not None:
+        noise = elem_rel_err(b, b64, ELEM_FLOOR)
+        pe = elem_rel_err(a, b64, ELEM_FLOOR)
+        assert pe <= max(ELEM_SLACK * noise, ELEM_TOL), \
+            "%s: per-element err vs fp64 %.3e, the fp32 reference's own is %.3e (floor %g)" % (what, pe, noise, ELEM_FLOOR)
+    elif elem_tol is not None:
         pe = elem_rel_err(a, b, ELEM_FLOOR)
         assert pe < elem_tol, "%s: per-element rel err %.3e (floor %g)" % (what, pe, ELEM_FLOOR)
     return e
+
+
+def dropout_keep(rows, cols, p, seed_lo, seed_hi, site):
+    """The keep mask of ggpm_dropout (include/ggpm_hip.h), restated in numpy: [rows, cols] bool."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def fmix(h):
+        h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x85EBCA6B)) & M
+        h = h ^ (h >> np.uint64(13)); h = (h * np.uint64(0xC2B2AE35)) & M
+        return h ^ (h >> np.uint64(16))
+
+    idx = np.arange(rows * cols, dtype=np.uint64)
+    h = fmix((idx * np.uint64(0x9E3779B1) + np.uint64(seed_lo)) & M)
+    h = fmix(h ^ ((np.uint64(seed_hi) + np.uint64(site) * np.uint64(0x7F4A7C15)) & M))
+    return ((h >> np.uint64(8)) >= np.uint64(int(p * 16777216.0))).reshape(rows, cols)
 
 
 def sparse_inputs(E1, I, H, ms, K, seed):
@@ -231,3 +260,69 @@ class HeadsGolden:
         scale = max(float(stat[2]), 1e-12)
         assert np.abs(g.reshape(-1)[idx] - self.z["gprobe/" + pname]).max() <= rel * scale, pname
         assert abs(np.sqrt((g ** 2).sum()) - stat[1]) <= rel * max(stat[1], 1e-12) * 10, pname
+
+
+def vae_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "vae_*.npz")))
+
+
+class VaeGolden(Golden):
+    """Full-VAE-step fixtures (tests/golden/make_golden_vae.py): the reference's HierPropertyVAE forward + backward."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        (self.H, self.latent, self.depthT, self.depthG, self.diterT, self.diterG, self.B, self.n_motif, self.n_attach,
+         self.seed, m0, m1, tie, full) = [int(v) for v in self.z["meta"]]
+        self.motifs, self.tie, self.full = (m0, m1), bool(tie), bool(full)
+        self.rnn = str(self.z["rnn"])
+        self.beta = float(self.z["beta"])
+
+    def specs(self):
+        from ggpm_amd import synth
+        return synth.random_batch(self.seed, self.B, motifs=self.motifs, n_motif_vocab=self.n_motif,
+                                  n_attach_vocab=self.n_attach)
+
+    def state_dict(self):
+        from ggpm_amd.params import vae_param_shapes, tied_state_dict
+        sd = seeded_state_dict(vae_param_shapes(self.rnn, self.H, self.latent, self.n_motif, self.n_attach), self.seed)
+        return tied_state_dict(sd) if self.tie else sd
+
+    def args(self, vocab):
+        class A:
+            pass
+        a = A()
+        a.vocab, a.rnn_type, a.embed_size, a.hidden_size = vocab, self.rnn, self.H, self.H
+        a.atom_vocab = type("V", (), {"size": lambda s: 38})()
+        a.depthT, a.depthG, a.diterT, a.diterG = self.depthT, self.depthG, self.diterT, self.diterG
+        a.dropout, a.latent_size, a.tie_embedding = 0.0, self.latent, self.tie
+        return a
+
+    def ref_steps(self):
+        z = self.z
+        cols = []
+        for k in ("subnode", "submess", "atoms", "bonds"):
+            flat, off = z["ref_" + k], z["ref_" + k + "_off"]
+            cols.append([flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)])
+        return list(zip(*cols))
+
+    def check_grad(self, pname, g, rel):
+        g = np.asarray(g, dtype=np.float64)
+        if "grad/" + pname in self.z.files:
+            want = self.z["grad/" + pname].astype(np.float64)
+            scale = np.abs(want).max()
+            if scale < 1e-7 or pname.endswith("W_assm.bias"):
+                # analytically zero (W_assm.bias: the candidates of a row share one context vector and the softmax
+                # gradients of a row sum to 0): both sides hold rounding noise only
+                assert np.abs(g).max() < 1e-4 and scale < 1e-4, pname
+                return
+            err = np.abs(g - want).max() / scale
+            assert err <= rel, "%s grad %s: rel err %.3e" % (self.name, pname, err)
+            return
+        idx = self.probe_indices(pname, g.size)
+        stat = self.z["gstat/" + pname].astype(np.float64)
+        scale = max(stat[2], 1e-12)
+        err = np.abs(g.reshape(-1)[idx] - self.z["gprobe/" + pname]).max() / scale
+        assert err <= rel, "%s grad probe %s: rel err %.3e" % (self.name, pname, err)
+        l2 = np.sqrt((g ** 2).sum())
+        assert abs(l2 - stat[1]) <= rel * max(stat[1], 1e-12) * 4, "%s grad l2 %s: %g vs %g" % (self.name, pname, l2, stat[1])

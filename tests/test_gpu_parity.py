@@ -248,9 +248,9 @@ def test_encoder_matches_reference_golden(name):
         loss = loss + (torch.from_numpy(c).to(_dev()) * o).sum()
     loss.backward()
     for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
-        assert_close(o.detach().cpu().numpy(), g.z[k], "%s %s" % (name, k), tol=TOL)
+        assert_close(o.detach().cpu().numpy(), g.z[k], "%s %s" % (name, k), tol=TOL, b64=g.z[k + "_f64"])
     assert abs(float(kl.detach()) - float(g.z["kl"])) <= TOL * max(1.0, abs(float(g.z["kl"])))
-    assert_close(z.detach().cpu().numpy(), g.z["z"], name + " z", tol=TOL)
+    assert_close(z.detach().cpu().numpy(), g.z["z"], name + " z", tol=TOL, b64=g.z["z_f64"])
     assert abs(float(loss.detach()) - float(g.z["loss"])) <= TOL * max(1.0, abs(float(g.z["loss"])))
     for k, v in model.named_parameters():
         key = k[len("encoder."):] if k.startswith("encoder.") else k
@@ -294,11 +294,11 @@ def test_motif_encoder_matches_reference_golden(name):
         g.check_grad(k, v.grad.cpu().numpy(), rel=TOL)
 
 
-def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, grad_keys=None, tol=TOL, elem_tol=None):
-    """Full encoder on a synthetic batch: HIP path vs the oracle (fp32, same weights): the four outputs, the KL and the
-    gradient of EVERY parameter (``grad_keys`` restricts the gradient check to the listed parameters)."""
-    from golden_utils import ELEM_TOL
-    elem_tol = ELEM_TOL if elem_tol is None else elem_tol
+def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL):
+    """Full encoder on a synthetic batch: HIP path vs the oracle on the same weights -- the four outputs, the KL and the
+    gradient of EVERY parameter.  Norm-wise 1e-4 against the oracle's fp32 run (the BASELINE bar); per element
+    (golden_utils.assert_close) against the oracle's fp64 run, relative to the fp32 oracle's own rounding noise
+    (``f64=False`` skips the fp64 run -- large cases -- and leaves the norm-wise bar)."""
     from ggpm_amd import synth
     from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
     from ggpm_amd.property_vae import HierEncoderVAE
@@ -319,20 +319,28 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, grad_keys
     z, kl, outs = model((tree, graph), perturb_z=False)
     (kl + sum((o * o).sum() for o in outs)).backward()
 
-    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
-    tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
-    routs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
-    _, rkl = ref.rsample_kl(p, routs[0])
-    (rkl + sum((o * o).sum() for o in routs)).backward()
-    for name, o, r in zip(("hroot", "hnode", "hinter", "hatom"), outs, routs):
-        assert_close(o.detach().cpu().numpy(), r.detach().numpy(), name, tol=tol, elem_tol=elem_tol)
-    assert abs(float(kl.detach()) - float(rkl.detach())) <= tol * max(1.0, abs(float(rkl.detach())))
-    got = dict(model.named_parameters())
-    for k in (p.keys() if grad_keys is None else grad_keys):
-        want = p[k].grad.numpy() if p[k].grad is not None else np.zeros(tuple(p[k].shape), np.float32)
-        have = got[k if k.startswith("R_") else "encoder." + k].grad
-        have = have.cpu().numpy() if have is not None else np.zeros_like(want)
-        assert_close(have, want, "grad " + k, tol=tol, elem_tol=elem_tol)
+    runs = {}
+    for dtype in (torch.float32, torch.float64) if f64 else (torch.float32,):
+        p = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd.items()}
+        tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
+        routs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
+        _, rkl = ref.rsample_kl(p, routs[0])
+        (rkl + sum((o * o).sum() for o in routs)).backward()
+        r = {n: o.detach().numpy() for n, o in zip(("hroot", "hnode", "hinter", "hatom"), routs)}
+        for k, v in p.items():
+            r["grad " + k] = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))
+        r["kl"] = float(rkl.detach())
+        runs[dtype] = r
+        del p, routs
+    o32, o64 = runs[torch.float32], runs.get(torch.float64)
+    got = {n: o.detach().cpu().numpy() for n, o in zip(("hroot", "hnode", "hinter", "hatom"), outs)}
+    for k, v in model.named_parameters():
+        got["grad " + (k[len("encoder."):] if k.startswith("encoder.") else k)] = \
+            v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+    assert abs(float(kl.detach()) - o32["kl"]) <= tol * max(1.0, abs(o32["kl"]))
+    assert set(got) == set(o32) - {"kl"}
+    for k in got:
+        assert_close(got[k], o32[k], k, tol=tol, elem_tol=None, b64=None if o64 is None else o64[k])
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -376,7 +384,7 @@ def test_configs4_polymer_shard_matches_oracle(rnn):
     ~1 minute on this; bench.py --config 4 runs the 32-molecule batch)."""
     from ggpm_amd import synth
     specs = synth.random_batch(505, 6, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
-    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32)
+    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, f64=False)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -577,6 +585,58 @@ def test_fused_encoder_matches_op_by_op_path(name, which, monkeypatch):
         assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("name", ["tiny_gru_s1", "tiny_lstm_s2", "cfg_gru_s0", "cfg_lstm_s2"])
+def test_dropout_in_the_drivers_matches_oracle_with_the_same_masks(name):
+    """Training mode with dropout 0.1 (the thesis pre-training setting and 10 of the shipped configs) on the one-call C++
+    drivers: the counter-based masks of ggpm_dropout at the seven Dropout sites of ggpm/encoder.py:15-19,52-72.  torch's
+    generator cannot be bit-matched, so the SAME masks (restated in numpy, golden_utils.dropout_keep) are injected into
+    the oracle; outputs and every parameter gradient must agree.  Also: eval mode ignores dropout, two seeds differ."""
+    from golden_utils import dropout_keep
+    from ggpm_amd.nnutils import make_cuda
+    from oracle import ref_encoder as ref
+    g = Golden(name)
+    pdrop, seed = 0.1, (123456789, 987654321)
+    model = _build_encoder(g)
+    enc = model.encoder
+    enc.dropout = pdrop
+    enc._dropout_seed = seed
+    model.train()
+    tree, graph = make_cuda(g.numpy_tensors())
+    assert enc._fused_ok(tree, graph)
+    outs = enc.forward_padded(tree, graph)
+    H = g.H
+    coeffs = [torch.from_numpy(c).to(_dev()) for c in g.loss_coeffs([(o.shape[0], H) for o in outs])]
+    sum((c * o[:, :H]).sum() for c, o in zip(coeffs, outs)).backward()
+
+    N1t, N1g = tree[0].shape[0], graph[0].shape[0]
+    sites = {"E_i": (N1t, H, 0), "E_c": (N1t, H, 1), "graph_encoder.W_o": (N1g, H, 2), "W_i": (N1t, H, 3),
+             "inter_encoder.W_o": (N1t, H, 4), "W_c": (N1t, H, 5), "tree_encoder.W_o": (N1t, H, 6)}
+    masks = {k: torch.from_numpy(dropout_keep(r, c, pdrop, seed[0], seed[1], s).astype(np.float32) / (1.0 - pdrop))
+             for k, (r, c, s) in sites.items()}
+    keep = np.mean([float((m > 0).float().mean()) for m in masks.values()])
+    assert abs(keep - (1 - pdrop)) < 0.02
+    p = {k: v for k, v in g.params(requires_grad=True).items() if not k.startswith("R_")}
+    tt, gt = g.tensors()
+    routs = ref.hier_encoder_forward(p, g.rnn, g.depthT, g.depthG, tt, gt, masks=masks)
+    sum((torch.from_numpy(c.cpu().numpy()) * o).sum() for c, o in zip(coeffs, routs)).backward()
+    for k, o, r in zip(("hroot", "hnode", "hinter", "hatom"), outs, routs):
+        assert rel_err(o[:, :H].detach().cpu().numpy(), r.detach().numpy()) < TOL, k
+    for k, v in enc.named_parameters():
+        want = p[k].grad.numpy() if p[k].grad is not None else np.zeros(tuple(v.shape), np.float32)
+        assert rel_err(v.grad.cpu().numpy(), want) < TOL, k
+    # a different seed gives different outputs; eval mode gives the dropout-free ones
+    enc._dropout_seed = (1, 2)
+    other = enc.forward_padded(tree, graph)
+    assert not torch.equal(other[3], outs[3])
+    model.eval()
+    ev = enc.forward_padded(tree, graph)
+    enc.dropout = 0.0
+    model.train()
+    base = enc.forward_padded(tree, graph)
+    for a, b in zip(ev, base):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["cfg_gru_s0", "cfg_lstm_s2", "tiny_gru_s1", "edge_gru_s32"])
 def test_tree_fixed_point_shortcut_is_bit_identical(name):
     """With the longest dependency chain C of the tree messages known (make_cuda measures it on the host), the tree-side
@@ -687,8 +747,79 @@ def test_decoder_score_heads_match_reference_golden(name):
         assert rel_err(t.grad.cpu().numpy(), g.z["din/" + k]) < TOL, k
     for k, v in heads.named_parameters():
         if k.startswith("matchNN"):
-            continue                          # enum_attach is decoder-loop code, not part of the score/loss path
+            continue                          # not on this path: test_enum_attach_matches_reference_golden
         g.check_grad(k, v.grad.cpu().numpy(), TOL)
+
+
+def _attach_names():
+    import glob
+    import os
+    from golden_utils import GOLDEN_DIR
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "attach_*.npz")))
+
+
+@pytest.mark.parametrize("name", _attach_names())
+def test_enum_attach_matches_reference_golden(name):
+    """HierMPNDecoder.enum_attach (E_assm, E_order, matchNN; ggpm/decoder.py:286-301) vs vectors produced by the
+    reference: single-atom and atom-pair candidates, outputs and the gradients of matchNN, E_assm and the atom vectors."""
+    import os
+    import types
+    from golden_utils import GOLDEN_DIR
+    from ggpm_amd.decoder import HierMPNDecoder
+    from ggpm_amd.params import seeded_state_dict
+    from ggpm_amd.vocab import IndexPairVocab
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, L, n_motif, n_attach, n_atoms, n_cands, k, nth, seed = [int(v) for v in z["meta"]]
+    dec = HierMPNDecoder(IndexPairVocab(n_motif, n_attach), _Vocab(38), "GRU", H, H, L, 1, 2, 0.0).to(_dev())
+    sd = seeded_state_dict({"matchNN.0.weight": (H, 2 * H + 20), "matchNN.0.bias": (H,), "hmpn.E_i.0.weight": (n_attach, H)},
+                           seed)
+    res = dec.load_state_dict({kk: torch.from_numpy(v) for kk, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys
+    node = torch.from_numpy(z["node"]).to(_dev()).requires_grad_(True)
+    cands = z["cands"]
+    cl = [int(c[0]) for c in cands] if k == 1 else [tuple(int(v) for v in c) for c in cands]
+    out = dec.enum_attach(types.SimpleNamespace(node=node), cl, z["icls"].tolist(), nth)
+    (torch.from_numpy(z["coef"]).to(_dev()) * out).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), z["out"]) < TOL
+    assert rel_err(node.grad.cpu().numpy(), z["d_node"]) < TOL
+    named = dict(dec.named_parameters())
+    for kk in sd:
+        assert rel_err(named[kk].grad.cpu().numpy(), z["grad/" + kk]) < TOL, kk
+
+
+def _vae_names():
+    from golden_utils import vae_case_names
+    return vae_case_names()
+
+
+@pytest.mark.parametrize("name", _vae_names())
+def test_vae_step_matches_reference_golden(name):
+    """The full VAE training step -- HierPropertyVAE.forward (ggpm/property_vae.py:47-62): encoder, rsample, the
+    teacher-forced HierMPNDecoder.forward with enum_attach and the four losses (ggpm/decoder.py:166-301) -- and its
+    backward, vs vectors the reference itself produced: total loss (reconstruction + beta KL), KL, the metric tuple and
+    the gradient of every parameter (tied embeddings included)."""
+    from golden_utils import VaeGolden
+    from ggpm_amd import synth
+    from ggpm_amd.decoder import DecodeSchedule
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    g = VaeGolden(name)
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    model = HierPropertyVAE(g.args(IndexPairVocab(g.n_motif, g.n_attach))).to(_dev())
+    res = model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()}, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.startswith(("decoder.rnn_cell.", "decoder.E_assm.")) for k in res.missing_keys), res.missing_keys
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    loss, metrics = model(None, None, tensors, [None] * g.B, None, None, beta=g.beta, perturb_z=False, schedule=sch)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g.z["loss"])) <= TOL * abs(float(g.z["loss"]))
+    assert abs(metrics["KL:"] - float(g.z["kl"])) <= TOL * max(1.0, abs(float(g.z["kl"])))
+    got = [metrics[k] for k in ("Word", "I-Word", "Topo", "Assm")]
+    assert np.allclose(got, g.z["metrics"], atol=1e-6), (got, g.z["metrics"])
+    for k, v in model.named_parameters():
+        grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+        g.check_grad(k, grad, rel=TOL)
 
 
 def test_rsample_with_perturbation_matches_torch_formula():

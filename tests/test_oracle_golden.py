@@ -235,3 +235,122 @@ def test_tree_chain_length_matches_the_fixed_point_of_the_oracle():
     assert tree_chain_length(cyc) == 0
     import torch
     assert tree_chain_length(torch.from_numpy(bg)) == chain
+
+
+# ------------------------------------------------------------------------------------------ full VAE step (R1)
+from golden_utils import VaeGolden, vae_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", vae_case_names())
+def test_decode_schedule_matches_reference_bookkeeping(name):
+    """ggpm_amd.decoder.DecodeSchedule (host integer plumbing of the product) against the index lists the reference's
+    own decoder loop produced (ggpm/decoder.py:186-259), captured by make_golden_vae.py where the reference hands them
+    to IncHierMPNEncoder / zip_tensors."""
+    from ggpm_amd.decoder import DecodeSchedule
+    g = VaeGolden(name)
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    for a, b in zip(tensors[0][:-1], g.numpy_tensors()[0][:-1]):
+        assert (a == b).all()
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    ref = g.ref_steps()
+    assert len(sch.steps) == len(ref)
+    for st, (sn, sm, at, bo) in zip(sch.steps, ref):
+        assert st["subnode"] == sn and st["submess"] == sm
+        assert sorted(st["atoms"]) == sorted(at) and sorted(st["bonds"]) == sorted(bo)
+    tb, tl = sch.topo()
+    assert tb == g.z["ref_topo_batch"].tolist() and tl == g.z["ref_topo_label"].tolist()
+    cb, cc, ci = sch.cls()
+    assert cb == g.z["ref_cls_batch"].tolist() and cc == g.z["ref_cls_clab"].tolist() and ci == g.z["ref_cls_ilab"].tolist()
+    assert sch.assm_batch() == g.z["ref_assm_batch"].tolist()
+
+
+def test_decode_schedule_from_networkx_batch():
+    """The drop-in entry (``graphs`` as MolGraph.tensorize returns them): node attributes -> the same schedule."""
+    import networkx as nx
+    from ggpm_amd.decoder import DecodeSchedule, synth_orders
+    from ggpm_amd.vocab import IndexPairVocab
+    g = VaeGolden("vae_gru_s40")
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    tree = nx.DiGraph()
+    for b, m in enumerate(specs):
+        toff, aoff = tensors[0][-1][b][0], tensors[1][-1][b][0]
+        for i in range(m.n_motifs):
+            tree.add_node(toff + i, smiles="m%d" % m.motif_label[i][0],
+                          inter_label=[(a + aoff, "a%d" % att) for a, att in m.inter_label[i]],
+                          assm_cands=[x + aoff for x in m.assm_cands[i]])
+    orders = synth_orders(specs, tensors[0][-1])
+    a = DecodeSchedule.from_graphs((tree, None), tensors, orders, IndexPairVocab(g.n_motif, g.n_attach))
+    b = DecodeSchedule.from_specs(specs, tensors)
+    assert len(a.steps) == len(b.steps)
+    for x, y in zip(a.steps, b.steps):
+        assert all(x[k] == y[k] for k in x if k != "assm")
+        assert [(c.tolist(), i, n, bi) for c, i, n, bi in x["assm"]] == [(c.tolist(), i, n, bi) for c, i, n, bi in y["assm"]]
+
+
+@pytest.mark.parametrize("name", vae_case_names())
+def test_oracle_vae_step_matches_reference(name):
+    """oracle/ref_decoder.py (HierPropertyVAE.forward: encoder, rsample, teacher-forced decoder with enum_attach, the
+    four losses) against the reference's loss, KL, metric tuple and parameter gradients."""
+    from ggpm_amd.decoder import DecodeSchedule
+    from ggpm_amd.vocab import IndexPairVocab
+    from oracle import ref_decoder as refd
+    g = VaeGolden(name)
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    sd = g.state_dict()
+    p = {}
+    for k, v in sd.items():
+        p[k] = torch.from_numpy(v).requires_grad_(True)
+    if g.tie:
+        for k in ("E_c.0.weight", "E_i.0.weight"):
+            p["encoder." + k] = p["decoder.hmpn." + k]
+    tt, gt = ref.to_long_tensors(tensors[0]), ref.to_long_tensors(tensors[1])
+    mask = IndexPairVocab(g.n_motif, g.n_attach).mask
+    loss, kl, accs, recon = refd.vae_forward(p, g.rnn, g.depthT, g.depthG, g.diterT, g.diterG, tt, gt, sch, mask, g.beta)
+    loss.backward()
+    assert abs(float(loss) - float(g.z["loss"])) <= 2e-5 * abs(float(g.z["loss"]))
+    assert abs(float(kl) - float(g.z["kl"])) <= 2e-5 * max(1.0, abs(float(g.z["kl"])))
+    assert np.allclose([float(a) for a in accs], g.z["metrics"], atol=1e-6)
+    seen = set()
+    for k, v in p.items():
+        if id(v) in seen:
+            continue
+        seen.add(id(v))
+        key = k if not (g.tie and k.startswith("encoder.E_")) else "decoder.hmpn." + k[len("encoder."):]
+        grad = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+        g.check_grad(_ref_param_name(key, g), grad, rel=1e-4)
+
+
+def _ref_param_name(key, g):
+    """named_parameters() of the reference lists a shared tensor under the FIRST name it meets: the encoder's for tied
+    embeddings, ``decoder.hmpn.tree_encoder.rnn`` before the alias ``decoder.rnn_cell``."""
+    if g.tie and key.startswith("decoder.hmpn.E_"):
+        return "encoder." + key[len("decoder.hmpn."):]
+    return key
+
+
+def _attach_names():
+    import glob
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "attach_*.npz")))
+
+
+@pytest.mark.parametrize("name", _attach_names())
+def test_oracle_enum_attach_matches_reference(name):
+    """oracle/ref_decoder.enum_attach against the reference's HierMPNDecoder.enum_attach (single atoms and atom pairs)."""
+    from ggpm_amd.params import seeded_state_dict
+    from oracle import ref_decoder as refd
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, L, n_motif, n_attach, n_atoms, n_cands, k, nth, seed = [int(v) for v in z["meta"]]
+    sd = seeded_state_dict({"matchNN.0.weight": (H, 2 * H + 20), "matchNN.0.bias": (H,), "hmpn.E_i.0.weight": (n_attach, H)},
+                           seed)
+    p = {kk: torch.from_numpy(v).requires_grad_(True) for kk, v in sd.items()}
+    node = torch.from_numpy(z["node"]).requires_grad_(True)
+    out = refd.enum_attach(p, node, torch.from_numpy(z["cands"]), z["icls"].tolist(), nth)
+    (torch.from_numpy(z["coef"]) * out).sum().backward()
+    assert rel_err(out.detach().numpy(), z["out"]) < 2e-6
+    assert rel_err(node.grad.numpy(), z["d_node"]) < 2e-6
+    for kk in p:
+        assert rel_err(p[kk].grad.numpy(), z["grad/" + kk]) < 2e-6, kk
