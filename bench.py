@@ -230,8 +230,15 @@ class Workload:
             else:
                 torch.nn.init.xavier_normal_(p)
         broadcast_parameters(self.model)
-        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        # Adam (vae_train.py:60) on one flat view of the parameters; gradients in the flat buffer the all-reduce uses
+        # anyway (GGPM_FLAT_ADAM=0: torch.optim.Adam over the parameter list)
+        if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
+            from ggpm_amd.optim import FlatAdam
+            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
+            self.opt = FlatAdam(self.sync, lr=1e-3)
+        else:
+            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder)
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
         self.host_iter = None
         if a.host_input:
             import itertools
@@ -492,6 +499,7 @@ def main():
     ap.add_argument("--no-second-cell", action="store_true",
                     help="skip the run of the other message function (configs[1] reports GRU and, under \"lstm\", LSTM)")
     ap.add_argument("--no-vae", action="store_true", help="skip the full-VAE-step row (\"vae_step\", configs[1], N = 1)")
+    ap.add_argument("--only-vae", action="store_true", help="profiling: run ONLY the full-VAE-step row and print it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -529,6 +537,10 @@ def main():
     from ggpm_amd import _lib
     lib = _lib.load(build_if_missing=False)
 
+    if a.only_vae:
+        vae = VaeWorkload(cfg, rnn, a, dev)
+        print(json.dumps({"vae_step": vae.measure()}), flush=True)
+        return
     main_wl = Workload(cfg, rnn, a, rank, world, dev)
     m = main_wl.measure(lib, rank)
     n_motif, n_attach = cfg["vocab"]

@@ -166,12 +166,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
 
     if (dbg_on) a.dbg[1] = wall_clock64();
     if (dbg15) a.dbg[6] = wall_clock64();
+    // the first weight fragments of P2 travel from L2 while this wave waits for the slower gatherers
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const bool p2_gemm = !(a.ablate & 2) && !a.h0_zero;
+    const float* const wps2[2] = {a.Wz, a.Wh};
+    GgpmRing<2> ring2;
+    if (p2_gemm && t < t_end) ggpm_ring_prefetch<2>(wps2, KC, t, lane, ring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
     const int lr = lane & 15, row = r0 + lr;
-    const int t_end = min(NT, (grp + 1) * a.tg);
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
@@ -179,10 +184,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         const float4 xh = ggpm_ld4(a.Xh + o);
         f32x4 acc[2][RT];
         ggpm_zero_acc<2, RT>(acc);
-        if (!(a.ablate & 2) && !a.h0_zero) {
+        if (p2_gemm) {
             const float* const tiles[2] = {Ts, Tg};
-            const float* const wps[2] = {a.Wz, a.Wh};
-            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (dbg_on) a.dbg[3] = wall_clock64();
         float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
@@ -211,6 +215,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     if (!a.fuse_b) return;
 
     // ---- P3 (single column group only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
+    const float* const wps3[1] = {a.Ur};
+    GgpmRing<1> ring3;
+    if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     const float* Th = lds + 2 * ROWS * LD;
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
@@ -219,8 +226,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         const float* const tiles[1] = {Th};
-        const float* const wps[1] = {a.Ur};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
     }
 }
@@ -234,10 +240,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps[1] = {a.Ur};
+    GgpmRing<1> ring;
+    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
     const int row = r0 + (lane & 15);
-    const int t_end = min(NT, (grp + 1) * a.tg);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const float4 b = ggpm_ld4(a.bu + c);
@@ -245,8 +254,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!(a.ablate & 2)) {
             const float* const tiles[1] = {Th};
-            const float* const wps[1] = {a.Ur};
-            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
     }
@@ -354,12 +362,15 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     }
 
     if (dbg_on) a.dbg[1] = wall_clock64();
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps2[1] = {a.UrT};
+    GgpmRing<1> ring2;
+    if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dq stash stores finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: dh = partial + dq . U_r ; gate derivatives, for this wave's tiles
     const int lr = lane & 15, row = r0 + lr;
-    const int t_end = min(NT, (grp + 1) * a.tg);
     float4 dsd_keep[2] = {ggpm_zero4(), ggpm_zero4()};      // fused P3: ds_dir of this wave's (at most two) tiles
     int it = 0;
     for (int tt = t; tt < t_end; tt += GGPM_NWA, ++it) {
@@ -375,8 +386,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            const float* const wps[1] = {a.UrT};
-            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (dbg_on) a.dbg[3] = wall_clock64();
         if (row >= a.E1) {
@@ -431,6 +441,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 
     // ---- P3 (single column group only): the workgroup holds the complete dz_pre / dm_pre rows ->
     // dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h ; dXr += dG * R   (the body of kernel B)
+    const float* const wps3[2] = {a.WhT, a.WzT};
+    GgpmRing<2> ring3;
+    if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     it = 0;
     for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
@@ -442,8 +455,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         ggpm_zero_acc<2, RT>(acc);
         {
             const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
-            const float* const wps[2] = {a.WhT, a.WzT};
-            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         }
         if (row >= a.E1) continue;
         const float4 dg = ggpm_f4(acc[0][0]);
@@ -464,11 +476,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps[2] = {a.WhT, a.WzT};
+    GgpmRing<2> ring;
+    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<2>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
     ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
     ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
     __syncthreads();
     const int e = r0 + (lane & 15);
-    const int t_end = min(NT, (grp + 1) * a.tg);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
@@ -478,8 +493,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
         ggpm_zero_acc<2, RT>(acc);
         {
             const float* const tiles[2] = {T2, T1};
-            const float* const wps[2] = {a.WhT, a.WzT};
-            ggpm_wave_gemm<2, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         if (e >= a.E1) continue;
         const float4 dg = ggpm_f4(acc[0][0]);

@@ -111,10 +111,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         }
     }
 
+    // the first weight fragments of P2 travel from L2 while this wave waits for the slower gatherers
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps2[3] = {a.Wi, a.Wo, a.Wu};
+    GgpmRing<3> ring2;
+    if (!a.h0_zero && t < t_end) ggpm_ring_prefetch<3>(wps2, KC, t, lane, ring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
-    const int t_end = min(NT, (grp + 1) * a.tg);
     float* Th = lds + 2 * ROWS * LD;      // fused P3 only: the complete h' rows of this workgroup
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
@@ -124,8 +128,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         ggpm_zero_acc<3, RT>(acc);
         if (!a.h0_zero) {
             const float* const tiles[3] = {Ts, Ts, Ts};
-            const float* const wps[3] = {a.Wi, a.Wo, a.Wu};
-            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
         if (row >= a.E1) {
@@ -158,13 +161,15 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     if (!a.fuse_b) return;
 
     // ---- P3 (single column group only): qf' = Wf_h h' from the rows this workgroup already holds
+    const float* const wps3[1] = {a.Wf};
+    GgpmRing<1> ring3;
+    if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         const float* const tiles[1] = {Th};
-        const float* const wps[1] = {a.Wf};
-        ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+        ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
     }
@@ -179,17 +184,19 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps[1] = {a.Wf};
+    GgpmRing<1> ring;
+    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
     const int row = r0 + (lane & 15);
-    const int t_end = min(NT, (grp + 1) * a.tg);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         {
             const float* const tiles[1] = {Th};
-            const float* const wps[1] = {a.Wf};
-            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
@@ -296,10 +303,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         }
     }
 
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps2[1] = {a.WfT};
+    GgpmRing<1> ring2;
+    if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dqf stash stores finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
-    const int t_end = min(NT, (grp + 1) * a.tg);
     float* Ta = lds + 3 * ROWS * LD;      // fused P3 only: complete di_pre / do_pre / du_pre rows
     float* Tb = lds + 4 * ROWS * LD;
     float* Tc = lds + 5 * ROWS * LD;
@@ -322,8 +332,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            const float* const wps[1] = {a.WfT};
-            ggpm_wave_gemm<1, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (row >= a.E1) {
             if (a.fuse_b) {
@@ -392,14 +401,16 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     if (!a.fuse_b) return;
 
     // ---- P3 (single column group only): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h from the rows held here
+    const float* const wps3[3] = {a.WiT, a.WoT, a.WuT};
+    GgpmRing<3> ring3;
+    if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
         f32x4 acc[3][RT];
         ggpm_zero_acc<3, RT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
-            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1)
@@ -418,19 +429,21 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
+    const int t_end = min(NT, (grp + 1) * a.tg);
+    const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
+    GgpmRing<3> ring;
+    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<3>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
     ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
     ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
     ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
     __syncthreads();
     const int e = r0 + (lane & 15);
-    const int t_end = min(NT, (grp + 1) * a.tg);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         f32x4 acc[3][RT];
         ggpm_zero_acc<3, RT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
-            ggpm_wave_gemm<3, RT>(tiles, LD, wps, KC, tt, lane, acc);
+            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (e < a.E1)

@@ -16,6 +16,7 @@
 // this code, so results are run-to-run bitwise identical.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 constexpr int GGPM_NW = 4;        // waves per workgroup of the "B" kernels (one output tile per wave)
 constexpr int GGPM_NWA = 16;      // waves per workgroup of the "A" kernels: all 16 gather, the first TG own a tile
@@ -26,25 +27,46 @@ __device__ __forceinline__ size_t ggpm_pack_index(int t, int kc, int KC, int lan
     return (((size_t)t * KC + kc) * 64 + lane) * 4;
 }
 
+// Weight-fragment prefetch ring of one wave: PF k chunks x NOPS products, one 16-byte fragment per lane each.
+template <int NOPS>
+struct GgpmRing {
+    f32x4 r[GGPM_PF][NOPS];
+};
+
+// Loads the first PF chunks of tile t into the ring.  The weights do not depend on anything the kernel computes, so a
+// phase issues this BEFORE the barrier that publishes its activation tile: the L2 round trip (~1-2 us, otherwise
+// exposed at the head of every phase) then runs while the wave waits for the slower waves of its workgroup.
+template <int NOPS>
+__device__ __forceinline__ void ggpm_ring_prefetch(const float* const (&wps)[NOPS], int KC, int t, int lane,
+                                                   GgpmRing<NOPS>& ring) {
+#pragma unroll
+    for (int d = 0; d < GGPM_PF; ++d) {
+        const int kk = min(d, KC - 1);
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o)
+            ring.r[d][o] = *reinterpret_cast<const f32x4*>(wps[o] + ggpm_pack_index(t, kk, KC, lane));
+    }
+}
+
 // acc[op][r] += Wp[op](tile t) x tile[op](row tile r)^T   for NOPS independent products sharing the k loop
 // (e.g. the z and m gates of a GRU step).  Straight-line body: NOPS refill loads + NOPS*RT ds_read_b128 +
-// 4*NOPS*RT MFMAs per k chunk; the refill index is clamped instead of branched.
-template <int NOPS, int RT>
-__device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS], int LD,
-                                               const float* const (&wps)[NOPS], int KC, int t, int lane,
-                                               f32x4 (&acc)[NOPS][RT]) {
+// 4*NOPS*RT MFMAs per k chunk.  `ring` must hold the first PF chunks of tile t (ggpm_ring_prefetch); refills past the
+// end of tile t fetch the head of tile `t_next` (>= 0: the wave's next tile of the same products, whose call then
+// finds its ring loaded) or re-read the last chunk (t_next < 0; no branch).
+template <int NOPS, int RT, bool CHAIN = (NOPS < 3)>      // (three products: the chained ring costs registers -> spills)
+__device__ __forceinline__ void ggpm_wave_gemm_ring(const float* const (&tiles)[NOPS], int LD,
+                                                    const float* const (&wps)[NOPS], int KC, int t, int t_next, int lane,
+                                                    f32x4 (&acc)[NOPS][RT], GgpmRing<NOPS>& ring) {
     constexpr int PF = GGPM_PF;       // (a deeper ring for the single-product loops measured no faster)
     const int boff = (lane & 15) * LD + 4 * (lane >> 4);
     const float* wp[NOPS];
+    const float* wn[NOPS];
 #pragma unroll
-    for (int o = 0; o < NOPS; ++o) wp[o] = wps[o] + ggpm_pack_index(t, 0, KC, lane);
-    f32x4 ring[PF][NOPS];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        const int kk = min(d, KC - 1);
-#pragma unroll
-        for (int o = 0; o < NOPS; ++o) ring[d][o] = *reinterpret_cast<const f32x4*>(wp[o] + (size_t)kk * 256);
+    for (int o = 0; o < NOPS; ++o) {
+        wp[o] = wps[o] + ggpm_pack_index(t, 0, KC, lane);
+        wn[o] = wps[o] + ggpm_pack_index(t_next >= 0 ? t_next : t, 0, KC, lane);
     }
+    const bool chain = CHAIN && t_next >= 0 && KC >= PF;      // (KC < PF: the loop below never refills: re-prefetch)
     int kc = 0;
     for (; kc + PF <= KC; kc += PF) {
 #pragma unroll
@@ -52,14 +74,17 @@ __device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS]
             f32x4 a[NOPS], b[NOPS][RT];
 #pragma unroll
             for (int o = 0; o < NOPS; ++o) {
-                a[o] = ring[d][o];
+                a[o] = ring.r[d][o];
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
                     b[o][r] = *reinterpret_cast<const f32x4*>(tiles[o] + r * 16 * LD + boff + (kc + d) * 16);
             }
-            const int kn = min(kc + d + PF, KC - 1);
+            const int kq = kc + d + PF;
+            const bool over = kq >= KC;
+            const int kn = over ? (chain ? kq - KC : KC - 1) : kq;
 #pragma unroll
-            for (int o = 0; o < NOPS; ++o) ring[d][o] = *reinterpret_cast<const f32x4*>(wp[o] + (size_t)kn * 256);
+            for (int o = 0; o < NOPS; ++o)
+                ring.r[d][o] = *reinterpret_cast<const f32x4*>((over && chain ? wn[o] : wp[o]) + (size_t)kn * 256);
             __builtin_amdgcn_sched_barrier(0);   // keep the refill loads HERE (PF chunks ahead of their use)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -70,10 +95,11 @@ __device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS]
                         acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[o][s], b[o][r][s], acc[o][r], 0, 0, 0);
         }
     }
-    // remainder (KC % PF chunks): their fragments already sit in ring[0 .. rem)
+    // remainder (rem = KC % PF chunks): their fragments sit in ring slots [0, rem)
+    const int rem = KC - kc;
 #pragma unroll
     for (int d = 0; d < PF - 1; ++d) {
-        if (kc + d < KC) {
+        if (d < rem) {
 #pragma unroll
             for (int o = 0; o < NOPS; ++o)
 #pragma unroll
@@ -81,10 +107,46 @@ __device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS]
                     const f32x4 b = *reinterpret_cast<const f32x4*>(tiles[o] + r * 16 * LD + boff + (kc + d) * 16);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[d][o][s], b[s], acc[o][r], 0, 0, 0);
+                        acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.r[d][o][s], b[s], acc[o][r], 0, 0, 0);
                 }
         }
     }
+    if (t_next < 0) return;
+    if (!CHAIN || !chain) {
+        ggpm_ring_prefetch<NOPS>(wps, KC, t_next, lane, ring);
+        return;
+    }
+    // chained: the slots [rem, PF) already hold chunks 0 .. PF-rem-1 of tile t_next (refilled by the last trips of the
+    // loop above); rotate them to the front and fetch the missing rem chunks, so that the ring looks as
+    // ggpm_ring_prefetch(t_next) would have left it -- but with most of it loaded a whole tile ago
+    auto rotate = [&](auto R) {
+        constexpr int r0 = decltype(R)::value;
+        if constexpr (r0 > 0) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d)
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o) {
+                    if (d + r0 < PF) ring.r[d][o] = ring.r[d + r0][o];
+                    else ring.r[d][o] = *reinterpret_cast<const f32x4*>(wn[o] + (size_t)d * 256);
+                }
+        }
+    };
+    switch (rem) {
+        case 1: rotate(std::integral_constant<int, 1>{}); break;
+        case 2: rotate(std::integral_constant<int, 2>{}); break;
+        case 3: rotate(std::integral_constant<int, 3>{}); break;
+        default: break;
+    }
+}
+
+// One product set on one tile with the ring loaded on the spot (phases that have nothing to overlap the load with).
+template <int NOPS, int RT>
+__device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS], int LD,
+                                               const float* const (&wps)[NOPS], int KC, int t, int lane,
+                                               f32x4 (&acc)[NOPS][RT]) {
+    GgpmRing<NOPS> ring;
+    ggpm_ring_prefetch<NOPS>(wps, KC, t, lane, ring);
+    ggpm_wave_gemm_ring<NOPS, RT>(tiles, LD, wps, KC, t, -1, lane, acc, ring);
 }
 
 template <int NOPS, int RT>

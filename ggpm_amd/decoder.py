@@ -189,11 +189,13 @@ class DecodeSchedule:
         if torch.device(device).type == "cuda":
             hostbuf = hostbuf.pin_memory()
         devbuf = hostbuf.to(device, non_blocking=True)
+        dev32 = devbuf.to(torch.int32)          # embedding ids are int32 for the gather kernels (one conversion per batch)
         view = lambda k: devbuf[where[k][0]:where[k][0] + where[k][1]]
+        view32 = lambda k: dev32[where[k][0]:where[k][0] + where[k][1]]
         steps = []
         for e in plan:
             d = {k: view(e[k]) for k in ("subnode", "submess", "atoms", "bonds", "cls_mess")}
-            d["assm"] = [(k, {n: view(v) for n, v in g.items()}) for k, g in e["assm"]]
+            d["assm"] = [(k, {n: (view32(v) if n == "icls" else view(v)) for n, v in g.items()}) for k, g in e["assm"]]
             steps.append(d)
         self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, **{k: view(v) for k, v in tail.items()})
         return self
@@ -233,6 +235,7 @@ class HierMPNDecoder(ScoreHeads):
     def enum_attach_batched(self, hgraph_node, k: int, atoms, icls, nth) -> torch.Tensor:
         """``enum_attach`` (ggpm/decoder.py:286-301) for all predictions of one step whose candidates consist of ``k``
         atoms: ``matchNN([node[cand] | E_assm(icls) | onehot(nth_child)])``, summed over the ``k`` atoms of a candidate.
+        ``atoms`` / ``nth`` int64, ``icls`` int32 (embedding ids, as the gather kernel reads them).
         -> [candidates, Hp] (zero pad columns)."""
         H, He = self.hidden_size, self.embed_size
         cand = hgraph_node.index_select(0, atoms).contiguous()
@@ -247,7 +250,7 @@ class HierMPNDecoder(ScoreHeads):
         dev = hgraph.node.device
         c = torch.as_tensor(np.asarray(cands, dtype=np.int64).reshape(len(cands), -1), device=dev)
         k, n = c.shape[1], c.shape[0]
-        ic = torch.as_tensor(list(icls) * n, dtype=torch.long, device=dev)
+        ic = torch.as_tensor(list(icls) * n, dtype=torch.int32, device=dev)
         nth = torch.full((n * k,), int(nth_child), dtype=torch.long, device=dev)
         return self.enum_attach_batched(hgraph.node, k, c.reshape(-1), ic, nth)[:, :self.hidden_size]
 

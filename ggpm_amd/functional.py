@@ -46,6 +46,13 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+def _empty_same_layout(x: torch.Tensor) -> torch.Tensor:
+    """An uninitialised [rows, cols] tensor with x's leading dimension.  (``torch.empty_like`` of a column slice of a
+    padded buffer -- e.g. the [rows, H + 20] view of a [rows, ld] message-input buffer when H + 20 is not a multiple
+    of 4 -- returns a DENSE tensor, whose leading dimension is not x's.)"""
+    return torch.empty(x.shape[0], _ld(x), dtype=x.dtype, device=x.device)[:, :x.shape[1]]
+
+
 # ----------------------------------------------------------------------------- graph layout
 class CSR:
     """Device CSR (int32 rowptr[rows+1], col[cap]) plus its lazily built transpose."""
@@ -568,7 +575,7 @@ class _GruLevel(torch.autograd.Function):
         ldx = _ld(x)
         dx = None
         if ctx.needs_input_grad[0]:      # needed upstream right away: stays on the main stream
-            dx = torch.empty_like(x)
+            dx = _empty_same_layout(x)
             gemm(0, 0, E1, I, H, dX[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x.shape[1])
             gemm(0, 0, E1, I, H, dX[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
             gemm(0, 0, E1, I, H, dX[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
@@ -707,7 +714,7 @@ class _GruSparse(torch.autograd.Function):
         db_z, db_h = colsum(dXs[0], ms, H), colsum(dXs[2], ms, H)
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x_sub)
+            dx = _empty_same_layout(x_sub)
             gemm(0, 0, ms, I, H, dXs[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x_sub.shape[1])
             gemm(0, 0, ms, I, H, dXs[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
             gemm(0, 0, ms, I, H, dXs[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
@@ -804,7 +811,7 @@ class _LstmSparse(torch.autograd.Function):
             dbs.append(colsum(dXs[k], ms, H))
         dx = None
         if ctx.needs_input_grad[2]:
-            dx = torch.empty_like(x_sub)
+            dx = _empty_same_layout(x_sub)
             for k in range(4):
                 gemm(0, 0, ms, I, H, dXs[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx,
                      x_sub.shape[1] if k == 0 else I, accumulate=k > 0)
@@ -887,7 +894,7 @@ class _LstmLevel(torch.autograd.Function):
         ldx = _ld(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = _empty_same_layout(x)
             for k in range(4):
                 gemm(0, 0, E1, I, H, dX[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx, x.shape[1] if k == 0 else I,
                      accumulate=k > 0)

@@ -39,7 +39,7 @@ class FlatGradSync:
     collectives were slower than one (6.38 vs 5.98 ms/step) and the multi-GPU balance could not be measured here.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, encoder=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, encoder=None, keep_flat: bool = False):
         import os
         import weakref
         seen, uniq = set(), []
@@ -77,12 +77,18 @@ class FlatGradSync:
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # rehearsal switch: run the pack + collective even with one rank (exercises the RCCL path on a 1-GPU box)
         self.force = dist.is_initialized() and os.environ.get("GGPM_FORCE_ALLREDUCE") == "1"
+        # keep_flat: gradients live in the flat buffer on ONE rank too (no collective): the encoder backward writes
+        # there and ggpm_amd.optim.FlatAdam reads it as the gradient of its single flat parameter
+        self.keep_flat = keep_flat
         self._early_work = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"             # RCCL averages in the collective; gloo sums, then one division
 
     # ------------------------------------------------------------------ interface used by fused._HierEncoder.backward
     def active(self) -> bool:
+        return self.world_size > 1 or self.force or self.keep_flat
+
+    def collective(self) -> bool:
         return self.world_size > 1 or self.force
 
     def accepts(self, params) -> bool:
@@ -90,7 +96,7 @@ class FlatGradSync:
                 and all(p is q for p, q in zip(params, self.encoder_params)))
 
     def wants_early_bucket(self) -> bool:
-        return self.bucketed and self.early_numel > 0
+        return self.bucketed and self.early_numel > 0 and self.collective()
 
     def _reduce(self, t: torch.Tensor, async_op: bool):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -121,6 +127,12 @@ class FlatGradSync:
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks then divide by world size (mean of per-rank batch-mean losses)."""
         if not self.active():
+            return None
+        if not self.collective():         # one rank, keep_flat: only gather what autograd left outside the buffer
+            in_place = len(self.encoder_params) > 0 and all(
+                p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                for p, v in zip(self.encoder_params, self.encoder_views))
+            self.pack(start=len(self.encoder_params) if in_place else 0)
             return None
         early, self._early_work = self._early_work, None
         if early is not None:

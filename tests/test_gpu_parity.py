@@ -294,7 +294,7 @@ def test_motif_encoder_matches_reference_golden(name):
         g.check_grad(k, v.grad.cpu().numpy(), rel=TOL)
 
 
-def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL):
+def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None):
     """Full encoder on a synthetic batch: HIP path vs the oracle on the same weights -- the four outputs, the KL and the
     gradient of EVERY parameter.  Norm-wise 1e-4 against the oracle's fp32 run (the BASELINE bar); per element
     (golden_utils.assert_close) against the oracle's fp64 run, relative to the fp32 oracle's own rounding noise
@@ -340,7 +340,7 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True,
     assert abs(float(kl.detach()) - o32["kl"]) <= tol * max(1.0, abs(o32["kl"]))
     assert set(got) == set(o32) - {"kl"}
     for k in got:
-        assert_close(got[k], o32[k], k, tol=tol, elem_tol=None, b64=None if o64 is None else o64[k])
+        assert_close(got[k], o32[k], k, tol=tol, elem_tol=None, b64=None if o64 is None else o64[k], slack=slack)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -380,11 +380,16 @@ def test_configs3_h600_shard_matches_oracle():
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
 def test_configs4_polymer_shard_matches_oracle(rnn):
-    """BASELINE configs[4] in fp32: ~200-atom polymers (46..58 motifs), H = 600, depth 30, 6 molecules (the oracle needs
-    ~1 minute on this; bench.py --config 4 runs the 32-molecule batch)."""
+    """BASELINE configs[4] in fp32: ~200-atom polymers (46..58 motifs), H = 600, depth 30, 4 molecules (the oracle's fp32
+    and fp64 runs need ~1 minute on this; bench.py --config 4 runs the 32-molecule batch).  The LSTM case meets the
+    1e-4 bar.  The GRU recurrence with seeded random weights is chaotic at this depth on ~50-motif trees (its state is a
+    SUM over predecessors, h' = (1-z) sum_p h_p + z m, and grows along branching paths until the reset gates saturate):
+    the REFERENCE's own fp32 run is 2e-3 (hroot) to 8e-3 (gradients) away from its fp64 run
+    (profiles/r02_parity_report_configs4_gru.txt), and two fp32 evaluation orders differ by that amplification times a
+    random factor.  There the check is that the HIP result stays within 32x the reference's own distance to fp64."""
     from ggpm_amd import synth
-    specs = synth.random_batch(505, 6, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
-    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, f64=False)
+    specs = synth.random_batch(505, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
+    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, slack=32.0 if rnn == "GRU" else None)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -439,6 +444,52 @@ def test_sparse_forward_matches_reference_golden(name):
         assert rel_err(ct.grad.cpu().numpy()[1:], z["dc_in"][1:]) < TOL
     for k, v in mod.named_parameters():
         assert rel_err(v.grad.cpu().numpy(), z["grad/" + k]) < TOL, k
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+@pytest.mark.parametrize("E1,I,H,depth,ms", [(450, 62, 250, 5, 120), (450, 270, 250, 1, 40), (700, 62, 300, 5, 200),
+                                            (120, 620, 600, 1, 30)])
+def test_sparse_forward_matches_oracle_at_config_sizes(rnn, E1, I, H, depth, ms):
+    """sparse_forward at the hidden sizes / depths the decoder uses it with (diterG = 5 on the atom level, diterT = 1 on
+    the tree levels; H = 250 / 300 / 600) against the oracle: new state, and the gradients of the incoming state, the
+    inputs and every parameter."""
+    from golden_utils import sparse_inputs
+    from ggpm_amd import rnn as R
+    from ggpm_amd.params import rnn_param_shapes, seeded_state_dict
+    from oracle import ref_encoder as ref
+    h, c, submess, x, bg, coef = sparse_inputs(E1, I, H, ms, 4, E1 + H + depth)
+    sd = seeded_state_dict(rnn_param_shapes(rnn, I, H), 3)
+    mod = (R.GRU if rnn == "GRU" else R.LSTM)(I, H, depth).to(_dev())
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ht, ct = (torch.from_numpy(a).to(_dev()).requires_grad_(True) for a in (h, c))
+    # the inputs arrive as the decoder hands them over: a column slice of a padded [ms, ceil4(I)] buffer (not dense
+    # when I = H + 20 is not a multiple of 4, e.g. H = 250)
+    xbuf = torch.zeros(ms, (I + 3) // 4 * 4, device=_dev())
+    xbuf[:, :I] = torch.from_numpy(x).to(_dev())
+    xleaf = xbuf.requires_grad_(True)
+    xt = xleaf[:, :I]
+    sm, bgt = torch.from_numpy(submess).to(_dev()), torch.from_numpy(bg).to(_dev())
+    cf = torch.from_numpy(coef).to(_dev())
+    p = {"rnn." + k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    hr, cr, xr = (torch.from_numpy(a).requires_grad_(True) for a in (h, c, x))
+    if rnn == "GRU":
+        ho = mod.sparse_forward(ht, xt, sm, bgt)
+        (cf[0] * ho).sum().backward()
+        ro = ref.gru_sparse_forward(p, "rnn.", hr, xr, torch.from_numpy(submess), torch.from_numpy(bg), depth)
+        (torch.from_numpy(coef[0]) * ro).sum().backward()
+    else:
+        ho, co = mod.sparse_forward((ht, ct), xt, sm, bgt)
+        ((cf[0] * ho).sum() + (cf[1] * co).sum()).backward()
+        ro, rc = ref.lstm_sparse_forward(p, "rnn.", hr, cr, xr, torch.from_numpy(submess), torch.from_numpy(bg), depth)
+        ((torch.from_numpy(coef[0]) * ro).sum() + (torch.from_numpy(coef[1]) * rc).sum()).backward()
+        assert rel_err(co.detach().cpu().numpy(), rc.detach().numpy()) < TOL
+        assert rel_err(ct.grad.cpu().numpy()[1:], cr.grad.numpy()[1:]) < TOL
+    assert rel_err(ho.detach().cpu().numpy(), ro.detach().numpy()) < TOL
+    assert rel_err(ht.grad.cpu().numpy()[1:], hr.grad.numpy()[1:]) < TOL          # (row 0: see the golden test above)
+    assert rel_err(xleaf.grad[:, :I].cpu().numpy(), xr.grad.numpy()) < TOL
+    assert float(xleaf.grad[:, I:].abs().sum()) == 0.0
+    for k, v in mod.named_parameters():
+        assert rel_err(v.grad.cpu().numpy(), p["rnn." + k].grad.numpy()) < TOL, k
 
 
 def _inc_names():

@@ -81,3 +81,25 @@ def test_flat_grad_allreduce_world2_gloo():
             grads.append(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]))
         mean = (grads[0] + grads[1]) / 2
         assert torch.allclose(torch.from_numpy(res[0][1][step]), mean, atol=1e-7)
+
+
+def test_flat_adam_equals_adam_over_the_parameter_list():
+    """ggpm_amd.optim.FlatAdam (one flat view of all parameters, gradients in FlatGradSync's flat buffer) gives exactly
+    the parameters torch.optim.Adam over model.parameters() gives (vae_train.py:60)."""
+    from ggpm_amd.optim import FlatAdam
+    a, b = _model(seed=3), _model(seed=3)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2)
+    sync = FlatGradSync(b.parameters(), keep_flat=True)
+    ob = FlatAdam(sync, lr=1e-2)
+    for i in range(4):
+        x = _data(i)
+        oa.zero_grad()
+        a(x).pow(2).mean().backward()
+        oa.step()
+        ob.zero_grad()
+        b(x).pow(2).mean().backward()
+        sync.all_reduce()
+        ob.step()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
