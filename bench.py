@@ -212,7 +212,7 @@ def cpu_baseline(batches, rnn, H, depth, latent, n_motif, n_attach, budget_s=24.
 class Workload:
     """One (config, message function) pair on this rank: model, optimizer, device-resident batches."""
 
-    def __init__(self, cfg, rnn, a, rank, world, dev):
+    def __init__(self, cfg, rnn, a, rank, world, dev, gate_dtype="f32"):
         from ggpm_amd.nnutils import make_cuda
         from ggpm_amd.parallel import FlatGradSync, broadcast_parameters
         from ggpm_amd.property_vae import HierEncoderVAE
@@ -229,6 +229,7 @@ class Workload:
                 torch.nn.init.constant_(p, 0)
             else:
                 torch.nn.init.xavier_normal_(p)
+        self.model.encoder.gate_dtype = gate_dtype
         broadcast_parameters(self.model)
         # Adam (vae_train.py:60) on one flat view of the parameters; gradients in the flat buffer the all-reduce uses
         # anyway (GGPM_FLAT_ADAM=0: torch.optim.Adam over the parameter list)
@@ -372,9 +373,11 @@ class Workload:
         kname = max(per["atom"], key=lambda k: per["atom"][k]["total_ms"])      # dominant kernel of the step
         k = per["atom"][kname]
         traffic = None
-        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        try:      # HBM bytes per ATOM-LEVEL launch from the committed rocprofv3 --pmc passes of this same command
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(self.rnn, {}).get(kname)
+                tj = json.load(f)
+            if self.cfg is CONFIGS.get(1) or all(self.cfg[k] == CONFIGS[1][k] for k in ("hidden", "depth", "batch", "gen")):
+                traffic = tj.get(self.rnn + "_atom_level", {}).get(kname, {}).get("bytes_per_launch")
         except Exception:
             pass
         tree = {lv: per[lv][kname] for lv in ("attachment", "motif") if kname in per.get(lv, {})}
@@ -485,6 +488,9 @@ def main():
                          "been seen (allocator blocks, lazily created streams and events) before the timed region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs[]")
     ap.add_argument("--rnn", default=None, choices=["GRU", "LSTM"], help="message function (default: the config's)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="gate products of the depth loops: fp32 MFMA (parity contract) or bf16 operands with fp32 "
+                         "accumulate (configs[4]; everything else stays fp32).  --config 4 reports both.")
     ap.add_argument("--hidden", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
@@ -541,7 +547,7 @@ def main():
         vae = VaeWorkload(cfg, rnn, a, dev)
         print(json.dumps({"vae_step": vae.measure()}), flush=True)
         return
-    main_wl = Workload(cfg, rnn, a, rank, world, dev)
+    main_wl = Workload(cfg, rnn, a, rank, world, dev, gate_dtype=a.dtype)
     m = main_wl.measure(lib, rank)
     n_motif, n_attach = cfg["vocab"]
     result = {
@@ -549,7 +555,7 @@ def main():
                   "(encoder + KL heads + optimizer)",
         "value": m["value"], "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic" + (" (host-resident batches, PCIe-inclusive diagnostic)" if a.host_input else ""),
         "config": {"workload": "BASELINE %s: %.1f atoms/molecule, motif vocab %d/%d, hidden=%d depth=%d latent=%d "
                                "batch=%d per GPU, %s cell; step = zero_grad + encoder fwd + KL + bwd%s + Adam"
@@ -579,6 +585,20 @@ def main():
                                              "algorithmic_gflop_per_step_per_gpu", "step_tflops_executed",
                                              "full_depth_loops", "roofline") if k in mo}
         cpu_runs.append(("LSTM", other.pool))
+
+    # configs[4] names bf16: the same workload with bf16 gate products, in the same line
+    if a.config == 4 and a.dtype == "f32" and not a.no_second_cell and not a.host_input:
+        del main_wl
+        torch.cuda.empty_cache()
+        other = Workload(cfg, rnn, a, rank, world, dev, gate_dtype="bf16")
+        mo = other.measure(lib, rank)
+        result["bf16"] = {k: mo[k] for k in ("ms_per_step", "value", "unit", "host_enqueue_ms_per_step",
+                                             "step_tflops_executed", "full_depth_loops", "roofline") if k in mo}
+        result["bf16"]["dtype"] = ("bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16) for the H x H gate products of "
+                                   "the depth loops; state, stashes, gate math, input projections and weight-gradient "
+                                   "contractions fp32; tolerance: tests/test_gpu_parity.py::test_bf16_gate_products")
+        if "roofline" in result["bf16"]:
+            result["bf16"]["roofline"]["note"] = "fractions are quoted against the fp32 MFMA peak for comparability"
 
     # the reported row: full VAE training step (never allowed to cost the line)
     vae = None

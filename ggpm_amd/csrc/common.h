@@ -78,6 +78,11 @@ int ggpm_take_backward_lo();
 void ggpm_wgrad_lo_depth(int lo);
 int ggpm_take_wgrad_lo();
 
+// Gate-product dtype of the level calls issued by this thread: 0 fp32 (default), 1 bf16 operands.  Set by the encoder
+// drivers from ggpm_enc_dims.gate_dtype for the duration of their call (mpn_gru.hip).
+void ggpm_set_gate_dtype(int dtype);
+int ggpm_gate_dtype();
+
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
 void ggpm_timing_tag(int tag);       // 1 atom, 2 attachment, 3 motif level, 0 untagged; collected as which + 8 * tag
 void ggpm_timing_begin(int which, hipStream_t s, double flops);

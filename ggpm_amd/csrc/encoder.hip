@@ -58,6 +58,13 @@ struct Dims {
     int tree_chain;                // longest dependency chain of the tree messages (0: unknown)
     float dropout;                 // training-mode drop probability (0: none)
     unsigned int seed_lo, seed_hi;
+    int gate_dtype;                // 0 fp32, 1 bf16 operands for the gate products of the depth loops
+};
+
+// the level calls of this thread take the gate-product dtype from a thread-local (tile_mma.h) for the driver's duration
+struct GateDtypeScope {
+    explicit GateDtypeScope(int dtype) { ggpm_set_gate_dtype(dtype); }
+    ~GateDtypeScope() { ggpm_set_gate_dtype(0); }
 };
 
 // dropout sites (include/ggpm_hip.h)
@@ -79,6 +86,7 @@ Dims make_dims(const ggpm_enc_dims* d) {
     x.lstm = d->rnn_type == 1; x.nX = x.lstm ? 4 : 3; x.lcount = x.lstm ? 10 : 9;
     x.tree_chain = d->tree_chain;
     x.dropout = d->dropout; x.seed_lo = d->seed_lo; x.seed_hi = d->seed_hi;
+    x.gate_dtype = d->gate_dtype == 1 ? 1 : 0;
     return x;
 }
 
@@ -290,6 +298,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
         !gbgraph || !roots || !saved || !hroot || !hnode || !hinter || !hatom)
         return GGPM_ERR_ARG;
     const Dims d = make_dims(dims);
+    GateDtypeScope gate_scope(d.gate_dtype);
     Arena A = {reinterpret_cast<char*>(saved), 0, false, saved_bytes};
     Saved S;
     layout_saved(A, d, S);
@@ -609,6 +618,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
         phase > 2)
         return GGPM_ERR_ARG;
     const Dims d = make_dims(dims);
+    GateDtypeScope gate_scope(d.gate_dtype);
     Arena A = {reinterpret_cast<char*>(saved), 0, false, saved_bytes};
     Saved S;
     layout_saved(A, d, S);

@@ -30,6 +30,24 @@ __global__ void ggpm_pack_weight_kernel(GgpmPackArgs a) {
     const float* __restrict__ W = a.W[m];
     const int ldw = a.ldw[m];
     const int out = 16 * t + (lane & 15);
+    if (a.bf16) {                            // grid.x = kc32(Hp) chunks of 32 columns
+        const int KC32 = ggpm_kc32_dev(Hp);
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 32 * kc + 8 * (lane >> 4) + i;
+            float x = 0.f;
+            if (out < H && k < H) x = a.transpose ? W[(size_t)k * ldw + out] : W[(size_t)out * ldw + k];
+            v[i] = (__bf16)x;
+        }
+        __bf16* dst = reinterpret_cast<__bf16*>(a.dst) + (size_t)m * Hp * 32 * KC32;
+        *reinterpret_cast<bf16x8*>(dst + ggpm_pack_index_bf16(t, kc, KC32, lane)) = v;
+        if (a.bias && m == 0 && t == 0 && kc * 64 + lane < Hp) {
+            const int c = kc * 64 + lane;
+            a.bias_out[c] = (c < H) ? a.bias[c] : 0.f;
+        }
+        return;                              // (kc32 * 64 >= Hp: the blocks above cover every bias column)
+    }
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -47,9 +65,13 @@ __global__ void ggpm_pack_weight_kernel(GgpmPackArgs a) {
 }
 
 void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s) {
-    dim3 grid(a.Hp / 16, a.Hp / 16, nmat);
+    dim3 grid(a.bf16 ? ggpm_kc32(a.Hp) : a.Hp / 16, a.Hp / 16, nmat);
     ggpm_pack_weight_kernel<<<grid, 64, 0, s>>>(a);
 }
+
+namespace { thread_local int g_gate_dtype = 0; }
+void ggpm_set_gate_dtype(int dtype) { g_gate_dtype = dtype == 1 ? 1 : 0; }
+int ggpm_gate_dtype() { return g_gate_dtype; }
 
 namespace {
 
@@ -70,6 +92,7 @@ struct GruFwdArgs {
     int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
     unsigned long long* dbg;       // optional phase stamps of workgroup (0,0) (GGPM_ADEBUG; dev only)
     const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
+    int bf16;                      // gate products on bf16 operands (packed weights are bf16 fragments then)
     int h0_zero;                   // first depth of a dense level: h^0 = 0, so s = g = 0 without a gather and the gate
                                    // products vanish (h^1 = sigmoid(x_z) tanh(x_h)); H^0 / Q^0 are neither built nor read
 };
@@ -85,7 +108,7 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time (full Hp width: two 256-column sweeps
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
-template <bool STASH>
+template <bool STASH, bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -171,7 +194,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     const bool p2_gemm = !(a.ablate & 2) && !a.h0_zero;
     const float* const wps2[2] = {a.Wz, a.Wh};
     GgpmRing<2> ring2;
-    if (p2_gemm && t < t_end) ggpm_ring_prefetch<2>(wps2, KC, t, lane, ring2);
+    if constexpr (!BF16)
+        if (p2_gemm && t < t_end) ggpm_ring_prefetch<2>(wps2, KC, t, lane, ring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
@@ -186,7 +210,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         ggpm_zero_acc<2, RT>(acc);
         if (p2_gemm) {
             const float* const tiles[2] = {Ts, Tg};
-            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (dbg_on) a.dbg[3] = wall_clock64();
         float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
@@ -217,7 +242,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     // ---- P3 (single column group only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
     const float* const wps3[1] = {a.Ur};
     GgpmRing<1> ring3;
-    if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+    if constexpr (!BF16)
+        if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     const float* Th = lds + 2 * ROWS * LD;
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
@@ -226,12 +252,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         const float* const tiles[1] = {Th};
-        ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+        if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
+        else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
     }
 }
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -243,7 +271,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[1] = {a.Ur};
     GgpmRing<1> ring;
-    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
+    if constexpr (!BF16)
+        if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
     const int row = r0 + (lane & 15);
@@ -254,7 +283,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!(a.ablate & 2)) {
             const float* const tiles[1] = {Th};
-            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
     }
@@ -284,10 +314,12 @@ struct GruBwdArgs {
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
     const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
     unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
+    int bf16;                      // gate products on bf16 operands
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
 // gate derivatives for this workgroup's column group.
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -365,7 +397,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[1] = {a.UrT};
     GgpmRing<1> ring2;
-    if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
+    if constexpr (!BF16)
+        if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dq stash stores finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
@@ -386,7 +419,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (dbg_on) a.dbg[3] = wall_clock64();
         if (row >= a.E1) {
@@ -443,7 +477,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     // dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h ; dXr += dG * R   (the body of kernel B)
     const float* const wps3[2] = {a.WhT, a.WzT};
     GgpmRing<2> ring3;
-    if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
+    if constexpr (!BF16)
+        if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     it = 0;
     for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
@@ -455,7 +490,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         ggpm_zero_acc<2, RT>(acc);
         {
             const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
-            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         }
         if (row >= a.E1) continue;
         const float4 dg = ggpm_f4(acc[0][0]);
@@ -467,6 +503,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 
 // Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -479,7 +516,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[2] = {a.WhT, a.WzT};
     GgpmRing<2> ring;
-    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<2>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
+    if constexpr (!BF16)
+        if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<2>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
     ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
     ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
     __syncthreads();
@@ -493,7 +531,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
         ggpm_zero_acc<2, RT>(acc);
         {
             const float* const tiles[2] = {T2, T1};
-            ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         if (e >= a.E1) continue;
         const float4 dg = ggpm_f4(acc[0][0]);
@@ -547,13 +586,12 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
     if (a.fuse_b) with_b = false;
     const size_t lds_a = (a.fuse_b ? 3 : 2) * lds_b;
     ggpm_timing_begin(0, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 2)) * flops1);     // the first depth has no gate products
-    if (stash) {
-        set_lds(gru_fwd_a<true>, lds_a);
-        gru_fwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
-    } else {
-        set_lds(gru_fwd_a<false>, lds_a);
-        gru_fwd_a<false><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
-    }
+    auto go = [&](auto kernel) {
+        set_lds(kernel, lds_a);
+        kernel<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
+    };
+    if (a.bf16) { if (stash) go(gru_fwd_a<true, true>); else go(gru_fwd_a<false, true>); }
+    else { if (stash) go(gru_fwd_a<true, false>); else go(gru_fwd_a<false, false>); }
     ggpm_timing_end(0, s);
     if (a.dbg && (++dbg_count % 97) == 0) {
         unsigned long long h[7];
@@ -564,9 +602,9 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
                 (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, ((double)h[5] - (double)h[0]) * 0.01, (h[6] - h[5]) * 0.01);
     }
     if (with_b) {
-        set_lds(gru_fwd_b, lds_b);
         ggpm_timing_begin(4, s, 1 * flops1);
-        gru_fwd_b<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a);
+        if (a.bf16) { set_lds(gru_fwd_b<true>, lds_b); gru_fwd_b<true><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a); }
+        else { set_lds(gru_fwd_b<false>, lds_b); gru_fwd_b<false><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a); }
         ggpm_timing_end(4, s);
     }
 }
@@ -579,7 +617,7 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
                 !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t lds_a = a.fuse_b ? 2 * lds : lds;
-    set_lds(gru_bwd_a, lds_a);
+    if (a.bf16) set_lds(gru_bwd_a<true>, lds_a); else set_lds(gru_bwd_a<false>, lds_a);
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
@@ -588,7 +626,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
         a.dbg = dbg_buf;
     }
     ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
-    gru_bwd_a<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
+    if (a.bf16) gru_bwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
+    else gru_bwd_a<false><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     ggpm_timing_end(1, s);
     if (a.dbg && !a.first && (++dbg_count % 89) == 0) {
         unsigned long long h[5];
@@ -599,9 +638,9 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
                 (h[4] - h[3]) * 0.01);
     }
     if (with_b) {
-        set_lds(gru_bwd_b, lds);
         ggpm_timing_begin(5, s, 2 * flops1);
-        gru_bwd_b<<<grid_a, GGPM_NWA * 64, lds, s>>>(a);
+        if (a.bf16) { set_lds(gru_bwd_b<true>, lds); gru_bwd_b<true><<<grid_a, GGPM_NWA * 64, lds, s>>>(a); }
+        else { set_lds(gru_bwd_b<false>, lds); gru_bwd_b<false><<<grid_a, GGPM_NWA * 64, lds, s>>>(a); }
         ggpm_timing_end(5, s);
     }
 }
@@ -651,11 +690,13 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     if (!gru_shape_ok(Hp)) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* pWz = wpack; float* pWh = wpack + HH; float* pUr = wpack + 2 * HH; float* pbu = wpack + 3 * HH;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWz = wpack; float* pWh = wpack + mstep; float* pUr = wpack + 2 * mstep; float* pbu = wpack + 3 * HH;
     {
         GgpmPackArgs pk = {};
         pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
-        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = bu; pk.bias_out = pbu;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = bu; pk.bias_out = pbu; pk.bf16 = bf16;
         ggpm_launch_pack(pk, 3, s);
     }
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
@@ -663,11 +704,11 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     if (frozen) {      // sparse_forward: start from the caller's state, q^0 = U_r h^0 + b_u by one B launch
         sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
         GruFwdArgs a0 = {};
-        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu;
+        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu; a0.bf16 = bf16;
         const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
-        set_lds(gru_fwd_b, lds_b);
-        gru_fwd_b<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0);
+        if (bf16) { set_lds(gru_fwd_b<true>, lds_b); gru_fwd_b<true><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        else { set_lds(gru_fwd_b<false>, lds_b); gru_fwd_b<false><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
     }
     // dense levels start from h^0 = 0: the first depth launch knows that (h0_zero), so H^0 / Q^0 are never materialised
 
@@ -683,6 +724,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         a.ablate = abl ? atoi(abl) : 0;
         a.frozen = frozen;
         a.ptab = pred_tab;
+        a.bf16 = bf16;
         a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
@@ -790,7 +832,9 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dGb[0] = w; w += slot; dGb[1] = w; w += slot;
     float* DSD = w; w += slot;
     float* carry = w; w += slot;
-    float* pWzT = w; w += HH; float* pWhT = w; w += HH; float* pUrT = w; w += HH;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWzT = w; float* pWhT = w + mstep; float* pUrT = w + 2 * mstep; w += 3 * HH;
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
@@ -798,7 +842,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     {
         GgpmPackArgs pk = {};
         pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
-        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWzT; pk.bias = nullptr; pk.bias_out = nullptr;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWzT; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
         ggpm_launch_pack(pk, 3, s);
     }
     // dXz / dXh are started (not accumulated) by the first backward depth; so is dXr when that depth has a dS/dG product
@@ -827,7 +871,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.frozen = frozen; a.carry = carry; a.final_pass = 0; a.dHin = nullptr;
         a.DMP = DMP + (size_t)(t - 1) * slot; a.DZP = DZP + (size_t)(t - 1) * slot; a.DSD = DSD;
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
-        a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT;
+        a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);     // (the dS/dG launch of step lo > 1 still forms dXr)
         if (side_stream && !frozen) {
@@ -883,7 +927,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = 0; a.final_pass = 1;
         a.Xr = Xr; a.Hcur = Hs; a.Qcur = Qs;
         a.dSin = dSb[1]; a.dGin = dGb[1];          // written by the B launch of depth 1
-        a.DQ = DQ; a.UrT = pUrT; a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.DQ = DQ; a.UrT = pUrT; a.srowptr = succ_rowptr; a.scol = succ_col; a.bf16 = bf16;
         a.frozen = frozen; a.carry = carry; a.dHin = dHin;
         launch_bwd(a, false, flops1, s);
         GGPM_CHECK_LAUNCH();

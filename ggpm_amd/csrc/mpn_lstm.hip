@@ -28,6 +28,7 @@ struct LstmFwdArgs {
     const unsigned char* frozen;     // sparse_forward only: rows that keep their (h, c)
     int fuse_b;                      // single column group: kernel A also forms qf' = Wf_h h' (no B launch)
     int h0_zero;                     // first depth of a dense level: h^0 = c^0 = 0 -> no gather, no gate products
+    int bf16;                        // gate products on bf16 operands (packed weights are bf16 fragments then)
 };
 
 __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w); }
@@ -36,7 +37,7 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time: s over the full row (GEMM operand), the
 // forget sum fc (and its backward coefficient) only over this workgroup's column group; then the first `tg`
 // waves run [Wi_h; Wo_h; Wu_h] . s for their output tile and the gate math.
-template <bool STASH>
+template <bool STASH, bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -115,7 +116,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[3] = {a.Wi, a.Wo, a.Wu};
     GgpmRing<3> ring2;
-    if (!a.h0_zero && t < t_end) ggpm_ring_prefetch<3>(wps2, KC, t, lane, ring2);
+    if constexpr (!BF16)
+        if (!a.h0_zero && t < t_end) ggpm_ring_prefetch<3>(wps2, KC, t, lane, ring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
@@ -128,7 +130,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         ggpm_zero_acc<3, RT>(acc);
         if (!a.h0_zero) {
             const float* const tiles[3] = {Ts, Ts, Ts};
-            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
         if (row >= a.E1) {
@@ -163,19 +166,22 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     // ---- P3 (single column group only): qf' = Wf_h h' from the rows this workgroup already holds
     const float* const wps3[1] = {a.Wf};
     GgpmRing<1> ring3;
-    if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+    if constexpr (!BF16)
+        if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
         f32x4 acc[1][RT];
         ggpm_zero_acc<1, RT>(acc);
         const float* const tiles[1] = {Th};
-        ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+        if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
+        else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
     }
 }
 
 // Kernel B (same geometry as A): qf' = Wf_h h'.
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -187,7 +193,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[1] = {a.Wf};
     GgpmRing<1> ring;
-    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
+    if constexpr (!BF16)
+        if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
     const int row = r0 + (lane & 15);
@@ -196,7 +203,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         {
             const float* const tiles[1] = {Th};
-            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
@@ -225,10 +233,12 @@ struct LstmBwdArgs {
     int final_pass;
     float *dHin, *dCin;
     int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
+    int bf16;                        // gate products on bf16 operands
 };
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
 // gate derivatives; dXf += dFC * F.
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -306,7 +316,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[1] = {a.WfT};
     GgpmRing<1> ring2;
-    if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
+    if constexpr (!BF16)
+        if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dqf stash stores finish under the GEMM
 
     const int lr = lane & 15, row = r0 + lr;
@@ -332,7 +343,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         ggpm_zero_acc<1, RT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
         if (row >= a.E1) {
             if (a.fuse_b) {
@@ -403,14 +415,16 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     // ---- P3 (single column group only): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h from the rows held here
     const float* const wps3[3] = {a.WiT, a.WoT, a.WuT};
     GgpmRing<3> ring3;
-    if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
+    if constexpr (!BF16)
+        if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
     ggpm_lds_barrier();
     for (int tt = wave; tt < NT; tt += GGPM_NWA) {
         f32x4 acc[3][RT];
         ggpm_zero_acc<3, RT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (row < a.E1)
@@ -419,6 +433,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
 }
 
 // Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
+template <bool BF16>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -432,7 +447,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
     GgpmRing<3> ring;
-    if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<3>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
+    if constexpr (!BF16)
+        if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<3>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
     ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
     ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
     ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
@@ -443,7 +459,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
         ggpm_zero_acc<3, RT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
         if (e < a.E1)
@@ -484,18 +501,17 @@ void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream
     if (a.fuse_b) with_b = false;
     const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp), lb = lds_tiles(1, Hp);
     ggpm_timing_begin(2, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 3)) * flops1);     // the first depth has no gate products
-    if (stash) {
-        set_lds(lstm_fwd_a<true>, la);
-        lstm_fwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
-    } else {
-        set_lds(lstm_fwd_a<false>, la);
-        lstm_fwd_a<false><<<grid_a, GGPM_NWA * 64, la, s>>>(a);
-    }
+    auto go = [&](auto kernel) {
+        set_lds(kernel, la);
+        kernel<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
+    };
+    if (a.bf16) { if (stash) go(lstm_fwd_a<true, true>); else go(lstm_fwd_a<false, true>); }
+    else { if (stash) go(lstm_fwd_a<true, false>); else go(lstm_fwd_a<false, false>); }
     ggpm_timing_end(2, s);
     if (with_b) {
-        set_lds(lstm_fwd_b, lb);
         ggpm_timing_begin(6, s, 1 * flops1);
-        lstm_fwd_b<<<grid_a, GGPM_NWA * 64, lb, s>>>(a);
+        if (a.bf16) { set_lds(lstm_fwd_b<true>, lb); lstm_fwd_b<true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else { set_lds(lstm_fwd_b<false>, lb); lstm_fwd_b<false><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         ggpm_timing_end(6, s);
     }
 }
@@ -508,14 +524,14 @@ void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
                 !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t la = a.fuse_b ? lds_tiles(6, Hp) : l3;
-    set_lds(lstm_bwd_a, la);
     ggpm_timing_begin(3, s, (a.fuse_b ? 4 : 1) * flops1);
-    lstm_bwd_a<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
+    if (a.bf16) { set_lds(lstm_bwd_a<true>, la); lstm_bwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else { set_lds(lstm_bwd_a<false>, la); lstm_bwd_a<false><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     ggpm_timing_end(3, s);
     if (with_b) {
-        set_lds(lstm_bwd_b, l3);
         ggpm_timing_begin(7, s, 3 * flops1);
-        lstm_bwd_b<<<grid_a, GGPM_NWA * 64, l3, s>>>(a);
+        if (a.bf16) { set_lds(lstm_bwd_b<true>, l3); lstm_bwd_b<true><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else { set_lds(lstm_bwd_b<false>, l3); lstm_bwd_b<false><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         ggpm_timing_end(7, s);
     }
 }
@@ -558,12 +574,14 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
     if (!lstm_shape_ok(Hp)) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* pWi = wpack; float* pWo = wpack + HH; float* pWu = wpack + 2 * HH; float* pWf = wpack + 3 * HH;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWi = wpack; float* pWo = wpack + mstep; float* pWu = wpack + 2 * mstep; float* pWf = wpack + 3 * mstep;
     {
         GgpmPackArgs pk = {};
         pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
         pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
-        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = nullptr; pk.bias_out = nullptr;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
         ggpm_launch_pack(pk, 4, s);
     }
     const int tg = pick_tg(E1, Hp / 16);
@@ -571,11 +589,11 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         dim3 ig(ggpm_ceil_div(Hp, 256), E1);
         lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
         LstmFwdArgs a0 = {};
-        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf;
+        a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf; a0.bf16 = bf16;
         const size_t lb = lds_tiles(1, Hp);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg));
-        set_lds(lstm_fwd_b, lb);
-        lstm_fwd_b<<<grid_a, GGPM_NWA * 64, lb, s>>>(a0);
+        if (bf16) { set_lds(lstm_fwd_b<true>, lb); lstm_fwd_b<true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        else { set_lds(lstm_fwd_b<false>, lb); lstm_fwd_b<false><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
     } else {
         (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
         (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);
@@ -590,6 +608,7 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;
         a.frozen = frozen;
+        a.bf16 = bf16;
         a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
             a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
@@ -682,7 +701,9 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     float* dSb[2]; float* dFb[2];
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dFb[0] = w; w += slot; dFb[1] = w; w += slot;
     float* carry_h = w; w += slot; float* carry_c = w; w += slot;
-    float* pWiT = w; w += HH; float* pWoT = w; w += HH; float* pWuT = w; w += HH; float* pWfT = w; w += HH;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep; w += 4 * HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
 
@@ -690,7 +711,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         GgpmPackArgs pk = {};
         pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
         pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
-        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWiT; pk.bias = nullptr; pk.bias_out = nullptr;
+        pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWiT; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
         ggpm_launch_pack(pk, 4, s);
     }
     // dXi / dXo / dXu / dXf are started (not accumulated) by the first backward depth
@@ -720,7 +741,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         a.dHin = nullptr; a.dCin = nullptr;
         a.DI = DI + (size_t)(t - 1) * slot; a.DO = DO + (size_t)(t - 1) * slot; a.DU = DU + (size_t)(t - 1) * slot;
         a.dXi = dXi; a.dXo = dXo; a.dXu = dXu; a.dXf = dXf;
-        a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT;
+        a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
     }
@@ -730,7 +751,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = 0; a.final_pass = 1;
         a.Xf = Xf; a.Ccur = Cs; a.Qcur = Qs;
         a.dSin = dSb[1]; a.dFCin = dFb[1];          // written by the launches of depth 1
-        a.DQ = DQ; a.WfT = pWfT; a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.DQ = DQ; a.WfT = pWfT; a.srowptr = succ_rowptr; a.scol = succ_col; a.bf16 = bf16;
         a.frozen = frozen; a.carry_h = carry_h; a.carry_c = carry_c; a.dHin = dHin; a.dCin = dCin;
         launch_bwd(a, false, flops1, s);
         GGPM_CHECK_LAUNCH();

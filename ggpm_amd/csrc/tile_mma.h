@@ -149,6 +149,72 @@ __device__ __forceinline__ void ggpm_wave_gemm(const float* const (&tiles)[NOPS]
     ggpm_wave_gemm_ring<NOPS, RT>(tiles, LD, wps, KC, t, -1, lane, acc, ring);
 }
 
+// ---- bf16 gate products (BASELINE configs[4]: "bf16" -- operands rounded to bf16, fp32 accumulate) -----------------------
+// v_mfma_f32_16x16x32_bf16: one instruction contracts 32 k values; lane l supplies k = 32*kc + 8*(l>>4) + 0..7 of BOTH
+// operands (weight row 16*t + (l&15), activation row l&15) and receives the same 4 output features of row (l&15) as
+// the fp32 path, so the epilogues are shared.  Weights are packed once per call as bf16 in fragment order
+// [out tile][k chunk of 32][lane][8] (16 bytes per lane per instruction, zero padded to a multiple of 32 columns);
+// activations stay fp32 in the LDS tiles and are rounded (RNE, v_cvt_pk_bf16_f32) as they are read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ size_t ggpm_pack_index_bf16(int t, int kc, int KC32, int lane) {
+    return (((size_t)t * KC32 + kc) * 64 + lane) * 8;      // in bf16 elements
+}
+static inline int ggpm_kc32(int Hp) { return (Hp + 31) / 32; }
+__device__ __forceinline__ int ggpm_kc32_dev(int Hp) { return (Hp + 31) >> 5; }
+
+template <int NOPS, int RT>
+__device__ __forceinline__ void ggpm_wave_gemm_bf16(const float* const (&tiles)[NOPS], int LD,
+                                                    const float* const (&wps_f32)[NOPS], int Hp, int t, int lane,
+                                                    f32x4 (&acc)[NOPS][RT]) {
+    constexpr int PF = 2;
+    const int KC32 = ggpm_kc32_dev(Hp);
+    const int boff = (lane & 15) * LD + 8 * (lane >> 4);
+    const bf16x8* wp[NOPS];
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o)
+        wp[o] = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(wps_f32[o]) +
+                                                 ggpm_pack_index_bf16(t, 0, KC32, lane));
+    bf16x8 ring[PF][NOPS];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) ring[d][o] = wp[o][(size_t)min(d, KC32 - 1) * 64];
+    for (int kc = 0; kc < KC32; kc += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            if (kc + d < KC32) {
+                const int k0 = 32 * (kc + d) + 8 * (lane >> 4);
+                const bool live = k0 < Hp;              // Hp is a multiple of 16: a group of 8 columns is all in or all out
+                bf16x8 a[NOPS], b[NOPS][RT];
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o) {
+                    a[o] = ring[d][o];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                        if (live) {
+                            const float* src = tiles[o] + r * 16 * LD + boff + 32 * (kc + d);
+                            lo = *reinterpret_cast<const f32x4*>(src);
+                            hi = *reinterpret_cast<const f32x4*>(src + 4);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { b[o][r][i] = (__bf16)lo[i]; b[o][r][4 + i] = (__bf16)hi[i]; }
+                    }
+                }
+                const int kn = min(kc + d + PF, KC32 - 1);
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o) ring[d][o] = wp[o][(size_t)kn * 64];
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], b[o][r], acc[o][r], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int NOPS, int RT>
 __device__ __forceinline__ void ggpm_zero_acc(f32x4 (&acc)[NOPS][RT]) {
 #pragma unroll
@@ -218,9 +284,11 @@ struct GgpmPackArgs {
     float* dst;
     const float* bias;
     float* bias_out;
+    int bf16;          // pack as bf16 fragments (ggpm_wave_gemm_bf16): matrix m at dst + m * Hp * 32 * kc32(Hp) bf16 elements
 };
 __global__ void ggpm_pack_weight_kernel(GgpmPackArgs a);
 void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s);
+
 // Output tiles per column group of the depth-step kernels for a level of E1 messages and NT = Hp/16 tiles.
 // One 16-wave workgroup fits a CU at a time, so the grid is kept at <= ~256 workgroups: big levels use ONE
 // group (no redundant gathers; waves loop over tiles wave, wave+16, ...), small levels split the columns so

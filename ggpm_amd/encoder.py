@@ -150,6 +150,11 @@ class HierMPNEncoder(nn.Module):
         self.E_c, self.E_i = other.E_c, other.E_i
         self.E_a, self.E_b = other.E_a, other.E_b
 
+    #: dtype of the H x H gate products inside the depth loops of the one-call drivers: "f32" (default; the 1e-4 parity
+    #: contract) or "bf16" (operands rounded to bf16, fp32 accumulate on v_mfma_f32_16x16x32_bf16 -- BASELINE configs[4];
+    #: everything else stays fp32).  None: the environment variable GGPM_GATE_DTYPE, else "f32".
+    gate_dtype = None
+
     # ------------------------------------------------------------------ embeddings (padded tensors)
     def _tree_mess(self, hnode, lvl: LevelGraph):
         H = self.hidden_size

@@ -37,7 +37,10 @@ class EncDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("H", "He", "depthT", "depthG", "atom_size", "n_motif", "n_attach", "N1g",
                                             "E1g", "Kg_a", "Kg_b", "N1t", "E1t", "Kt_a", "Kt_b", "Kt_c", "B", "rnn_type",
                                             "tree_chain")] + \
-               [("dropout", ctypes.c_float), ("seed_lo", ctypes.c_uint), ("seed_hi", ctypes.c_uint)]
+               [("dropout", ctypes.c_float), ("seed_lo", ctypes.c_uint), ("seed_hi", ctypes.c_uint),
+                ("gate_dtype", ctypes.c_int)]
+
+GATE_DTYPES = {"f32": 0, "fp32": 0, "bf16": 1}
 
 
 def _dropout_seed():
@@ -183,7 +186,8 @@ def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
                    tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm),
-                   int(getattr(tf[3], "ggpm_chain", 0)), 0.0, 0, 0)
+                   int(getattr(tf[3], "ggpm_chain", 0)), 0.0, 0, 0,
+                   GATE_DTYPES[getattr(encoder, "gate_dtype", None) or os.environ.get("GGPM_GATE_DTYPE", "f32")])
     if encoder.training and encoder.dropout > 0:      # nn.Dropout semantics: active in training mode only
         seed = getattr(encoder, "_dropout_seed", None) or _dropout_seed()      # (tests pin the seed)
         dims.dropout, dims.seed_lo, dims.seed_hi = float(encoder.dropout), seed[0], seed[1]

@@ -319,6 +319,10 @@ typedef struct ggpm_enc_dims {
                                             (ggpm/rnn.py:41-50 iterates a fixed depth regardless). */
     float dropout;                       /* drop probability of the training forward (0: none / eval) */
     unsigned int seed_lo, seed_hi;       /* mask stream of this forward/backward pair */
+    int gate_dtype;                      /* 0: fp32 gate products (v_mfma_f32_16x16x4_f32; the 1e-4 parity configurations);
+                                            1: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) for the H x H gate
+                                            products of the depth loops -- BASELINE configs[4].  State, stashes, gate math,
+                                            input projections and weight-gradient contractions stay fp32. */
 } ggpm_enc_dims;
 size_t ggpm_encoder_saved_bytes(const ggpm_enc_dims* dims);
 size_t ggpm_encoder_work_bytes(const ggpm_enc_dims* dims);

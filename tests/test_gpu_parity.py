@@ -688,6 +688,65 @@ def test_dropout_in_the_drivers_matches_oracle_with_the_same_masks(name):
         assert torch.equal(a, b)
 
 
+BF16_OUT_TOL, BF16_GRAD_TOL = 0.2, 0.3
+
+
+@pytest.mark.parametrize("case", ["cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10"])
+def test_bf16_gate_products(case):
+    """BASELINE configs[4] names bf16: ``encoder.gate_dtype = "bf16"`` rounds the OPERANDS of the H x H gate products of
+    the depth loops to bf16 (8 mantissa bits) and accumulates in fp32 on v_mfma_f32_16x16x32_bf16; state, stashes, gate
+    math, input projections and weight gradients stay fp32.  This is NOT the 1e-4 contract.  An operand error of 2^-9
+    per product goes through 20-30 recurrent depths; measured against the fp32 gate products of the same HIP path on the
+    same inputs (norm-wise, worst tensor): LSTM H=250 depth 20 outputs 4e-3 / gradients 0.17, LSTM H=600 depth 30 on
+    ~200-atom polymers 3e-2 / 4e-2, GRU H=300 depth 20 0.12 / 0.16 (the sum-aggregating GRU amplifies more, see
+    test_configs4_polymer_shard_matches_oracle).  Stated tolerance: BF16_OUT_TOL for outputs and KL, BF16_GRAD_TOL for
+    every parameter gradient -- a mixed-precision training mode to be judged by its loss curve, not a parity mode."""
+    from ggpm_amd import synth
+    from ggpm_amd.nnutils import make_cuda
+    if case.startswith("cfg"):
+        g = Golden(case)
+        build = lambda: _build_encoder(g)
+        tensors, H = g.numpy_tensors(), g.H
+    else:
+        rnn, depth = ("LSTM", 30) if "lstm" in case else ("GRU", 10)
+        H = 600
+        specs = synth.random_batch(606, 3, motifs=(46, 58), n_motif_vocab=60, n_attach_vocab=180)
+        tensors = synth.tensorize(specs)
+
+        def build():
+            from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+            from ggpm_amd.property_vae import HierEncoderVAE
+
+            class A:
+                pass
+            a = A()
+            a.vocab, a.atom_vocab = _Vocab((60, 180)), _Vocab(38)
+            a.rnn_type, a.embed_size, a.hidden_size = rnn, H, H
+            a.depthT = a.depthG = depth
+            a.dropout, a.latent_size = 0.0, 32
+            sd = seeded_state_dict(encoder_param_shapes(rnn, H, 60, 180), 5)
+            sd.update(seeded_state_dict(vae_head_shapes(H, 32), 6))
+            m = HierEncoderVAE(a).to(_dev())
+            m.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
+            return m
+    res = []
+    for dt in ("f32", "bf16"):
+        model = build()
+        model.encoder.gate_dtype = dt
+        tree, graph = make_cuda(tensors)
+        outs = model.encoder.forward_padded(tree, graph)
+        from ggpm_amd.property_vae import rsample
+        _, kl = rsample(outs[0], model.R_mean, model.R_var, perturb=False)
+        (kl + sum((o[:, :H] * o[:, :H]).sum() for o in outs)).backward()
+        res.append(([o.detach()[:, :H].cpu().numpy() for o in outs] + [np.asarray(float(kl.detach()))],
+                    {k: v.grad.cpu().numpy() for k, v in model.named_parameters() if v.grad is not None}))
+    worst_o = max(rel_err(b, a) for a, b in zip(res[0][0], res[1][0]))
+    worst_g = max(rel_err(res[1][1][k], res[0][1][k]) for k in res[0][1] if np.abs(res[0][1][k]).max() > 0)
+    print("bf16 vs fp32 gate products (%s): outputs %.2e, gradients %.2e" % (case, worst_o, worst_g))
+    assert worst_o > 1e-6          # the bf16 path really ran
+    assert worst_o < BF16_OUT_TOL and worst_g < BF16_GRAD_TOL, (worst_o, worst_g)
+
+
 @pytest.mark.parametrize("name", ["cfg_gru_s0", "cfg_lstm_s2", "tiny_gru_s1", "edge_gru_s32"])
 def test_tree_fixed_point_shortcut_is_bit_identical(name):
     """With the longest dependency chain C of the tree messages known (make_cuda measures it on the host), the tree-side

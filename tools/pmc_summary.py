@@ -37,3 +37,9 @@ for tot, k, n, f, w in rows:
     agg[k[0]][1] += n
 out = {name: round(v[0] / v[1]) for name, v in agg.items() if re.match(r'(gru|lstm)_(fwd|bwd)_[ab]$', name)}
 print(json.dumps(out))
+# the atom-level launches only (the largest grid of each depth kernel): what bench.py's roofline.traffic quotes
+big = {}
+for tot, k, n, f, w in rows:
+    if re.match(r'(gru|lstm)_(fwd|bwd)_[ab]$', k[0]) and (k[0] not in big or int(k[1]) > big[k[0]][0]):
+        big[k[0]] = (int(k[1]), round(tot), n)
+print(json.dumps({"atom_level": {k: {"grid_threads": v[0], "bytes_per_launch": v[1], "launches": v[2]} for k, v in big.items()}}))
