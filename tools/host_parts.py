@@ -8,14 +8,20 @@ from ggpm_amd.nnutils import make_cuda
 from ggpm_amd.parallel import FlatGradSync
 from ggpm_amd.property_vae import HierEncoderVAE, rsample
 
-rnn = os.environ.get("RNN", "GRU")
+rnn = os.environ.get("RNN", "GRU")      # CONFIG=<BASELINE config index> picks the workload
 dev = torch.device("cuda:0")
-pool = bench.make_batches(8, 32, seed0=1000, motifs=(8, 12), n_motif=500, n_attach=1500)
+CFG = bench.CONFIGS[int(os.environ.get("CONFIG", "1"))]
+pool = bench.make_batches(8, CFG["batch"], seed0=1000, gen=CFG["gen"], n_motif=CFG["vocab"][0], n_attach=CFG["vocab"][1])
 dev_batches = [make_cuda(b) for b in pool]
 torch.manual_seed(0)
-model = HierEncoderVAE(bench.make_args(rnn, 300, 20, 32, 500, 1500)).to(dev)
-sync = FlatGradSync(model.parameters(), encoder=model.encoder)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+model = HierEncoderVAE(bench.make_args(rnn, CFG["hidden"], CFG["depth"], CFG["latent"], *CFG["vocab"])).to(dev)
+if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
+    from ggpm_amd.optim import FlatAdam
+    sync = FlatGradSync(model.parameters(), encoder=model.encoder, keep_flat=True)
+    opt = FlatAdam(sync, lr=1e-3)
+else:
+    sync = FlatGradSync(model.parameters(), encoder=model.encoder)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 acc = {}
 
 # time spent inside the two C driver calls themselves (the rest of "encoder forward" / "backward" is Python + autograd)

@@ -37,9 +37,15 @@ for tot, k, n, f, w in rows:
     agg[k[0]][1] += n
 out = {name: round(v[0] / v[1]) for name, v in agg.items() if re.match(r'(gru|lstm)_(fwd|bwd)_[ab]$', name)}
 print(json.dumps(out))
-# the atom-level launches only (the largest grid of each depth kernel): what bench.py's roofline.traffic quotes
-big = {}
+# the atom-level launches only (the launches of a depth kernel that move at least half of that kernel's largest
+# per-launch traffic: the atom graph has ~5x the messages of the tree-side levels): what bench.py's roofline.traffic quotes
+top = collections.defaultdict(float)
 for tot, k, n, f, w in rows:
-    if re.match(r'(gru|lstm)_(fwd|bwd)_[ab]$', k[0]) and (k[0] not in big or int(k[1]) > big[k[0]][0]):
-        big[k[0]] = (int(k[1]), round(tot), n)
-print(json.dumps({"atom_level": {k: {"grid_threads": v[0], "bytes_per_launch": v[1], "launches": v[2]} for k, v in big.items()}}))
+    top[k[0]] = max(top[k[0]], tot)
+big = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+for tot, k, n, f, w in rows:
+    if re.match(r'(gru|lstm)_(fwd|bwd)_[ab]$', k[0]) and tot >= 0.5 * top[k[0]]:
+        b = big[k[0]]
+        b[0] += tot * n; b[1] += f * n; b[2] += w * n; b[3] += n
+print(json.dumps({"atom_level": {k: {"bytes_per_launch": round(v[0] / v[3]), "read_bytes": round(v[1] / v[3]),
+                                     "write_bytes": round(v[2] / v[3]), "launches": v[3]} for k, v in big.items()}}))
