@@ -83,7 +83,8 @@ SIGNATURES = {
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # GGPM_LIB_PATH: an alternative build of the same sources (A/B runs of compile-time tuning switches)
+    return os.environ.get("GGPM_LIB_PATH") or _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True):

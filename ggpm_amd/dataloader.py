@@ -90,13 +90,16 @@ class DevicePrefetcher:
         arrays, layout, total = batch_layout(tensors)
         tscope, gscope = tensors[0][-1], tensors[1][-1]
         chain = tree_chain_length(tensors[0][3])         # host data here: lets the tree-side levels stop at their fixed point
-        host = self._stage(slot, total)
+        B = len(tscope)
+        host = self._stage(slot, total + (B + 1) // 2)   # + the molecules' root node ids, int32, behind the 9 arrays
         pack_into(host.numpy(), arrays, layout)          # straight into the (pinned) staging buffer
+        host.numpy().view(np.int32)[2 * total:2 * total + B] = [st for st, _ in tscope]
 
         def views(flat):
             tree, graph = unpack_views(flat, layout, tscope, gscope)
             if chain:
                 tree[3].ggpm_chain = chain
+            tree[0].ggpm_roots = flat.view(torch.int32)[2 * total:2 * total + B]     # what embed_root gathers by
             return tree, graph
 
         if not self.cuda:

@@ -221,7 +221,9 @@ class HierMPNEncoder(nn.Module):
         if prep is None and self._fused_ok(tree_tensors, graph_tensors):
             from . import fused
             if roots is None:
-                roots = _RING.upload([st for st, _ in tree_tensors[-1]], tree_tensors[0].device)
+                roots = getattr(tree_tensors[0], "ggpm_roots", None)         # make_cuda / DevicePrefetcher leave it there
+                if roots is None or roots.numel() != len(tree_tensors[-1]):
+                    roots = _RING.upload([st for st, _ in tree_tensors[-1]], tree_tensors[0].device)
             return fused.hier_encoder(self, tree_tensors, graph_tensors, roots)
         if prep is None:
             prep = PreparedBatch(tree_tensors, graph_tensors, roots)

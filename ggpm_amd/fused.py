@@ -86,10 +86,8 @@ class _HierEncoder(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         saved_bytes = int(lib.ggpm_encoder_saved_bytes(ctypes.byref(dims)))
         saved = torch.empty(_arena_size(saved_bytes), dtype=torch.uint8, device=dev)
-        hroot = torch.empty(dims.B, Hp, **f32)
-        hnode = torch.empty(dims.N1t, Hp, **f32)
-        hinter = torch.empty(dims.N1t, Hp, **f32)
-        hatom = torch.empty(dims.N1g, Hp, **f32)
+        out = torch.empty(dims.B + 2 * dims.N1t + dims.N1g, Hp, **f32)          # one allocation, four row ranges
+        hroot, hnode, hinter, hatom = out.split([dims.B, dims.N1t, dims.N1t, dims.N1g])
         params = [p if p.is_contiguous() else p.contiguous() for p in params]
         side, side_p = _side_ptr(dev)
         if side is not None:
