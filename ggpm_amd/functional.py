@@ -282,8 +282,12 @@ class _Linear(torch.autograd.Function):
             return dW_, db_
 
         wref, bias = ctx.weight_ref, ctx.bias_ref
-        use_side = (side_stream_enabled() and ctx.needs_input_grad[0] and getattr(wref, "is_leaf", False)
-                    and (bias is None or getattr(bias, "is_leaf", False)))
+        leaf = (ctx.needs_input_grad[0] and getattr(wref, "is_leaf", False)
+                and (bias is None or (getattr(bias, "is_leaf", False) and ctx.needs_input_grad[1])))
+        if leaf and defer_wgrads_enabled():       # one contraction per parameter at the end of the pass (see _DEFER)
+            _defer_linear(wref, bias, dpre, list(xs), Ks)
+            return (None, None, None, None, None, None, *dxs)
+        use_side = side_stream_enabled() and leaf
         if use_side:      # weight / bias gradients: second stream, straight into param.grad (as the level functions do)
             main = torch.cuda.current_stream()
             side = _side_stream(weight.device)
@@ -345,11 +349,16 @@ class _GatherRows(torch.autograd.Function):
         _lib.check(_lib.load().ggpm_gather_rows(_p(table), _ld(table), _p(idx), rows, width, _p(out), ld_out, 0,
                                                 ld_out, _stream()), "gather_rows")
         ctx.idx_csr, ctx.width, ctx.tshape, ctx.tld = idx_csr, width, table.shape, _ld(table)
+        ctx.table_ref, ctx.idx = table, idx
         return out
 
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous() if dout.stride(1) != 1 else dout
+        if ctx.needs_input_grad[0] and getattr(ctx.table_ref, "is_leaf", False) and defer_wgrads_enabled():
+            _defer_register()       # one scatter over the rows of all visits at the end of the pass
+            _DEFER["gather"].setdefault(id(ctx.table_ref), (ctx.table_ref, ctx.width, []))[2].append((dout, ctx.idx))
+            return None, None, None, None, None
         csrT = ctx.idx_csr.T
         dtable = torch.empty(ctx.tshape, dtype=torch.float32, device=dout.device)
         _segment_sum_raw(dout, csrT, ctx.width, dtable)
@@ -441,6 +450,84 @@ def _accumulate_grad(param: torch.Tensor, g: torch.Tensor, main: torch.cuda.Stre
 
 def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
     torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+
+
+# ----------------------------------------------------------------------------- deferred parameter gradients
+# The teacher-forced decoder uses the same parameters on every one of its ~20 steps, so a backward pass meets each
+# Linear ~20 times.  Forming dW = dpre^T x (+ column sum, + the accumulate kernel autograd adds) per visit is ~40 tiny
+# launches per parameter and pass.  With GGPM_DEFER_WGRADS=1 (default) a visit only queues its (dpre, x) rows; when the
+# backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
+# visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
+# parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None}
+
+
+def defer_wgrads_enabled() -> bool:
+    return os.environ.get("GGPM_DEFER_WGRADS", "1") != "0"
+
+
+def _defer_register() -> None:
+    if not _DEFER["registered"]:
+        _DEFER["linear"].clear()          # (leftovers of a backward pass that raised)
+        _DEFER["sum"].clear()
+        _DEFER["gather"].clear()
+        _DEFER["registered"] = True
+        _DEFER["stream"] = torch.cuda.current_stream()
+        torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
+
+
+def _defer_linear(weight, bias, dpre, xs, Ks) -> None:
+    _defer_register()
+    _DEFER["linear"].setdefault(id(weight), (weight, bias, Ks, []))[3].append((dpre, xs))
+
+
+def _defer_sum(param, grad) -> None:
+    """param.grad += grad, summed with the pass's other contributions to the same parameter by ONE reduction at the end."""
+    if grad is None:
+        return
+    _defer_register()
+    _DEFER["sum"].setdefault(id(param), (param, []))[1].append(grad)
+
+
+def _add_to_grad(param, g) -> None:
+    if param.grad is None:
+        param.grad = g
+    else:
+        param.grad.add_(g)
+
+
+def _defer_flush() -> None:
+    lin, sums, gath = dict(_DEFER["linear"]), dict(_DEFER["sum"]), dict(_DEFER["gather"])
+    _DEFER["linear"].clear()
+    _DEFER["sum"].clear()
+    _DEFER["gather"].clear()
+    _DEFER["registered"] = False
+    with torch.cuda.stream(_DEFER["stream"]):
+        for weight, bias, Ks, visits in lin.values():
+            N = weight.shape[0]
+            if len(visits) == 1:
+                dpre, xs = visits[0]
+            else:
+                dpre = torch.cat([v[0] for v in visits], dim=0)
+                xs = [torch.cat([v[1][i][:, :K] for v in visits], dim=0) for i, K in enumerate(Ks)]
+            M = dpre.shape[0]
+            dW = torch.empty_like(weight)
+            o = 0
+            for x, K in zip(xs, Ks):
+                gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW[:, o:], dW.stride(0), K, splitk=True)
+                o += K
+            _add_to_grad(weight, dW)
+            if bias is not None:
+                _add_to_grad(bias, colsum(dpre, M, N))
+        for param, grads in sums.values():
+            _add_to_grad(param, grads[0] if len(grads) == 1 else torch.stack(grads, dim=0).sum(dim=0))
+        for table, width, visits in gath.values():       # embedding tables: d(table)[id] = sum of the rows that used id
+            dout = visits[0][0] if len(visits) == 1 else torch.cat([v[0] for v in visits], dim=0)
+            idx = visits[0][1] if len(visits) == 1 else torch.cat([v[1].reshape(-1) for v in visits], dim=0)
+            csrT = csr_from_index(idx.reshape(-1), ncols=table.shape[0]).T
+            dtable = torch.empty(table.shape, dtype=torch.float32, device=dout.device)
+            _segment_sum_raw(dout, csrT, width, dtable)
+            _add_to_grad(table, dtable)
 
 
 # ----------------------------------------------------------------------------- persistent depth loops
@@ -674,6 +761,7 @@ class _GruSparse(torch.autograd.Function):
             ctx.save_for_backward(x_sub, submess, W_z, W_r, U_r, W_h)
             ctx.stash = (X[1], frozen, pred, Hs, Qs, Ss, Gs, Zs, Ms, Rs)
             ctx.meta = (depth, I, H)
+            ctx.param_refs = (W_z, b_z, W_r, U_r, b_u, W_h, b_h)
         return out[:, :H]
 
     @staticmethod
@@ -718,7 +806,12 @@ class _GruSparse(torch.autograd.Function):
             gemm(0, 0, ms, I, H, dXs[0], Hp, Wz_x, W_z.stride(0), dx, ldx, x_sub.shape[1])
             gemm(0, 0, ms, I, H, dXs[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
             gemm(0, 0, ms, I, H, dXs[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
-        return (dHin[:, :H], dx, None, None, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None)
+        pgrads = (dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h)
+        if defer_wgrads_enabled() and all(getattr(q, "is_leaf", False) and q.requires_grad for q in ctx.param_refs):
+            for q, g in zip(ctx.param_refs, pgrads):      # summed once per parameter at the end of the pass (see _DEFER)
+                _defer_sum(q, g)
+            pgrads = (None,) * 7
+        return (dHin[:, :H], dx, None, None, *pgrads, None, None, None)
 
 
 def gru_sparse(h_in, x_sub, submess, bgraph_sub, W_z, b_z, W_r, U_r, b_u, W_h, b_h, depth: int, I: int, H: int):
@@ -769,6 +862,7 @@ class _LstmSparse(torch.autograd.Function):
             ctx.save_for_backward(x_sub, submess, W_i, W_o, W_u, W_f)
             ctx.stash = (X[3], frozen, pred, Hs, Cs, Qs, Ss, Is, Os, Us, Fs)
             ctx.meta = (depth, I, H)
+            ctx.param_refs = (W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f)
         return Hs[k][:, :H], Cs[k][:, :H]
 
     @staticmethod
@@ -815,8 +909,12 @@ class _LstmSparse(torch.autograd.Function):
             for k in range(4):
                 gemm(0, 0, ms, I, H, dXs[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx,
                      x_sub.shape[1] if k == 0 else I, accumulate=k > 0)
-        return (dHin[:, :H], dCin[:, :H], dx, None, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3],
-                dbs[3], None, None, None)
+        pgrads = (dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3])
+        if defer_wgrads_enabled() and all(getattr(q, "is_leaf", False) and q.requires_grad for q in ctx.param_refs):
+            for q, g in zip(ctx.param_refs, pgrads):      # summed once per parameter at the end of the pass (see _DEFER)
+                _defer_sum(q, g)
+            pgrads = (None,) * 8
+        return (dHin[:, :H], dCin[:, :H], dx, None, None, *pgrads, None, None, None)
 
 
 def lstm_sparse(h_in, c_in, x_sub, submess, bgraph_sub, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, depth, I, H):
