@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -41,6 +43,7 @@ class DecodeSchedule:
 
     def __init__(self):
         self.steps: List[dict] = []
+        self.plan: Optional[dict] = None
         self.root_clab: List[int] = []
         self.root_ilab: List[int] = []
         self.max_cls_size = 0
@@ -80,10 +83,16 @@ class DecodeSchedule:
         tree_tensors, graph_tensors = tensors
         host = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
         tfnode, tfmess, cgraph = host(tree_tensors[0]), host(tree_tensors[1]), host(tree_tensors[4])
+        tagraph, tbgraph = host(tree_tensors[2]), host(tree_tensors[3])
         gfmess = host(graph_tensors[1])
         tree_scope = tree_tensors[-1]
         S = DecodeSchedule()
         B = S.batch_size = len(orders)
+        E1 = tfmess.shape[0]
+        mess_time = np.full(E1, -1, dtype=np.int64)          # step at which a tree message is computed (each exactly once)
+        mess_inst = np.zeros(E1, dtype=np.int64)             # the (step, node) visit whose vector is its input
+        inst_node, inst_step, pool_rows = [], [], []
+        revealed = set()
         tmess = {(int(u), int(v)): e for e, (u, v) in enumerate(tfmess[:, :2]) if e > 0}
         gadj: Dict[int, List[Tuple[int, int]]] = {}
         for e in range(1, gfmess.shape[0]):
@@ -107,11 +116,17 @@ class DecodeSchedule:
             st = dict(subnode=[], submess=[], atoms=subgraph[0], bonds=subgraph[1], topo_batch=[], topo_label=[],
                       cls_mess=[], cls_batch=[], cls_clab=[], cls_ilab=[], assm=[])
             batch_list = [i for i in range(B) if t < len(orders[i])]
+            revealed.update(subgraph[0])
             for i in batch_list:
                 xid, yid, tlab = orders[i][t]
                 st["subnode"].append(int(xid))
+                pool_rows.append([int(a) if (a > 0 and int(a) in revealed) else 0 for a in cgraph[xid]])
+                inst_node.append(int(xid))
+                inst_step.append(t)
                 if yid is not None:
-                    st["submess"].append(tmess[(int(xid), int(yid))])
+                    m = tmess[(int(xid), int(yid))]
+                    st["submess"].append(m)
+                    mess_time[m], mess_inst[m] = t, len(inst_node) - 1
             new_atoms = []
             for i in batch_list:
                 xid, yid, tlab = orders[i][t]
@@ -134,7 +149,59 @@ class DecodeSchedule:
                     st["assm"].append((cands, icls, nth_child, i))
             subgraph = reveal(new_atoms)
             S.steps.append(st)
+        S._level_plan(tfnode, tfmess, tagraph, tbgraph, tree_scope, mess_time, mess_inst, inst_node, inst_step, pool_rows)
         return S
+
+    def _level_plan(self, tfnode, tfmess, tagraph, tbgraph, tree_scope, mess_time, mess_inst, inst_node, inst_step,
+                    pool_rows) -> None:
+        """Index tables of the BATCHED form of the two tree-side levels (HierMPNDecoder.forward_batched).
+
+        Teacher forcing fixes the whole schedule: every tree message (x -> y) is computed exactly once, at the step that
+        traverses it, from predecessor messages that were computed at earlier steps and never change afterwards.  The
+        loop over steps therefore evaluates, for these two levels, a feed-forward computation on a DAG: message m reads
+        the predecessors p of the padded table with time(p) < time(m) (plus, on the motif level, the constant pseudo
+        message that carries its molecule's root vector).  Synchronous message passing on that DAG from h = 0 -- the
+        encoder's own level kernels -- reaches exactly those values after `chain` iterations (chain = longest path).
+        Node vectors exist once per VISIT (step, node): a visit sums the incoming messages revealed up to its step."""
+        E1, B = tfmess.shape[0], self.batch_size
+        dec_ag, dec_bg = tagraph.astype(np.int64).copy(), tbgraph.astype(np.int64).copy()
+        for i, (root, _) in enumerate(tree_scope):           # init_decoder_state, ggpm/decoder.py:108-115
+            dec_ag[root, -1] = E1 + i
+            dec_bg[(tfmess[:, 0] == root) & (np.arange(E1) > 0), -1] = E1 + i
+        live = mess_time >= 0
+        live[0] = False
+        mt = np.where(mess_time >= 0, mess_time, np.iinfo(np.int64).max)
+
+        def dag(table, pseudo):
+            t = table[1:]
+            keep = (t > 0) & (t < E1) & (mt[np.minimum(t, E1 - 1)] < mt[1:, None])
+            if pseudo:
+                keep |= t >= E1
+            return np.where(keep, t, 0)
+
+        def incoming(table, pseudo):
+            t = table[np.asarray(inst_node, dtype=np.int64)]
+            keep = (t > 0) & (t < E1) & (mt[np.minimum(t, E1 - 1)] <= np.asarray(inst_step, dtype=np.int64)[:, None])
+            if pseudo:
+                keep |= t >= E1
+            return np.where(keep, t, 0)
+
+        dag_tree, dag_inter = dag(dec_bg, True), dag(tbgraph.astype(np.int64), False)
+        chain = np.zeros(E1, dtype=np.int64)
+        for m in np.argsort(mt[1:], kind="stable") + 1:      # longest dependency chain, in time order
+            if mess_time[m] < 0:
+                break
+            preds = dag_inter[m - 1]
+            chain[m] = 1 + (chain[preds[preds > 0]].max() if (preds > 0).any() else 0)
+        nodes = np.asarray(inst_node, dtype=np.int64)
+        self.plan = dict(
+            chain=int(chain.max()) if E1 > 1 else 0, n_inst=len(inst_node), E1=int(E1), all_live=bool(live[1:].all()),
+            inst_motif=tfnode[nodes, 0].astype(np.int64), inst_attach=tfnode[nodes, 1].astype(np.int64),
+            mess_inst=mess_inst[1:], mess_pos=tfmess[1:, 2].astype(np.int64), dag_tree=dag_tree, dag_inter=dag_inter,
+            in_tree=incoming(dec_ag, True), in_inter=incoming(tagraph.astype(np.int64), False),
+            pool=np.asarray(pool_rows, dtype=np.int64).reshape(len(inst_node), -1),
+            cls_mess=np.asarray([m for st in self.steps for m in st["cls_mess"]], dtype=np.int64),
+            inst_off=np.cumsum([0] + [len(st["subnode"]) for st in self.steps]).tolist())
 
     # ------------------------------------------------------------------ flat views used by both the HIP path and the oracle
     def topo(self):
@@ -182,6 +249,9 @@ class DecodeSchedule:
         tb, tl = self.topo()
         cb, cc, ci = self.cls()
         ab = self.assm_batch()
+        P = self.plan
+        ptab = {k: (put(P[k]), P[k].shape) for k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos", "dag_tree",
+                                                      "dag_inter", "in_tree", "in_inter", "pool", "cls_mess")}
         tail = dict(topo_batch=put(tb), topo_label=put(tl), cls_batch=put(cb), cls_clab=put(cc), cls_ilab=put(ci),
                     assm_batch=put(np.repeat(np.asarray(ab, dtype=np.int64), self.max_cls_size)))
         flat = np.concatenate(chunks) if chunks else np.zeros(0, np.int64)
@@ -197,7 +267,10 @@ class DecodeSchedule:
             d = {k: view(e[k]) for k in ("subnode", "submess", "atoms", "bonds", "cls_mess")}
             d["assm"] = [(k, {n: (view32(v) if n == "icls" else view(v)) for n, v in g.items()}) for k, g in e["assm"]]
             steps.append(d)
-        self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, **{k: view(v) for k, v in tail.items()})
+        plan = {k: ((view32 if k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos") else view)(i)).view(shape)
+                for k, (i, shape) in ptab.items()}
+        self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, plan=plan,
+                         **{k: view(v) for k, v in tail.items()})
         return self
 
 
@@ -267,6 +340,16 @@ class HierMPNDecoder(ScoreHeads):
             init_vecs = src_root_vecs
         else:
             init_vecs = F_.linear([src_root_vecs.contiguous()], [L], self.W_root.weight, self.W_root.bias)[:, :H]
+        if os.environ.get("GGPM_DECODER_BATCHED", "1") != "0" and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
+            topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_batched(schedule, D, tree_tensors, graph_tensors,
+                                                                            init_vecs)
+        else:
+            topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_stepwise(D, tree_tensors, graph_tensors, init_vecs)
+        return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev)
+
+    def _states_stepwise(self, D, tree_tensors, graph_tensors, init_vecs):
+        """The reference's loop, step by step (ggpm/decoder.py:175-259): three incremental encoder calls per step."""
+        dev = tree_tensors[0].device
 
         hmpn, rnn_cell = self.hmpn, self.rnn_cell
         inter_tensors = tree_tensors
@@ -296,12 +379,84 @@ class HierMPNDecoder(ScoreHeads):
                 assm_vecs.append(self.enum_attach_batched(hgraph.node, k, g["atoms"], g["icls"], g["nth"]))
                 assm_dest.append(g["dest"])
 
-        topo_vecs = torch.cat(topo_vecs, dim=0)
+        return torch.cat(topo_vecs, dim=0), torch.cat(cls_vecs, dim=0), assm_vecs, assm_dest
+
+    def _level_states(self, rnn, h0, hmess, dag, depth):
+        """All messages of one tree-side level at once: ``sparse_forward`` over every real message row with the
+        time-ordered predecessor table, iterated ``depth`` = longest chain times (see DecodeSchedule._level_plan)."""
+        E1 = dag.shape[0] + 1
+        rows = torch.arange(1, E1, dtype=torch.long, device=hmess.device)
+        I, H = rnn.input_size, rnn.hidden_size
+        if isinstance(h0, tuple):
+            i, o, u, f = rnn.W_i[0], rnn.W_o[0], rnn.W[0], rnn.W_f[0]
+            return F_.lstm_sparse(h0[0], h0[1], hmess, rows, dag, i.weight, i.bias, o.weight, o.bias, u.weight, u.bias,
+                                  f.weight, f.bias, depth, I, H)
+        return F_.gru_sparse(h0, hmess, rows, dag, rnn.W_z.weight, rnn.W_z.bias, rnn.W_r.weight, rnn.U_r.weight,
+                             rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias, depth, I, H)
+
+    def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
+        """Same vectors as ``_states_stepwise`` with the two tree-side levels de-sequentialised: only the atom level
+        (diterG interacting iterations per step) keeps the step loop; the attachment and motif levels are ONE call each
+        over all their messages (a DAG in decode time, DecodeSchedule._level_plan) and ONE read-out over all visits."""
+        hmpn, rnn_cell = self.hmpn, self.rnn_cell
+        H, He, P, T = self.hidden_size, self.embed_size, schedule.plan, D["plan"]
+        dev = tree_tensors[0].device
+        Hp = F_.padded_hidden(H)
+        izeros = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
+        n_gnodes = graph_tensors[0].size(0)
+        hgraph = IE.HTuple(mess=rnn_cell.get_init_state(graph_tensors[1]), vmask=izeros(n_gnodes),
+                           emask=izeros(graph_tensors[1].size(0)))
+        graph_emb = hmpn.embed_graph(graph_tensors) + (graph_tensors[-1],)
+        pooled, assm_vecs, assm_dest = [], [], []
+        off = P["inst_off"]
+        for t, st in enumerate(D["steps"]):                 # ---- atom level: the only truly sequential part
+            hgraph.vmask[st["atoms"]] = 1
+            hgraph.emask[st["bonds"]] = 1
+            if st["atoms"].numel() + st["bonds"].numel() > 0:
+                cur_graph = IE.apply_graph_mask(graph_emb, hgraph)
+                sub = hmpn.get_sub_tensor(cur_graph, (st["atoms"], st["bonds"]))[:-1]
+                hgraph.node, hgraph.mess = hmpn.graph_encoder(sub, hgraph.mess, n_gnodes, (st["atoms"], st["bonds"]))
+            pooled.append(F_.segment_sum(hgraph.node, F_.csr_from_padded(T["pool"][off[t]:off[t + 1]], ncols=n_gnodes), H))
+            for k, g in st["assm"]:
+                assm_vecs.append(self.enum_attach_batched(hgraph.node, k, g["atoms"], g["icls"], g["nth"]))
+                assm_dest.append(g["dest"])
+        pooled = torch.cat(pooled, dim=0)                    # [visits, Hp]
+        n_inst, E1, depth = P["n_inst"], P["E1"], max(P["chain"], 1)
+        ld = (H + MAX_POS + 3) // 4 * 4
+        src_csr = F_.csr_from_index(T["mess_inst"], ncols=n_inst)
+
+        def messages(hnode):                                 # [hnode[visit of the message] | onehot(position)]
+            return F_.tree_message_input(hnode, T["mess_inst"], src_csr, T["mess_pos"], H, MAX_POS, ld)[:, :H + MAX_POS]
+
+        def readout(enc, hnode, state, table):               # W_o([visit vector | sum of the incoming messages revealed])
+            hid = enc.rnn.get_hidden_state(state)
+            nei = F_.segment_sum(hid, F_.csr_from_padded(table, ncols=hid.shape[0]), H)
+            node = F_.linear([hnode, nei], [H, H], enc.W_o[0].weight, enc.W_o[0].bias, act=F_.ACT_RELU)
+            return enc.W_o[2](node)
+
+        # ---- attachment level (embed_sub_tree(is_inter_layer=True) + inter_encoder, ggpm/encoder.py:208-245)
+        finput = IE._embedding_rows(hmpn.E_i, T["inst_attach"])
+        hnode_i = hmpn.W_i[2](F_.linear([finput, pooled], [He, H], hmpn.W_i[0].weight, hmpn.W_i[0].bias, act=F_.ACT_RELU))
+        fm = tree_tensors[1]
+        h_i = self._level_states(hmpn.inter_encoder.rnn, rnn_cell.get_init_state(fm), messages(hnode_i), T["dag_inter"], depth)
+        hinter_node = readout(hmpn.inter_encoder, hnode_i, h_i, T["in_inter"])
+        # ---- motif level: the root vectors ride as B extra, frozen message rows (init_decoder_state, :102-122)
+        finput = IE._embedding_rows(hmpn.E_c, T["inst_motif"])
+        hnode_t = hmpn.W_c[2](F_.linear([finput, hinter_node], [He, H], hmpn.W_c[0].weight, hmpn.W_c[0].bias,
+                                        act=F_.ACT_RELU))
+        h_t = self._level_states(hmpn.tree_encoder.rnn, rnn_cell.get_init_state(fm, init_vecs), messages(hnode_t),
+                                 T["dag_tree"], depth)
+        htree_node = readout(hmpn.tree_encoder, hnode_t, h_t, T["in_tree"])
+        cls_vecs = torch.cat([init_vecs, rnn_cell.get_hidden_state(h_t).index_select(0, T["cls_mess"])], dim=0)
+        return htree_node[:, :H], cls_vecs, assm_vecs, assm_dest
+
+    def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev):
+        """The three batched heads and their losses / accuracies (ggpm/decoder.py:261-284)."""
+        H = self.hidden_size
         topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch"], topo_vecs)
         topo_loss = bce_with_logits_sum(topo_scores, D["topo_label"])
         topo_acc = ((topo_scores.detach() >= 0).long() == D["topo_label"]).float().sum() / D["topo_label"].numel()
 
-        cls_vecs = torch.cat(cls_vecs, dim=0)
         cls_loss, cls_pred, icls_pred = self.cls_losses(src_tree_vecs, D["cls_batch"], cls_vecs, D["cls_clab"],
                                                         D["cls_ilab"])
         cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
