@@ -85,6 +85,9 @@ class DecodeSchedule:
         tfnode, tfmess, cgraph = host(tree_tensors[0]), host(tree_tensors[1]), host(tree_tensors[4])
         tagraph, tbgraph = host(tree_tensors[2]), host(tree_tensors[3])
         gfmess = host(graph_tensors[1])
+        gagraph, gbgraph = host(graph_tensors[2]).astype(np.int64), host(graph_tensors[3]).astype(np.int64)
+        bond_live = np.zeros(gfmess.shape[0], dtype=bool)     # hgraph.emask as the loop evolves it
+        g_ag, g_bg = [], []
         tree_scope = tree_tensors[-1]
         S = DecodeSchedule()
         B = S.batch_size = len(orders)
@@ -117,6 +120,12 @@ class DecodeSchedule:
                       cls_mess=[], cls_batch=[], cls_clab=[], cls_ilab=[], assm=[])
             batch_list = [i for i in range(B) if t < len(orders[i])]
             revealed.update(subgraph[0])
+            # apply_graph_mask + get_sub_tensor of this step (ggpm/decoder.py:79-83, encoder.py:195-206), on the host:
+            # the rows of the step's atoms / bonds with the entries that are revealed by now
+            bond_live[np.asarray(subgraph[1], dtype=np.int64)] = True
+            ra, rb = gagraph[np.asarray(subgraph[0], dtype=np.int64)], gbgraph[np.asarray(subgraph[1], dtype=np.int64)]
+            g_ag.append(np.where(bond_live[ra], ra, 0))
+            g_bg.append(np.where(bond_live[rb], rb, 0))
             for i in batch_list:
                 xid, yid, tlab = orders[i][t]
                 st["subnode"].append(int(xid))
@@ -150,6 +159,12 @@ class DecodeSchedule:
             subgraph = reveal(new_atoms)
             S.steps.append(st)
         S._level_plan(tfnode, tfmess, tagraph, tbgraph, tree_scope, mess_time, mess_inst, inst_node, inst_step, pool_rows)
+        S.plan.update(g_agraph=np.concatenate(g_ag).reshape(-1, gagraph.shape[1]),
+                      g_bgraph=np.concatenate(g_bg).reshape(-1, gbgraph.shape[1]),
+                      atoms_all=np.asarray([a for st in S.steps for a in st["atoms"]], dtype=np.int64),
+                      bonds_all=np.asarray([b for st in S.steps for b in st["bonds"]], dtype=np.int64),
+                      atom_off=np.cumsum([0] + [len(st["atoms"]) for st in S.steps]).tolist(),
+                      bond_off=np.cumsum([0] + [len(st["bonds"]) for st in S.steps]).tolist())
         return S
 
     def _level_plan(self, tfnode, tfmess, tagraph, tbgraph, tree_scope, mess_time, mess_inst, inst_node, inst_step,
@@ -251,7 +266,8 @@ class DecodeSchedule:
         ab = self.assm_batch()
         P = self.plan
         ptab = {k: (put(P[k]), P[k].shape) for k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos", "dag_tree",
-                                                      "dag_inter", "in_tree", "in_inter", "pool", "cls_mess")}
+                                                      "dag_inter", "in_tree", "in_inter", "pool", "cls_mess", "g_agraph",
+                                                      "g_bgraph", "atoms_all", "bonds_all")}
         tail = dict(topo_batch=put(tb), topo_label=put(tl), cls_batch=put(cb), cls_clab=put(cc), cls_ilab=put(ci),
                     assm_batch=put(np.repeat(np.asarray(ab, dtype=np.int64), self.max_cls_size)))
         flat = np.concatenate(chunks) if chunks else np.zeros(0, np.int64)
@@ -404,17 +420,18 @@ class HierMPNDecoder(ScoreHeads):
         Hp = F_.padded_hidden(H)
         izeros = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
         n_gnodes = graph_tensors[0].size(0)
-        hgraph = IE.HTuple(mess=rnn_cell.get_init_state(graph_tensors[1]), vmask=izeros(n_gnodes),
-                           emask=izeros(graph_tensors[1].size(0)))
-        graph_emb = hmpn.embed_graph(graph_tensors) + (graph_tensors[-1],)
+        hgraph = IE.HTuple(mess=rnn_cell.get_init_state(graph_tensors[1]))
+        graph_emb = hmpn.embed_graph(graph_tensors)
+        # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
+        # feature rows of all steps are selected by one gather each
+        fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
+        fmess_all = graph_emb[1].index_select(0, T["bonds_all"])
         pooled, assm_vecs, assm_dest = [], [], []
-        off = P["inst_off"]
+        off, aoff, boff = P["inst_off"], P["atom_off"], P["bond_off"]
         for t, st in enumerate(D["steps"]):                 # ---- atom level: the only truly sequential part
-            hgraph.vmask[st["atoms"]] = 1
-            hgraph.emask[st["bonds"]] = 1
             if st["atoms"].numel() + st["bonds"].numel() > 0:
-                cur_graph = IE.apply_graph_mask(graph_emb, hgraph)
-                sub = hmpn.get_sub_tensor(cur_graph, (st["atoms"], st["bonds"]))[:-1]
+                sub = (fnode_all[aoff[t]:aoff[t + 1]], fmess_all[boff[t]:boff[t + 1]],
+                       T["g_agraph"][aoff[t]:aoff[t + 1]], T["g_bgraph"][boff[t]:boff[t + 1]])
                 hgraph.node, hgraph.mess = hmpn.graph_encoder(sub, hgraph.mess, n_gnodes, (st["atoms"], st["bonds"]))
             pooled.append(F_.segment_sum(hgraph.node, F_.csr_from_padded(T["pool"][off[t]:off[t + 1]], ncols=n_gnodes), H))
             for k, g in st["assm"]:
