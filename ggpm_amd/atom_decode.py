@@ -1,0 +1,340 @@
+"""The atom level of the teacher-forced decoder as ONE autograd node.
+
+Inside ``HierMPNDecoder.forward`` the reference calls ``IncHierMPNEncoder.forward`` once per decode step
+(ggpm/decoder.py:201-222); its first block (ggpm/encoder.py:235-239) recomputes, on the atom level, the bond messages
+among the atoms the previous step revealed (``diterG`` interacting iterations of ``sparse_forward``) and the vectors of
+those atoms (``IncMPNEncoder.forward``, ggpm/encoder.py:165-179).  This level is the part of the decoder that is truly
+sequential in the step index (the two tree-side levels are not, see ``DecodeSchedule._level_plan``).
+
+Teacher forcing fixes every index of that loop in advance, so ``AtomPlan`` builds all of them on the host, once per
+batch: per step the frozen mask, the masked predecessor CSR of the step's bonds and its transpose, the masked
+incoming-message CSR of the step's atoms and its transpose, and -- composed with the scatter into the zeroed node
+buffer the reference rebuilds at every step -- where each pooled cluster vector (``embed_sub_tree``) and each
+attachment candidate (``enum_attach``) reads the step's atom vectors.  ``atom_decode`` then runs the whole loop as one
+``torch.autograd.Function`` whose forward and backward call the C ABI directly (``ggpm_*_sparse_forward/backward``,
+``ggpm_segment_sum``, ``ggpm_gemm*``): no per-step autograd graph, no per-step index kernels, the gate input
+projections of ALL bonds computed once (they are depth- and step-invariant one-hot look-ups), and every weight gradient
+formed once per call (the read-out's from the stacked rows of all steps, the input halves from the summed ``dX``).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as F_
+
+
+def _csr_from_lists(counts: np.ndarray, flat: np.ndarray):
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), flat.astype(np.int32)
+
+
+def _transpose(rows: np.ndarray, cols: np.ndarray, ncols: int):
+    """(row, col) entry lists -> CSR of the transpose (rows of the result = columns), entries ascending."""
+    order = np.lexsort((rows, cols))
+    return (np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=ncols))]).astype(np.int32),
+            rows[order].astype(np.int32))
+
+
+class AtomPlan:
+    """Host-built index tables of the atom-level decode loop (see the module docstring)."""
+
+    def __init__(self, schedule, n_gnodes: int, n_gmess: int):
+        P, steps = schedule.plan, schedule.steps
+        self.T, self.N1, self.E1 = len(steps), n_gnodes, n_gmess
+        self.ok = all(len(st["atoms"]) > 0 for st in steps)          # (the reference keeps a stale node buffer otherwise)
+        ints: List[np.ndarray] = []
+        self.where = {}
+
+        def put(key, a):
+            self.where[key] = (sum(len(x) for x in ints), len(a))
+            ints.append(np.asarray(a, dtype=np.int32).reshape(-1))
+
+        frozen = np.ones((self.T, n_gmess), dtype=np.uint8)
+        aoff, boff, ioff = P["atom_off"], P["bond_off"], P["inst_off"]
+        self.aoff, self.ioff = aoff, ioff
+        # candidate atoms of all steps, grouped by atoms-per-candidate k first, then by step: one contiguous block per k
+        groups = sorted({len(icls) for st in steps for (_, icls, _, _) in st["assm"]})
+        cand_pos = {k: [] for k in groups}
+        cand_meta = {k: dict(icls=[], nth=[], dest=[]) for k in groups}
+        per_step_cands = []
+        pred_i = 0
+        for t, st in enumerate(steps):
+            bonds = np.asarray(st["bonds"], dtype=np.int64)
+            atoms = np.asarray(st["atoms"], dtype=np.int64)
+            frozen[t, bonds] = 0
+            # predecessor CSR over all E1 rows (only this step's bonds have entries) and its transpose
+            order = np.argsort(bonds, kind="stable")
+            tab = P["g_bgraph"][boff[t]:boff[t + 1]][order]
+            cnt = (tab > 0).sum(axis=1)
+            counts = np.zeros(n_gmess, dtype=np.int64)
+            counts[bonds[order]] = cnt
+            rp, col = _csr_from_lists(counts, tab[tab > 0])
+            put(("pred_rp", t), rp); put(("pred_col", t), col)
+            rpT, colT = _transpose(np.repeat(bonds[order], cnt), tab[tab > 0], n_gmess)
+            put(("succ_rp", t), rpT); put(("succ_col", t), colT)
+            # incoming messages of the step's atoms (rows local to the step) and the transpose (rows = messages)
+            atab = P["g_agraph"][aoff[t]:aoff[t + 1]]
+            acnt = (atab > 0).sum(axis=1)
+            rp, col = _csr_from_lists(acnt, atab[atab > 0])
+            put(("agr_rp", t), rp); put(("agr_col", t), col)
+            rpT, colT = _transpose(np.repeat(np.arange(len(atoms)), acnt), atab[atab > 0], n_gmess)
+            put(("agrT_rp", t), rpT); put(("agrT_col", t), colT)
+            # pooled cluster vectors of the step's visits read the step's atom vectors (other atoms' rows are zero in
+            # the node buffer the reference rebuilds every step)
+            pos = np.full(n_gnodes, -1, dtype=np.int64)
+            pos[atoms] = np.arange(len(atoms))
+            ptab = P["pool"][ioff[t]:ioff[t + 1]]
+            loc = np.where(ptab > 0, pos[ptab], -1)
+            pcnt = (loc >= 0).sum(axis=1)
+            rp, col = _csr_from_lists(pcnt, loc[loc >= 0])
+            put(("pool_rp", t), rp); put(("pool_col", t), col)
+            rpT, colT = _transpose(np.repeat(np.arange(len(ptab)), pcnt), loc[loc >= 0], len(atoms))
+            put(("poolT_rp", t), rpT); put(("poolT_col", t), colT)
+            here = []
+            for (cands, icls, nth, _) in st["assm"]:
+                k, n = len(icls), len(cands)
+                start = len(cand_pos[k])
+                cand_pos[k].extend(pos[cands.reshape(-1)].tolist())
+                m = cand_meta[k]
+                m["icls"].extend(list(icls) * n)
+                m["nth"].extend([nth] * (n * k))
+                m["dest"].extend(range(pred_i * schedule.max_cls_size, pred_i * schedule.max_cls_size + n))
+                here.append((k, start, n * k))
+                pred_i += 1
+            per_step_cands.append(here)
+        # flat candidate layout: block of k = 1 rows, then k = 2 ...
+        base, self.cand_blocks = 0, []
+        for k in groups:
+            self.cand_blocks.append((k, base, len(cand_pos[k])))
+            base += len(cand_pos[k])
+        self.n_cand = base
+        kbase = {k: b for k, b, _ in self.cand_blocks}
+        self.step_cands = []                                  # per step: [(flat row offset, count)] + transposed scatter
+        for t, here in enumerate(per_step_cands):
+            segs = [(kbase[k] + start, n) for (k, start, n) in here]
+            self.step_cands.append(segs)
+            ns = aoff[t + 1] - aoff[t]
+            for j, (k, start, n) in enumerate(here):
+                p = np.asarray(cand_pos[k][start:start + n], dtype=np.int64)
+                put(("cand_pos", t, j), p)
+                ok = p >= 0
+                rpT, colT = _transpose(np.arange(n)[ok], p[ok], ns)
+                put(("candT_rp", t, j), rpT); put(("candT_col", t, j), colT)
+        self.cand_meta = {k: {n: np.asarray(v, dtype=np.int64) for n, v in m.items()} for k, m in cand_meta.items()}
+        self.ints = np.concatenate(ints) if ints else np.zeros(0, np.int32)
+        self.frozen = frozen
+        self._dev = None
+
+    def to_device(self, device):
+        if self._dev is None or self._dev["device"] != device:
+            cuda = torch.device(device).type == "cuda"
+            hi, hf = torch.from_numpy(self.ints), torch.from_numpy(self.frozen)
+            if cuda:
+                hi, hf = hi.pin_memory(), hf.pin_memory()
+            di, df = hi.to(device, non_blocking=True), hf.to(device, non_blocking=True)
+            base = di.data_ptr()
+            ptr = {k: base + 4 * off for k, (off, n) in self.where.items()}
+            meta = {k: {n: torch.from_numpy(v).to(device, non_blocking=True) for n, v in m.items()}
+                    for k, m in self.cand_meta.items()}
+            for m in meta.values():
+                m["icls"] = m["icls"].to(torch.int32)
+            self._dev = dict(device=device, ints=di, frozen=df, ptr=ptr, meta=meta, keep=(hi, hf))
+        return self._dev
+
+
+def _vp(addr: int) -> ctypes.c_void_p:
+    return ctypes.c_void_p(addr)
+
+
+class _AtomDecode(torch.autograd.Function):
+    """(pooled cluster vectors of all visits [n_inst, Hp], attachment-candidate atom vectors [n_cand, Hp])."""
+
+    @staticmethod
+    def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, *params):
+        lib = _lib.load()
+        dev = hmess.device
+        D = plan.to_device(dev)
+        ptr, P = D["ptr"], F_._p
+        Hp = F_.padded_hidden(H)
+        E1, T = plan.E1, plan.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        lstm = cell == "LSTM"
+        G = 4 if lstm else 3
+        if lstm:
+            Wi, bi, Wo_g, bo_g, Wu, bu_g, Wf, bf, Wout, bout = params
+            gates = ((Wi, bi), (Wo_g, bo_g), (Wu, bu_g), (Wf, bf))
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
+            gates = ((Wz, bz), (Wr, None), (Wh, bh))
+        # hoisted gate input projections of ALL bond messages (step and depth invariant)
+        X = torch.empty(G, E1, Hp, **f32)
+        for k, (W, b) in enumerate(gates):
+            F_.gemm(0, 1, E1, H, I, hmess, F_._ld(hmess), W, W.stride(0), X[k], Hp, Hp, bias=b)
+        Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
+        Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
+        Qs = torch.empty(T, depth, E1, Hp, **f32)
+        St = torch.empty(T, 5, depth, E1, Hp, **f32)
+        zero = torch.zeros(E1, Hp, **f32)
+        ns_tot, n_inst = plan.aoff[-1], plan.ioff[-1]
+        NODE = torch.empty(ns_tot, Hp, **f32)
+        NEI = torch.empty(ns_tot, Hp, **f32)
+        pooled = torch.empty(n_inst, Hp, **f32)
+        cand = torch.zeros(max(plan.n_cand, 1), Hp, **f32)
+        wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H) if lstm else lib.ggpm_gru_pack_floats(H)), **f32)
+        s = F_._stream()
+        frz = D["frozen"]
+        ldF, ldwo = F_._ld(fn_all), Wout.stride(0)
+        h_prev, c_prev = zero, zero
+        for t in range(T):
+            a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
+            ns, ni = a1 - a0, i1 - i0
+            st = St[t]
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_forward(
+                    E1, H, depth, P(h_prev), P(c_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(X[3]), P(Wi[:, I:]),
+                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
+                    _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), P(Hs[t]), P(Cs[t]), P(Qs[t]), P(st[0]), P(st[1]),
+                    P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s), "lstm_sparse_forward")
+                c_prev = Cs[t, depth]
+            else:
+                _lib.check(lib.ggpm_gru_sparse_forward(
+                    E1, H, depth, P(h_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
+                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
+                    P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s),
+                    "gru_sparse_forward")
+            h_prev = Hs[t, depth]
+            nei, node = NEI[a0:a1], NODE[a0:a1]
+            _lib.check(lib.ggpm_segment_sum(P(h_prev), Hp, _vp(ptr[("agr_rp", t)]), _vp(ptr[("agr_col", t)]), ns, H,
+                                            P(nei), Hp, 0, Hp, s), "segment_sum")
+            F_.gemm_ksegments(1, ns, H, [fn_all[a0:a1], nei], [ldF, Hp], [Wout, Wout[:, Fdim:]], [ldwo, ldwo], [Fdim, H],
+                              node, Hp, Hp, bias=bout, act=F_.ACT_RELU)
+            if drop is not None:
+                _lib.check(lib.ggpm_dropout(P(node), ns, H, Hp, drop[0], drop[1], drop[2], t, s), "dropout")
+            _lib.check(lib.ggpm_segment_sum(P(node), Hp, _vp(ptr[("pool_rp", t)]), _vp(ptr[("pool_col", t)]), ni, H,
+                                            P(pooled[i0:i1]), Hp, 0, Hp, s), "segment_sum")
+            for j, (row0, n) in enumerate(plan.step_cands[t]):
+                _lib.check(lib.ggpm_gather_rows(P(node), Hp, _vp(ptr[("cand_pos", t, j)]), n, H, P(cand[row0:row0 + n]),
+                                                Hp, 0, Hp, s), "gather_rows")
+        ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
+        ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
+        ctx.keep = D
+        return pooled, cand
+
+    @staticmethod
+    def backward(ctx, d_pooled, d_cand):
+        lib = _lib.load()
+        plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
+        lstm = cell == "LSTM"
+        sv = list(ctx.saved_tensors)
+        fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
+        Cs = sv[8] if lstm else None
+        params = sv[9:] if lstm else sv[8:]
+        D = ctx.keep
+        ptr, P = D["ptr"], F_._p
+        dev = hmess.device
+        Hp = F_.padded_hidden(H)
+        E1, T = plan.E1, plan.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        G = 4 if lstm else 3
+        if lstm:
+            Wi, bi, Wo_g, bo_g, Wu, bu_g, Wf, bf, Wout, bout = params
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
+        d_pooled = d_pooled.contiguous()
+        d_cand = d_cand.contiguous()
+        s = F_._stream()
+        frz = D["frozen"]
+        ns_tot = plan.aoff[-1]
+        DPRE = torch.empty(ns_tot, Hp, **f32)
+        dX_tot = torch.zeros(G, E1, Hp, **f32)
+        dX = torch.empty(G, E1, Hp, **f32)
+        dH, dH2 = torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)
+        dC, dC2 = (torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)) if lstm else (None, None)
+        nh = 4 if lstm else 3                                   # hidden-half weight gradients (+ GRU: b_u)
+        acc = [torch.zeros(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.zeros(H, **f32)])
+        tmp = [torch.empty(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.empty(H, **f32)])
+        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(E1, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        ldwo = Wout.stride(0)
+        for t in range(T - 1, -1, -1):
+            a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
+            ns, ni = a1 - a0, i1 - i0
+            d_node = torch.empty(ns, Hp, **f32)
+            _lib.check(lib.ggpm_segment_sum(P(d_pooled[i0:i1]), Hp, _vp(ptr[("poolT_rp", t)]), _vp(ptr[("poolT_col", t)]),
+                                            ns, H, P(d_node), Hp, 0, Hp, s), "segment_sum")
+            for j, (row0, n) in enumerate(plan.step_cands[t]):
+                _lib.check(lib.ggpm_segment_sum(P(d_cand[row0:row0 + n]), Hp, _vp(ptr[("candT_rp", t, j)]),
+                                                _vp(ptr[("candT_col", t, j)]), ns, H, P(d_node), Hp, 1, 0, s), "segment_sum")
+            dpre = DPRE[a0:a1]
+            _lib.check(lib.ggpm_act_backward(P(d_node), P(NODE[a0:a1]), ns, H, Hp, F_.ACT_RELU, 0, P(dpre), s), "act_backward")
+            if drop is not None:            # d(dropout . relu) = mask * scale * relu' (the saved output is the dropped one)
+                _lib.check(lib.ggpm_dropout(P(dpre), ns, H, Hp, drop[0], drop[1], drop[2], t, s), "dropout")
+            d_nei = torch.empty(ns, Hp, **f32)
+            F_.gemm(0, 0, ns, H, H, dpre, Hp, Wout[:, Fdim:], ldwo, d_nei, Hp, Hp)
+            # d(state after step t) = what step t+1 passed back + the read-out's share
+            _lib.check(lib.ggpm_segment_sum(P(d_nei), Hp, _vp(ptr[("agrT_rp", t)]), _vp(ptr[("agrT_col", t)]), E1, H,
+                                            P(dH), Hp, 1, 0, s), "segment_sum")
+            st = St[t]
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_backward(
+                    E1, H, depth, P(frz[t]), P(X[3]), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0),
+                    P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), _vp(ptr[("pred_rp", t)]),
+                    _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Cs[t]),
+                    P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH), P(dC), P(dH2), P(dC2), P(dX[0]),
+                    P(dX[1]), P(dX[2]), P(dX[3]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[2]), H, P(tmp[3]), H, P(work),
+                    work.numel() * 4, s), "lstm_sparse_backward")
+                dC, dC2 = dC2, dC
+            else:
+                _lib.check(lib.ggpm_gru_sparse_backward(
+                    E1, H, depth, P(frz[t]), P(X[1]), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]),
+                    Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]),
+                    _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH),
+                    P(dH2), P(dX[0]), P(dX[1]), P(dX[2]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[3]), P(tmp[2]), H, P(work),
+                    work.numel() * 4, s), "gru_sparse_backward")
+            dH, dH2 = dH2, dH
+            torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
+        # ---- parameter gradients, once
+        x_ld = F_._ld(hmess)
+
+        def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
+            dW = torch.empty_like(W)
+            F_.gemm(1, 0, H, I, E1, dX_tot[k], Hp, hmess, x_ld, dW, dW.stride(0), I, splitk=True)
+            if hidden is not None:
+                dW[:, I:] = hidden
+            return dW
+
+        dWout = torch.empty_like(Wout)
+        F_.gemm(1, 0, H, Fdim, ns_tot, DPRE, Hp, fn_all, F_._ld(fn_all), dWout, dWout.stride(0), Fdim, splitk=True)
+        F_.gemm(1, 0, H, H, ns_tot, DPRE, Hp, NEI, Hp, dWout[:, Fdim:], dWout.stride(0), H, splitk=True)
+        dbout = F_.colsum(DPRE, ns_tot, H)
+        if lstm:
+            grads = []
+            for k, W in enumerate((Wi, Wo_g, Wu, Wf)):
+                grads += [full(W, k, acc[k]), F_.colsum(dX_tot[k], E1, H)]
+            grads += [dWout, dbout]
+        else:          # tmp / acc order of the GRU: Wz_h, U_r, Wh_h, b_u
+            grads = [full(Wz, 0, acc[0]), F_.colsum(dX_tot[0], E1, H), full(Wr, 1, None), acc[1], acc[3],
+                     full(Wh, 2, acc[2]), F_.colsum(dX_tot[2], E1, H), dWout, dbout]
+        return (None,) * 9 + tuple(grads)
+
+
+def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: torch.Tensor, fn_all: torch.Tensor):
+    """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``."""
+    from .rnn import LSTM
+    rnn, wo = graph_encoder.rnn, graph_encoder.W_o
+    lstm = isinstance(rnn, LSTM)
+    if lstm:
+        params = (rnn.W_i[0].weight, rnn.W_i[0].bias, rnn.W_o[0].weight, rnn.W_o[0].bias, rnn.W[0].weight, rnn.W[0].bias,
+                  rnn.W_f[0].weight, rnn.W_f[0].bias)
+    else:
+        params = (rnn.W_z.weight, rnn.W_z.bias, rnn.W_r.weight, rnn.U_r.weight, rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias)
+    drop = None
+    if graph_encoder.training and wo[2].p > 0:
+        seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64)
+        drop = (float(wo[2].p), int(seed[0]), int(seed[1]))
+    return _AtomDecode.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
+                             rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)

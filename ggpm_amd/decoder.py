@@ -44,6 +44,7 @@ class DecodeSchedule:
     def __init__(self):
         self.steps: List[dict] = []
         self.plan: Optional[dict] = None
+        self._atom_plan = None
         self.root_clab: List[int] = []
         self.root_ilab: List[int] = []
         self.max_cls_size = 0
@@ -219,6 +220,13 @@ class DecodeSchedule:
             inst_off=np.cumsum([0] + [len(st["subnode"]) for st in self.steps]).tolist())
 
     # ------------------------------------------------------------------ flat views used by both the HIP path and the oracle
+    def atom_plan(self, n_gnodes: int, n_gmess: int):
+        """Index tables of the atom-level decode loop (ggpm_amd.atom_decode.AtomPlan), built once per batch."""
+        if self._atom_plan is None:
+            from .atom_decode import AtomPlan
+            self._atom_plan = AtomPlan(self, n_gnodes, n_gmess)
+        return self._atom_plan
+
     def topo(self):
         """(batch index, label) of every topology prediction in the reference's order (step major)."""
         return ([i for st in self.steps for i in st["topo_batch"]], [v for st in self.steps for v in st["topo_label"]])
@@ -326,8 +334,11 @@ class HierMPNDecoder(ScoreHeads):
         atoms: ``matchNN([node[cand] | E_assm(icls) | onehot(nth_child)])``, summed over the ``k`` atoms of a candidate.
         ``atoms`` / ``nth`` int64, ``icls`` int32 (embedding ids, as the gather kernel reads them).
         -> [candidates, Hp] (zero pad columns)."""
+        return self.enum_attach_rows(hgraph_node.index_select(0, atoms).contiguous(), k, icls, nth)
+
+    def enum_attach_rows(self, cand, k: int, icls, nth) -> torch.Tensor:
+        """As ``enum_attach_batched`` with the candidates' atom vectors already gathered (one row per candidate atom)."""
         H, He = self.hidden_size, self.embed_size
-        cand = hgraph_node.index_select(0, atoms).contiguous()
         emb = IE._embedding_rows(self.E_assm, icls)
         order = TF.one_hot(nth, MAX_POS).to(torch.float32)
         l1 = self.matchNN[0]
@@ -425,10 +436,21 @@ class HierMPNDecoder(ScoreHeads):
         # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
         # feature rows of all steps are selected by one gather each
         fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
-        fmess_all = graph_emb[1].index_select(0, T["bonds_all"])
         pooled, assm_vecs, assm_dest = [], [], []
         off, aoff, boff = P["inst_off"], P["atom_off"], P["bond_off"]
-        for t, st in enumerate(D["steps"]):                 # ---- atom level: the only truly sequential part
+        ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if os.environ.get("GGPM_ATOM_DECODE", "1") != "0" else None
+        if ap is not None and ap.ok:                        # ---- atom level as ONE autograd node (atom_decode.py)
+            from .atom_decode import atom_decode
+            pooled_all, cand = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all)
+            meta = ap.to_device(dev)["meta"]
+            for k, base, n in ap.cand_blocks:
+                assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
+                assm_dest.append(meta[k]["dest"])
+            steps = []
+        else:
+            fmess_all = graph_emb[1].index_select(0, T["bonds_all"])
+            steps = D["steps"]
+        for t, st in enumerate(steps):                      # ---- atom level, step by step (fallback)
             if st["atoms"].numel() + st["bonds"].numel() > 0:
                 sub = (fnode_all[aoff[t]:aoff[t + 1]], fmess_all[boff[t]:boff[t + 1]],
                        T["g_agraph"][aoff[t]:aoff[t + 1]], T["g_bgraph"][boff[t]:boff[t + 1]])
@@ -437,7 +459,7 @@ class HierMPNDecoder(ScoreHeads):
             for k, g in st["assm"]:
                 assm_vecs.append(self.enum_attach_batched(hgraph.node, k, g["atoms"], g["icls"], g["nth"]))
                 assm_dest.append(g["dest"])
-        pooled = torch.cat(pooled, dim=0)                    # [visits, Hp]
+        pooled = torch.cat(pooled, dim=0) if steps else pooled_all          # [visits, Hp]
         n_inst, E1, depth = P["n_inst"], P["E1"], max(P["chain"], 1)
         ld = (H + MAX_POS + 3) // 4 * 4
         src_csr = F_.csr_from_index(T["mess_inst"], ncols=n_inst)

@@ -902,16 +902,18 @@ def _vae_names():
     return vae_case_names()
 
 
-@pytest.mark.parametrize("mode", ["batched", "stepwise"])
+@pytest.mark.parametrize("mode", ["batched", "levels", "stepwise"])
 @pytest.mark.parametrize("name", _vae_names())
 def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     """The full VAE training step -- HierPropertyVAE.forward (ggpm/property_vae.py:47-62): encoder, rsample, the
     teacher-forced HierMPNDecoder.forward with enum_attach and the four losses (ggpm/decoder.py:166-301) -- and its
     backward, vs vectors the reference itself produced: total loss (reconstruction + beta KL), KL, the metric tuple and
     the gradient of every parameter (tied embeddings included).  Both forms of the decoder: ``stepwise`` (the reference's
-    loop, three incremental-encoder calls per step) and ``batched`` (default: the attachment and motif levels as ONE
-    level call each over the decode-time DAG of their messages, only the atom level stepping)."""
-    monkeypatch.setenv("GGPM_DECODER_BATCHED", "1" if mode == "batched" else "0")
+    loop, three incremental-encoder calls per step), ``levels`` (the attachment and motif levels as ONE level call each
+    over the decode-time DAG of their messages, the atom level stepping through the incremental encoder) and ``batched``
+    (default: additionally the atom level's step loop as one autograd node on host-built index tables, atom_decode.py)."""
+    monkeypatch.setenv("GGPM_DECODER_BATCHED", "0" if mode == "stepwise" else "1")
+    monkeypatch.setenv("GGPM_ATOM_DECODE", "1" if mode == "batched" else "0")
     from golden_utils import VaeGolden
     from ggpm_amd import synth
     from ggpm_amd.decoder import DecodeSchedule
