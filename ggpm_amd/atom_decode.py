@@ -48,10 +48,13 @@ class AtomPlan:
         self.ok = all(len(st["atoms"]) > 0 for st in steps)          # (the reference keeps a stale node buffer otherwise)
         ints: List[np.ndarray] = []
         self.where = {}
+        fill = [0]
 
         def put(key, a):
-            self.where[key] = (sum(len(x) for x in ints), len(a))
-            ints.append(np.asarray(a, dtype=np.int32).reshape(-1))
+            a = np.asarray(a, dtype=np.int32).reshape(-1)
+            self.where[key] = (fill[0], len(a))
+            fill[0] += len(a)
+            ints.append(a)
 
         frozen = np.ones((self.T, n_gmess), dtype=np.uint8)
         aoff, boff, ioff = P["atom_off"], P["bond_off"], P["inst_off"]

@@ -249,9 +249,12 @@ class DecodeSchedule:
         chunks: List[np.ndarray] = []
         where: List[Tuple[int, int]] = []
 
+        fill = [0]
+
         def put(values) -> int:
             a = np.asarray(values, dtype=np.int64).reshape(-1)
-            where.append((sum(len(c) for c in chunks), len(a)))
+            where.append((fill[0], len(a)))
+            fill[0] += len(a)
             chunks.append(a)
             return len(where) - 1
 
