@@ -21,6 +21,13 @@
 constexpr int GGPM_NW = 4;        // waves per workgroup of the "B" kernels (one output tile per wave)
 constexpr int GGPM_NWA = 16;      // waves per workgroup of the "A" kernels: all 16 gather, the first TG own a tile
 constexpr int GGPM_PF = 4;        // weight-fragment prefetch depth (k chunks)
+#ifndef GGPM_PF3
+#define GGPM_PF3 3                // ... of the three-product loops (LSTM): 4 deep spilled 13-17 registers (48 -> 45.6 us)
+#endif
+#ifndef GGPM_CHAIN_MAX
+#define GGPM_CHAIN_MAX 3          // loops with fewer products than this chain their ring across a wave's tiles
+#endif
+template <int NOPS> struct GgpmPf { static constexpr int value = NOPS >= 3 ? GGPM_PF3 : GGPM_PF; };
 
 // Packed weight tile order: [out tile t][k chunk kc][lane 0..63][4 floats].
 __device__ __forceinline__ size_t ggpm_pack_index(int t, int kc, int KC, int lane) {
@@ -30,7 +37,7 @@ __device__ __forceinline__ size_t ggpm_pack_index(int t, int kc, int KC, int lan
 // Weight-fragment prefetch ring of one wave: PF k chunks x NOPS products, one 16-byte fragment per lane each.
 template <int NOPS>
 struct GgpmRing {
-    f32x4 r[GGPM_PF][NOPS];
+    f32x4 r[GgpmPf<NOPS>::value][NOPS];
 };
 
 // Loads the first PF chunks of tile t into the ring.  The weights do not depend on anything the kernel computes, so a
@@ -40,7 +47,7 @@ template <int NOPS>
 __device__ __forceinline__ void ggpm_ring_prefetch(const float* const (&wps)[NOPS], int KC, int t, int lane,
                                                    GgpmRing<NOPS>& ring) {
 #pragma unroll
-    for (int d = 0; d < GGPM_PF; ++d) {
+    for (int d = 0; d < GgpmPf<NOPS>::value; ++d) {
         const int kk = min(d, KC - 1);
 #pragma unroll
         for (int o = 0; o < NOPS; ++o)
@@ -53,11 +60,11 @@ __device__ __forceinline__ void ggpm_ring_prefetch(const float* const (&wps)[NOP
 // 4*NOPS*RT MFMAs per k chunk.  `ring` must hold the first PF chunks of tile t (ggpm_ring_prefetch); refills past the
 // end of tile t fetch the head of tile `t_next` (>= 0: the wave's next tile of the same products, whose call then
 // finds its ring loaded) or re-read the last chunk (t_next < 0; no branch).
-template <int NOPS, int RT, bool CHAIN = (NOPS < 3)>      // (three products: the chained ring costs registers -> spills)
+template <int NOPS, int RT, bool CHAIN = (NOPS < GGPM_CHAIN_MAX)>
 __device__ __forceinline__ void ggpm_wave_gemm_ring(const float* const (&tiles)[NOPS], int LD,
                                                     const float* const (&wps)[NOPS], int KC, int t, int t_next, int lane,
                                                     f32x4 (&acc)[NOPS][RT], GgpmRing<NOPS>& ring) {
-    constexpr int PF = GGPM_PF;       // (a deeper ring for the single-product loops measured no faster)
+    constexpr int PF = GgpmPf<NOPS>::value;       // (a deeper ring for the single-product loops measured no faster)
     const int boff = (lane & 15) * LD + 4 * (lane >> 4);
     const float* wp[NOPS];
     const float* wn[NOPS];
