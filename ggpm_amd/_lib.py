@@ -32,6 +32,7 @@ SIGNATURES = {
     "ggpm_act_backward": (I, [P, P, I, I, I, I, I, P, P]),
     "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, I, P]),
     "ggpm_gather_rows": (I, [P, I, P, I, I, P, I, I, I, P]),
+    "ggpm_scatter_rows": (I, [P, I, P, I, I, P, I, I, P]),
     "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
     "ggpm_gru_pack_floats": (c_size_t, [I]),

@@ -15,10 +15,19 @@ attachment candidate (``enum_attach``) reads the step's atom vectors.  ``atom_de
 ``ggpm_segment_sum``, ``ggpm_gemm*``): no per-step autograd graph, no per-step index kernels, the gate input
 projections of ALL bonds computed once (they are depth- and step-invariant one-hot look-ups), and every weight gradient
 formed once per call (the read-out's from the stacked rows of all steps, the input halves from the summed ``dX``).
+
+Compact steps (default, GGPM_ATOM_COMPACT=0 switches them off): a step recomputes a few hundred of the level's thousands
+of bond messages, so its ``sparse_forward`` runs on the step's COMPACT row set -- the step's bonds plus the frozen
+older bonds they read, renumbered 0..n-1 with host-built local CSRs -- instead of on every row of the level with a
+frozen mask: the rows are gathered from / scattered back into the level-wide state (``ggpm_gather_rows`` /
+``ggpm_scatter_rows``), the depth kernels launch ~1/8 of the row tiles and the hidden-half weight-gradient
+contractions shrink by the same factor.  Same arithmetic per row, so the results are bit-identical to the full-level
+form except for the weight gradients' summation order.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List
 
 import numpy as np
@@ -57,6 +66,8 @@ class AtomPlan:
             ints.append(a)
 
         frozen = np.ones((self.T, n_gmess), dtype=np.uint8)
+        frozen_loc: List[np.ndarray] = []                     # compact steps: mask over the step's local rows
+        self.nloc, self.floc_off = [], [0]
         aoff, boff, ioff = P["atom_off"], P["bond_off"], P["inst_off"]
         self.aoff, self.ioff = aoff, ioff
         # candidate atoms of all steps, grouped by atoms-per-candidate k first, then by step: one contiguous block per k
@@ -79,6 +90,24 @@ class AtomPlan:
             put(("pred_rp", t), rp); put(("pred_col", t), col)
             rpT, colT = _transpose(np.repeat(bonds[order], cnt), tab[tab > 0], n_gmess)
             put(("succ_rp", t), rpT); put(("succ_col", t), colT)
+            # the same two CSRs over the step's compact row set: its bonds + the frozen rows they read + the null row
+            rows = np.union1d(np.union1d(bonds, tab[tab > 0]), [0]).astype(np.int64)
+            n = len(rows)
+            lpos = np.full(n_gmess, -1, dtype=np.int64)
+            lpos[rows] = np.arange(n)
+            lcounts = np.zeros(n, dtype=np.int64)
+            lcounts[lpos[bonds[order]]] = cnt                  # (ascending global id = ascending local id)
+            rp, col = _csr_from_lists(lcounts, lpos[tab[tab > 0]])
+            put(("lpred_rp", t), rp); put(("lpred_col", t), col)
+            rpT, colT = _transpose(np.repeat(lpos[bonds[order]], cnt), lpos[tab[tab > 0]], n)
+            put(("lsucc_rp", t), rpT); put(("lsucc_col", t), colT)
+            fl = np.ones(n, dtype=np.uint8)
+            fl[lpos[bonds]] = 0
+            frozen_loc.append(fl)
+            self.nloc.append(n)
+            self.floc_off.append(self.floc_off[-1] + (n + 15) // 16 * 16)
+            put(("rows", t), rows)                             # local -> level row
+            put(("live", t), np.where(fl == 0, rows, -1))      # ... of the recomputed rows only (-1: skip)
             # incoming messages of the step's atoms (rows local to the step) and the transpose (rows = messages)
             atab = P["g_agraph"][aoff[t]:aoff[t + 1]]
             acnt = (atab > 0).sum(axis=1)
@@ -130,23 +159,52 @@ class AtomPlan:
         self.cand_meta = {k: {n: np.asarray(v, dtype=np.int64) for n, v in m.items()} for k, m in cand_meta.items()}
         self.ints = np.concatenate(ints) if ints else np.zeros(0, np.int32)
         self.frozen = frozen
+        self.frozen_loc = np.ones(self.floc_off[-1], dtype=np.uint8)
+        for t, fl in enumerate(frozen_loc):
+            self.frozen_loc[self.floc_off[t]:self.floc_off[t] + len(fl)] = fl
         self._dev = None
+
+    def gate_rows(self, t: int, gates: int) -> np.ndarray:
+        """Rows of the step's compact set inside the stacked [gates * E1, Hp] gate-input matrix."""
+        off, n = self.where[("rows", t)]
+        rows = self.ints[off:off + n].astype(np.int64)
+        return np.concatenate([k * self.E1 + rows for k in range(gates)]).astype(np.int32)
 
     def to_device(self, device):
         if self._dev is None or self._dev["device"] != device:
             cuda = torch.device(device).type == "cuda"
             hi, hf = torch.from_numpy(self.ints), torch.from_numpy(self.frozen)
+            hl = torch.from_numpy(self.frozen_loc)
             if cuda:
-                hi, hf = hi.pin_memory(), hf.pin_memory()
+                hi, hf, hl = hi.pin_memory(), hf.pin_memory(), hl.pin_memory()
             di, df = hi.to(device, non_blocking=True), hf.to(device, non_blocking=True)
+            dl = hl.to(device, non_blocking=True)
             base = di.data_ptr()
             ptr = {k: base + 4 * off for k, (off, n) in self.where.items()}
             meta = {k: {n: torch.from_numpy(v).to(device, non_blocking=True) for n, v in m.items()}
                     for k, m in self.cand_meta.items()}
             for m in meta.values():
                 m["icls"] = m["icls"].to(torch.int32)
-            self._dev = dict(device=device, ints=di, frozen=df, ptr=ptr, meta=meta, keep=(hi, hf))
+            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta, keep=(hi, hf, hl),
+                             gate_rows={})
         return self._dev
+
+    def gate_rows_device(self, gates: int):
+        """Per step: device pointer of gate_rows(t, gates) (3 gates for the GRU, 4 for the LSTM); built on first use."""
+        D = self._dev
+        if gates not in D["gate_rows"]:
+            parts = [self.gate_rows(t, gates) for t in range(self.T)]
+            offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
+            h = torch.from_numpy(np.concatenate(parts))
+            if D["ints"].is_cuda:
+                h = h.pin_memory()
+            d = h.to(D["device"], non_blocking=True)
+            D["gate_rows"][gates] = (d, h, [d.data_ptr() + 4 * int(o) for o in offs[:-1]])
+        return D["gate_rows"][gates][2]
+
+
+def compact_enabled() -> bool:
+    return os.environ.get("GGPM_ATOM_COMPACT", "1") != "0"
 
 
 def _vp(addr: int) -> ctypes.c_void_p:
@@ -177,11 +235,19 @@ class _AtomDecode(torch.autograd.Function):
         X = torch.empty(G, E1, Hp, **f32)
         for k, (W, b) in enumerate(gates):
             F_.gemm(0, 1, E1, H, I, hmess, F_._ld(hmess), W, W.stride(0), X[k], Hp, Hp, bias=b)
-        Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
-        Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
-        Qs = torch.empty(T, depth, E1, Hp, **f32)
-        St = torch.empty(T, 5, depth, E1, Hp, **f32)
+        compact = compact_enabled()
         zero = torch.zeros(E1, Hp, **f32)
+        if compact:
+            # level-wide state, updated in place step by step; the stashes live per step at the step's own row count
+            Hg, Cg = zero, (torch.zeros(E1, Hp, **f32) if lstm else None)
+            xrows = plan.gate_rows_device(G)
+            Xflat = X.view(G * E1, Hp)
+            Hs, Cs, Qs, St, Xl = [], [], [], [], []
+        else:
+            Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
+            Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
+            Qs = torch.empty(T, depth, E1, Hp, **f32)
+            St = torch.empty(T, 5, depth, E1, Hp, **f32)
         ns_tot, n_inst = plan.aoff[-1], plan.ioff[-1]
         NODE = torch.empty(ns_tot, Hp, **f32)
         NEI = torch.empty(ns_tot, Hp, **f32)
@@ -190,26 +256,56 @@ class _AtomDecode(torch.autograd.Function):
         wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H) if lstm else lib.ggpm_gru_pack_floats(H)), **f32)
         s = F_._stream()
         frz = D["frozen"]
+        frz_loc = D["frozen_loc"].data_ptr()
         ldF, ldwo = F_._ld(fn_all), Wout.stride(0)
         h_prev, c_prev = zero, zero
+
+        def sparse_forward(n, h_in, c_in, fz, x, rp, col, hs, cs, qs, st):
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_forward(
+                    n, H, depth, P(h_in), P(c_in), fz, P(x[0]), P(x[1]), P(x[2]), P(x[3]), P(Wi[:, I:]),
+                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
+                    rp, col, P(hs), P(cs), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s),
+                    "lstm_sparse_forward")
+            else:
+                _lib.check(lib.ggpm_gru_sparse_forward(
+                    n, H, depth, P(h_in), fz, P(x[0]), P(x[1]), P(x[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
+                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), rp, col, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]),
+                    P(st[3]), P(st[4]), P(wpack), 1, s), "gru_sparse_forward")
+
         for t in range(T):
             a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
             ns, ni = a1 - a0, i1 - i0
-            st = St[t]
-            if lstm:
-                _lib.check(lib.ggpm_lstm_sparse_forward(
-                    E1, H, depth, P(h_prev), P(c_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(X[3]), P(Wi[:, I:]),
-                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
-                    _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), P(Hs[t]), P(Cs[t]), P(Qs[t]), P(st[0]), P(st[1]),
-                    P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s), "lstm_sparse_forward")
-                c_prev = Cs[t, depth]
+            if compact:
+                n = plan.nloc[t]
+                rows = _vp(ptr[("rows", t)])
+                h_in = torch.empty(n, Hp, **f32)
+                _lib.check(lib.ggpm_gather_rows(P(Hg), Hp, rows, n, Hp, P(h_in), Hp, 0, 0, s), "gather_rows")
+                c_in = None
+                if lstm:
+                    c_in = torch.empty(n, Hp, **f32)
+                    _lib.check(lib.ggpm_gather_rows(P(Cg), Hp, rows, n, Hp, P(c_in), Hp, 0, 0, s), "gather_rows")
+                x = torch.empty(G, n, Hp, **f32)
+                _lib.check(lib.ggpm_gather_rows(P(Xflat), Hp, _vp(xrows[t]), G * n, Hp, P(x), Hp, 0, 0, s), "gather_rows")
+                hs, qs, st = torch.empty(depth + 1, n, Hp, **f32), torch.empty(depth, n, Hp, **f32), \
+                    torch.empty(5, depth, n, Hp, **f32)
+                cs = torch.empty(depth + 1, n, Hp, **f32) if lstm else None
+                sparse_forward(n, h_in, c_in, _vp(frz_loc + plan.floc_off[t]), x, _vp(ptr[("lpred_rp", t)]),
+                               _vp(ptr[("lpred_col", t)]), hs, cs, qs, st)
+                live = _vp(ptr[("live", t)])
+                _lib.check(lib.ggpm_scatter_rows(P(hs[depth]), Hp, live, n, Hp, P(Hg), Hp, 0, s), "scatter_rows")
+                if lstm:
+                    _lib.check(lib.ggpm_scatter_rows(P(cs[depth]), Hp, live, n, Hp, P(Cg), Hp, 0, s), "scatter_rows")
+                    Cs.append(cs)
+                Hs.append(hs); Qs.append(qs); St.append(st)
+                Xl.append(x[3] if lstm else x[1])           # the backward reads the forget / reset gate's input only
+                h_prev = Hg
             else:
-                _lib.check(lib.ggpm_gru_sparse_forward(
-                    E1, H, depth, P(h_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
-                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
-                    P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s),
-                    "gru_sparse_forward")
-            h_prev = Hs[t, depth]
+                sparse_forward(E1, h_prev, c_prev, P(frz[t]), X, _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
+                               Hs[t], Cs[t] if lstm else None, Qs[t], St[t])
+                if lstm:
+                    c_prev = Cs[t, depth]
+                h_prev = Hs[t, depth]
             nei, node = NEI[a0:a1], NODE[a0:a1]
             _lib.check(lib.ggpm_segment_sum(P(h_prev), Hp, _vp(ptr[("agr_rp", t)]), _vp(ptr[("agr_col", t)]), ns, H,
                                             P(nei), Hp, 0, Hp, s), "segment_sum")
@@ -222,8 +318,11 @@ class _AtomDecode(torch.autograd.Function):
             for j, (row0, n) in enumerate(plan.step_cands[t]):
                 _lib.check(lib.ggpm_gather_rows(P(node), Hp, _vp(ptr[("cand_pos", t, j)]), n, H, P(cand[row0:row0 + n]),
                                                 Hp, 0, Hp, s), "gather_rows")
-        ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
-        ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
+        ctx.plan, ctx.meta, ctx.drop, ctx.compact = plan, (cell, depth, H, Fdim, I), drop, compact
+        if compact:
+            ctx.save_for_backward(fn_all, hmess, NODE, NEI, *params, *Hs, *Qs, *St, *Xl, *Cs)
+        else:
+            ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
         ctx.keep = D
         return pooled, cand
 
@@ -233,14 +332,23 @@ class _AtomDecode(torch.autograd.Function):
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
         lstm = cell == "LSTM"
         sv = list(ctx.saved_tensors)
-        fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
-        Cs = sv[8] if lstm else None
-        params = sv[9:] if lstm else sv[8:]
+        compact, T = ctx.compact, plan.T
+        if compact:
+            fn_all, hmess, NODE, NEI = sv[:4]
+            npar = 10 if lstm else 9
+            params = sv[4:4 + npar]
+            rest = sv[4 + npar:]
+            Hs, Qs, St, Xl = rest[:T], rest[T:2 * T], rest[2 * T:3 * T], rest[3 * T:4 * T]
+            Cs = rest[4 * T:5 * T] if lstm else None
+        else:
+            fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
+            Cs = sv[8] if lstm else None
+            params = sv[9:] if lstm else sv[8:]
         D = ctx.keep
         ptr, P = D["ptr"], F_._p
         dev = hmess.device
         Hp = F_.padded_hidden(H)
-        E1, T = plan.E1, plan.T
+        E1 = plan.E1
         f32 = dict(dtype=torch.float32, device=dev)
         G = 4 if lstm else 3
         if lstm:
@@ -254,15 +362,40 @@ class _AtomDecode(torch.autograd.Function):
         ns_tot = plan.aoff[-1]
         DPRE = torch.empty(ns_tot, Hp, **f32)
         dX_tot = torch.zeros(G, E1, Hp, **f32)
-        dX = torch.empty(G, E1, Hp, **f32)
-        dH, dH2 = torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)
-        dC, dC2 = (torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)) if lstm else (None, None)
+        dH = torch.zeros(E1, Hp, **f32)
+        dC = torch.zeros(E1, Hp, **f32) if lstm else None
+        if compact:
+            nmax = max(plan.nloc)
+            xrows = plan.gate_rows_device(G)
+            dXflat = dX_tot.view(G * E1, Hp)
+            frz_loc = D["frozen_loc"].data_ptr()
+        else:
+            nmax = E1
+            dX = torch.empty(G, E1, Hp, **f32)
+            dH2 = torch.empty(E1, Hp, **f32)
+            dC2 = torch.empty(E1, Hp, **f32) if lstm else None
         nh = 4 if lstm else 3                                   # hidden-half weight gradients (+ GRU: b_u)
         acc = [torch.zeros(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.zeros(H, **f32)])
         tmp = [torch.empty(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.empty(H, **f32)])
-        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(E1, H, depth))
+        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         ldwo = Wout.stride(0)
+
+        def sparse_backward(n, fz, xg, rp, col, rpT, colT, hs, cs, qs, st, dhd, dcd, dhin, dcin, dx):
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_backward(
+                    n, H, depth, fz, P(xg), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0),
+                    P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), rp, col, rpT, colT, P(hs), P(cs),
+                    P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dhd), P(dcd), P(dhin), P(dcin), P(dx[0]),
+                    P(dx[1]), P(dx[2]), P(dx[3]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[2]), H, P(tmp[3]), H, P(work),
+                    work.numel() * 4, s), "lstm_sparse_backward")
+            else:
+                _lib.check(lib.ggpm_gru_sparse_backward(
+                    n, H, depth, fz, P(xg), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]),
+                    Wh.stride(0), rp, col, rpT, colT, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]),
+                    P(dhd), P(dhin), P(dx[0]), P(dx[1]), P(dx[2]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[3]), P(tmp[2]), H,
+                    P(work), work.numel() * 4, s), "gru_sparse_backward")
+
         for t in range(T - 1, -1, -1):
             a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
             ns, ni = a1 - a0, i1 - i0
@@ -281,25 +414,33 @@ class _AtomDecode(torch.autograd.Function):
             # d(state after step t) = what step t+1 passed back + the read-out's share
             _lib.check(lib.ggpm_segment_sum(P(d_nei), Hp, _vp(ptr[("agrT_rp", t)]), _vp(ptr[("agrT_col", t)]), E1, H,
                                             P(dH), Hp, 1, 0, s), "segment_sum")
-            st = St[t]
-            if lstm:
-                _lib.check(lib.ggpm_lstm_sparse_backward(
-                    E1, H, depth, P(frz[t]), P(X[3]), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0),
-                    P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), _vp(ptr[("pred_rp", t)]),
-                    _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Cs[t]),
-                    P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH), P(dC), P(dH2), P(dC2), P(dX[0]),
-                    P(dX[1]), P(dX[2]), P(dX[3]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[2]), H, P(tmp[3]), H, P(work),
-                    work.numel() * 4, s), "lstm_sparse_backward")
-                dC, dC2 = dC2, dC
+            if compact:
+                n = plan.nloc[t]
+                rows = _vp(ptr[("rows", t)])
+                dhd, dhin = torch.empty(n, Hp, **f32), torch.empty(n, Hp, **f32)
+                _lib.check(lib.ggpm_gather_rows(P(dH), Hp, rows, n, Hp, P(dhd), Hp, 0, 0, s), "gather_rows")
+                dcd = dcin = None
+                if lstm:
+                    dcd, dcin = torch.empty(n, Hp, **f32), torch.empty(n, Hp, **f32)
+                    _lib.check(lib.ggpm_gather_rows(P(dC), Hp, rows, n, Hp, P(dcd), Hp, 0, 0, s), "gather_rows")
+                dx = torch.empty(G, n, Hp, **f32)
+                sparse_backward(n, _vp(frz_loc + plan.floc_off[t]), Xl[t], _vp(ptr[("lpred_rp", t)]),
+                                _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]), Hs[t],
+                                Cs[t] if lstm else None, Qs[t], St[t], dhd, dcd, dhin, dcin, dx)
+                # d(state before step t): the frozen rows' carried gradient, zero on the recomputed rows
+                _lib.check(lib.ggpm_scatter_rows(P(dhin), Hp, rows, n, Hp, P(dH), Hp, 0, s), "scatter_rows")
+                if lstm:
+                    _lib.check(lib.ggpm_scatter_rows(P(dcin), Hp, rows, n, Hp, P(dC), Hp, 0, s), "scatter_rows")
+                _lib.check(lib.ggpm_scatter_rows(P(dx), Hp, _vp(xrows[t]), G * n, Hp, P(dXflat), Hp, 1, s), "scatter_rows")
+                torch._foreach_add_(acc, tmp)
             else:
-                _lib.check(lib.ggpm_gru_sparse_backward(
-                    E1, H, depth, P(frz[t]), P(X[1]), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]),
-                    Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]),
-                    _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH),
-                    P(dH2), P(dX[0]), P(dX[1]), P(dX[2]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[3]), P(tmp[2]), H, P(work),
-                    work.numel() * 4, s), "gru_sparse_backward")
-            dH, dH2 = dH2, dH
-            torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
+                sparse_backward(E1, P(frz[t]), X[3] if lstm else X[1], _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
+                                _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), Hs[t], Cs[t] if lstm else None, Qs[t],
+                                St[t], dH, dC, dH2, dC2, dX)
+                if lstm:
+                    dC, dC2 = dC2, dC
+                dH, dH2 = dH2, dH
+                torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
         # ---- parameter gradients, once
         x_ld = F_._ld(hmess)
 

@@ -48,6 +48,21 @@ __global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ t
     }
 }
 
+// dst[idx[r]] (+)= src[r]: the write side of gather_rows_k for UNIQUE indices (no atomics), one wave per row.
+__global__ void __launch_bounds__(256) scatter_rows_k(const float* __restrict__ src, int ld_src,
+                                                      const int32_t* __restrict__ idx, int rows, int width,
+                                                      float* __restrict__ dst, int ld_dst, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int id = idx[r];
+    if (id < 0) return;
+    const float* s = src + (size_t)r * ld_src;
+    float* d = dst + (size_t)id * ld_dst;
+    if (accumulate) for (int c = lane; c < width; c += 64) d[c] += s[c];
+    else for (int c = lane; c < width; c += 64) d[c] = s[c];
+}
+
 __global__ void onehot_k(const int32_t* __restrict__ idx, int rows, int classes, float* __restrict__ out,
                          int ld_out, int col_off, int zero_to) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,6 +116,16 @@ extern "C" int ggpm_gather_rows(const float* table, int ld_table, const int32_t*
     if (!table || !idx || !out || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
     gather_rows_k<<<ggpm_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(table, ld_table, idx, rows, width, out,
                                                                           ld_out, col_off, zero_to);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_scatter_rows(const float* src, int ld_src, const int32_t* idx, int rows, int width, float* dst,
+                                 int ld_dst, int accumulate, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!src || !idx || !dst || rows <= 0 || width <= 0) return GGPM_ERR_ARG;
+    scatter_rows_k<<<ggpm_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, rows, width, dst, ld_dst,
+                                                                           accumulate);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

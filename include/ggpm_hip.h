@@ -121,6 +121,11 @@ int ggpm_segment_sum(const float* src, int ld_src, const int32_t* rowptr, const 
  * = nn.Embedding / index_select of ggpm/encoder.py:98,103,111,114 */
 int ggpm_gather_rows(const float* table, int ld_table, const int32_t* idx, int rows, int width,
                      float* out, int ld_out, int col_off, int zero_to, ggpm_stream_t stream);
+/* dst[idx[r], 0:width] = src[r, 0:width] (accumulate != 0: +=); rows with idx < 0 are skipped.  The indices must be
+ * UNIQUE (plain stores).  The write side of index_select for the compact row sets of the teacher-forced atom-level
+ * decode (ggpm/encoder.py:165-179 run on the rows a step touches; ggpm_amd/atom_decode.py). */
+int ggpm_scatter_rows(const float* src, int ld_src, const int32_t* idx, int rows, int width, float* dst, int ld_dst,
+                      int accumulate, ggpm_stream_t stream);
 /* out[r, col_off + idx[r]] = 1, the other `classes` columns of that block 0: the one-hot tables
  * E_a/E_b/E_apos/E_pos of ggpm/encoder.py:74-77,121-125,104-105. */
 /* nn.Dropout in training mode (ggpm/encoder.py:15-19, 52-72), in place on x[rows, cols] (leading dimension ld):

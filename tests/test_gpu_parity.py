@@ -902,7 +902,7 @@ def _vae_names():
     return vae_case_names()
 
 
-@pytest.mark.parametrize("mode", ["batched", "levels", "stepwise"])
+@pytest.mark.parametrize("mode", ["batched", "batched_full", "levels", "stepwise"])
 @pytest.mark.parametrize("name", _vae_names())
 def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     """The full VAE training step -- HierPropertyVAE.forward (ggpm/property_vae.py:47-62): encoder, rsample, the
@@ -913,7 +913,8 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     over the decode-time DAG of their messages, the atom level stepping through the incremental encoder) and ``batched``
     (default: additionally the atom level's step loop as one autograd node on host-built index tables, atom_decode.py)."""
     monkeypatch.setenv("GGPM_DECODER_BATCHED", "0" if mode == "stepwise" else "1")
-    monkeypatch.setenv("GGPM_ATOM_DECODE", "1" if mode == "batched" else "0")
+    monkeypatch.setenv("GGPM_ATOM_DECODE", "1" if mode.startswith("batched") else "0")
+    monkeypatch.setenv("GGPM_ATOM_COMPACT", "0" if mode == "batched_full" else "1")     # compact row sets per decode step
     from golden_utils import VaeGolden
     from ggpm_amd import synth
     from ggpm_amd.decoder import DecodeSchedule
@@ -936,6 +937,33 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     for k, v in model.named_parameters():
         grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
         g.check_grad(k, grad, rel=TOL)
+
+
+def test_scatter_rows_inverts_gather_rows():
+    """ggpm_scatter_rows (unique indices, -1 = skip; store and accumulate) against numpy; with ggpm_gather_rows it is
+    the round trip of the compact decode steps."""
+    import ctypes
+    from ggpm_amd import _lib, functional as F_
+    dev = _dev()
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for rows, n, width, ld in [(1, 1, 4, 4), (40, 17, 300, 304), (900, 333, 62, 64), (50, 50, 7, 9)]:
+        idx = rng.permutation(rows)[:n].astype(np.int32)
+        idx[rng.random(n) < 0.2] = -1
+        src = rng.standard_normal((n, ld)).astype(np.float32)
+        base = rng.standard_normal((rows, ld)).astype(np.float32)
+        for accumulate in (0, 1):
+            dst = torch.from_numpy(base.copy()).to(dev)
+            t_src, t_idx = torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev)
+            _lib.check(lib.ggpm_scatter_rows(F_._p(t_src), ld, F_._p(t_idx), n, width, F_._p(dst), ld, accumulate,
+                                             F_._stream()), "scatter_rows")
+            want = base.copy()
+            ok = idx >= 0
+            if accumulate:
+                want[idx[ok], :width] += src[ok, :width]
+            else:
+                want[idx[ok], :width] = src[ok, :width]
+            assert np.array_equal(dst.cpu().numpy(), want)
 
 
 def test_rsample_with_perturbation_matches_torch_formula():

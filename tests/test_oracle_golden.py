@@ -289,6 +289,42 @@ def test_decode_schedule_from_networkx_batch():
         assert [(c.tolist(), i, n, bi) for c, i, n, bi in x["assm"]] == [(c.tolist(), i, n, bi) for c, i, n, bi in y["assm"]]
 
 
+def test_atom_plan_compact_row_sets_match_the_level_wide_tables():
+    """AtomPlan's per-step compact row sets (host logic of ggpm_amd/atom_decode.py): mapped back through ``rows`` the local
+    predecessor / successor CSRs and the local frozen mask are exactly the level-wide ones restricted to the step."""
+    from ggpm_amd.decoder import DecodeSchedule
+    specs = synth.random_batch(77, 6, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120)
+    tensors = synth.tensorize(specs)
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    E1 = tensors[1][1].shape[0]
+    plan = sch.atom_plan(tensors[1][0].shape[0], E1)
+
+    def arr(key):
+        off, n = plan.where[key]
+        return plan.ints[off:off + n].astype(np.int64)
+
+    assert plan.T == len(sch.steps) and len(plan.nloc) == plan.T
+    for t in range(plan.T):
+        rows, n = arr(("rows", t)), plan.nloc[t]
+        assert len(rows) == n and rows[0] == 0 and np.all(np.diff(rows) > 0)
+        fl = plan.frozen_loc[plan.floc_off[t]:plan.floc_off[t] + n]
+        assert np.array_equal(fl, plan.frozen[t][rows])                       # same mask on the rows of the set
+        assert set(np.nonzero(plan.frozen[t] == 0)[0]) <= set(rows.tolist())  # every recomputed row is in the set
+        live = arr(("live", t))
+        assert np.array_equal(live, np.where(fl == 0, rows, -1))
+        for loc, glob in (("lpred", "pred"), ("lsucc", "succ")):
+            rp, col = arr((loc + "_rp", t)), arr((loc + "_col", t))
+            grp, gcol = arr((glob + "_rp", t)), arr((glob + "_col", t))
+            assert len(rp) == n + 1 and len(grp) == E1 + 1
+            for i in range(n):
+                assert rows[col[rp[i]:rp[i + 1]]].tolist() == gcol[grp[rows[i]]:grp[rows[i] + 1]].tolist()
+            inside = np.zeros(E1, dtype=bool)
+            inside[rows] = True
+            assert all(grp[r + 1] == grp[r] for r in np.nonzero(~inside)[0])  # rows outside the set have no entries
+        gr = plan.gate_rows(t, 3)
+        assert np.array_equal(gr, np.concatenate([k * E1 + rows for k in range(3)]))
+
+
 @pytest.mark.parametrize("name", vae_case_names())
 def test_oracle_vae_step_matches_reference(name):
     """oracle/ref_decoder.py (HierPropertyVAE.forward: encoder, rsample, teacher-forced decoder with enum_attach, the
