@@ -50,6 +50,10 @@ SIGNATURES = {
     "ggpm_gru_sparse_forward": (I, [I, I, I, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                      P, I, P, I, P, P, I, P, c_size_t, P]),
+    "ggpm_backward_defer_stash": (None, [P, P, P, P]),
+    "ggpm_weight_grads_stacked_workspace_bytes": (c_size_t, [I, I]),
+    "ggpm_gru_weight_grads_stacked": (I, [I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, c_size_t, P]),
+    "ggpm_lstm_weight_grads_stacked": (I, [I, I, I, P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
     "ggpm_lstm_pack_floats": (c_size_t, [I]),
     "ggpm_lstm_forward": (I, [I, I, I, P, P, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_lstm_backward_workspace_bytes": (c_size_t, [I, I, I]),

@@ -159,10 +159,17 @@ class AtomPlan:
         self.cand_meta = {k: {n: np.asarray(v, dtype=np.int64) for n, v in m.items()} for k, m in cand_meta.items()}
         self.ints = np.concatenate(ints) if ints else np.zeros(0, np.int32)
         self.frozen = frozen
+        # stacked per-step blocks: depth * n rows (stashes) / (depth + 1) * n rows (states), see row_offsets()
         self.frozen_loc = np.ones(self.floc_off[-1], dtype=np.uint8)
         for t, fl in enumerate(frozen_loc):
             self.frozen_loc[self.floc_off[t]:self.floc_off[t] + len(fl)] = fl
         self._dev = None
+
+    def row_offsets(self, depth: int):
+        """-> (offsets of the steps' [depth, n] blocks, offsets of their [depth + 1, n] blocks), each of length T + 1."""
+        n = np.asarray(self.nloc, dtype=np.int64)
+        return (np.concatenate([[0], np.cumsum(depth * n)]).tolist(),
+                np.concatenate([[0], np.cumsum((depth + 1) * n)]).tolist())
 
     def gate_rows(self, t: int, gates: int) -> np.ndarray:
         """Rows of the step's compact set inside the stacked [gates * E1, Hp] gate-input matrix."""
@@ -242,7 +249,13 @@ class _AtomDecode(torch.autograd.Function):
             Hg, Cg = zero, (torch.zeros(E1, Hp, **f32) if lstm else None)
             xrows = plan.gate_rows_device(G)
             Xflat = X.view(G * E1, Hp)
-            Hs, Cs, Qs, St, Xl = [], [], [], [], []
+            # the steps' stashes stacked row-wise, one buffer per kind: the backward contracts them in one go
+            roff, qoff = plan.row_offsets(depth)
+            Hs_all = torch.empty(qoff[-1], Hp, **f32)
+            Cs_all = torch.empty(qoff[-1], Hp, **f32) if lstm else None
+            Qs_all = torch.empty(roff[-1], Hp, **f32)
+            St_all = torch.empty(5, roff[-1], Hp, **f32)
+            Xl = []
         else:
             Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
             Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
@@ -287,17 +300,16 @@ class _AtomDecode(torch.autograd.Function):
                     _lib.check(lib.ggpm_gather_rows(P(Cg), Hp, rows, n, Hp, P(c_in), Hp, 0, 0, s), "gather_rows")
                 x = torch.empty(G, n, Hp, **f32)
                 _lib.check(lib.ggpm_gather_rows(P(Xflat), Hp, _vp(xrows[t]), G * n, Hp, P(x), Hp, 0, 0, s), "gather_rows")
-                hs, qs, st = torch.empty(depth + 1, n, Hp, **f32), torch.empty(depth, n, Hp, **f32), \
-                    torch.empty(5, depth, n, Hp, **f32)
-                cs = torch.empty(depth + 1, n, Hp, **f32) if lstm else None
+                hs = Hs_all[qoff[t]:qoff[t + 1]].view(depth + 1, n, Hp)
+                cs = Cs_all[qoff[t]:qoff[t + 1]].view(depth + 1, n, Hp) if lstm else None
+                qs = Qs_all[roff[t]:roff[t + 1]].view(depth, n, Hp)
+                st = St_all[:, roff[t]:roff[t + 1]].view(5, depth, n, Hp)
                 sparse_forward(n, h_in, c_in, _vp(frz_loc + plan.floc_off[t]), x, _vp(ptr[("lpred_rp", t)]),
                                _vp(ptr[("lpred_col", t)]), hs, cs, qs, st)
                 live = _vp(ptr[("live", t)])
                 _lib.check(lib.ggpm_scatter_rows(P(hs[depth]), Hp, live, n, Hp, P(Hg), Hp, 0, s), "scatter_rows")
                 if lstm:
                     _lib.check(lib.ggpm_scatter_rows(P(cs[depth]), Hp, live, n, Hp, P(Cg), Hp, 0, s), "scatter_rows")
-                    Cs.append(cs)
-                Hs.append(hs); Qs.append(qs); St.append(st)
                 Xl.append(x[3] if lstm else x[1])           # the backward reads the forget / reset gate's input only
                 h_prev = Hg
             else:
@@ -320,7 +332,7 @@ class _AtomDecode(torch.autograd.Function):
                                                 Hp, 0, Hp, s), "gather_rows")
         ctx.plan, ctx.meta, ctx.drop, ctx.compact = plan, (cell, depth, H, Fdim, I), drop, compact
         if compact:
-            ctx.save_for_backward(fn_all, hmess, NODE, NEI, *params, *Hs, *Qs, *St, *Xl, *Cs)
+            ctx.save_for_backward(fn_all, hmess, NODE, NEI, Hs_all, Qs_all, St_all, *([Cs_all] if lstm else []), *params, *Xl)
         else:
             ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
         ctx.keep = D
@@ -334,12 +346,11 @@ class _AtomDecode(torch.autograd.Function):
         sv = list(ctx.saved_tensors)
         compact, T = ctx.compact, plan.T
         if compact:
-            fn_all, hmess, NODE, NEI = sv[:4]
+            fn_all, hmess, NODE, NEI, Hs_all, Qs_all, St_all = sv[:7]
+            Cs_all = sv[7] if lstm else None
+            k0 = 8 if lstm else 7
             npar = 10 if lstm else 9
-            params = sv[4:4 + npar]
-            rest = sv[4 + npar:]
-            Hs, Qs, St, Xl = rest[:T], rest[T:2 * T], rest[2 * T:3 * T], rest[3 * T:4 * T]
-            Cs = rest[4 * T:5 * T] if lstm else None
+            params, Xl = sv[k0:k0 + npar], sv[k0 + npar:]
         else:
             fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
             Cs = sv[8] if lstm else None
@@ -369,6 +380,13 @@ class _AtomDecode(torch.autograd.Function):
             xrows = plan.gate_rows_device(G)
             dXflat = dX_tot.view(G * E1, Hp)
             frz_loc = D["frozen_loc"].data_ptr()
+            roff, qoff = plan.row_offsets(depth)
+            # gate-gradient stashes of all steps, stacked like the forward's (DQ with a zero slot per step at the end so
+            # that it lines up with the depth + 1 state slots): contracted once behind the loop
+            stacked = os.environ.get("GGPM_ATOM_STACKED_WGRADS", "1") != "0"        # (0: contract per step; dev A/B)
+            if stacked:
+                DG_all = torch.empty(3 if lstm else 2, roff[-1], Hp, **f32)
+                DQ_all = torch.zeros(qoff[-1], Hp, **f32)
         else:
             nmax = E1
             dX = torch.empty(G, E1, Hp, **f32)
@@ -424,15 +442,20 @@ class _AtomDecode(torch.autograd.Function):
                     dcd, dcin = torch.empty(n, Hp, **f32), torch.empty(n, Hp, **f32)
                     _lib.check(lib.ggpm_gather_rows(P(dC), Hp, rows, n, Hp, P(dcd), Hp, 0, 0, s), "gather_rows")
                 dx = torch.empty(G, n, Hp, **f32)
+                if stacked:
+                    dg = [DG_all[k, roff[t]:roff[t + 1]] for k in range(DG_all.shape[0])] + [DQ_all[qoff[t]:qoff[t + 1]]]
+                    lib.ggpm_backward_defer_stash(P(dg[0]), P(dg[1]), P(dg[2]), P(dg[3]) if lstm else None)
                 sparse_backward(n, _vp(frz_loc + plan.floc_off[t]), Xl[t], _vp(ptr[("lpred_rp", t)]),
-                                _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]), Hs[t],
-                                Cs[t] if lstm else None, Qs[t], St[t], dhd, dcd, dhin, dcin, dx)
+                                _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]),
+                                Hs_all[qoff[t]:qoff[t + 1]], Cs_all[qoff[t]:qoff[t + 1]] if lstm else None,
+                                Qs_all[roff[t]:roff[t + 1]], St_all[:, roff[t]:roff[t + 1]], dhd, dcd, dhin, dcin, dx)
                 # d(state before step t): the frozen rows' carried gradient, zero on the recomputed rows
                 _lib.check(lib.ggpm_scatter_rows(P(dhin), Hp, rows, n, Hp, P(dH), Hp, 0, s), "scatter_rows")
                 if lstm:
                     _lib.check(lib.ggpm_scatter_rows(P(dcin), Hp, rows, n, Hp, P(dC), Hp, 0, s), "scatter_rows")
                 _lib.check(lib.ggpm_scatter_rows(P(dx), Hp, _vp(xrows[t]), G * n, Hp, P(dXflat), Hp, 1, s), "scatter_rows")
-                torch._foreach_add_(acc, tmp)
+                if not stacked:
+                    torch._foreach_add_(acc, tmp)
             else:
                 sparse_backward(E1, P(frz[t]), X[3] if lstm else X[1], _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
                                 _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), Hs[t], Cs[t] if lstm else None, Qs[t],
@@ -442,6 +465,18 @@ class _AtomDecode(torch.autograd.Function):
                 dH, dH2 = dH2, dH
                 torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
         # ---- parameter gradients, once
+        if compact and stacked:
+            R, RQ = roff[-1], qoff[-1]
+            wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
+            ws = torch.empty((wsb + 3) // 4, **f32)
+            if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h
+                _lib.check(lib.ggpm_lstm_weight_grads_stacked(
+                    R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H,
+                    P(acc[1]), H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s), "lstm_weight_grads_stacked")
+            else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
+                _lib.check(lib.ggpm_gru_weight_grads_stacked(
+                    R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H,
+                    P(acc[1]), H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s), "gru_weight_grads_stacked")
         x_ld = F_._ld(hmess)
 
         def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]

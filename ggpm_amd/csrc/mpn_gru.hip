@@ -678,6 +678,17 @@ void ggpm_backward_lo_depth(int lo) { g_bwd_lo = lo; }
 int ggpm_take_backward_lo() { const int v = g_bwd_lo; g_bwd_lo = 0; return v; }
 void ggpm_wgrad_lo_depth(int lo) { g_wgrad_lo = lo; }
 int ggpm_take_wgrad_lo() { const int v = g_wgrad_lo; g_wgrad_lo = 0; return v; }
+namespace { thread_local float* g_defer[4] = {nullptr, nullptr, nullptr, nullptr}; thread_local bool g_defer_set = false; }
+extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3) {
+    g_defer[0] = s0; g_defer[1] = s1; g_defer[2] = s2; g_defer[3] = s3;
+    g_defer_set = s0 != nullptr;
+}
+bool ggpm_take_defer_stash(float* (&out)[4]) {
+    const bool v = g_defer_set;
+    for (int i = 0; i < 4; ++i) { out[i] = g_defer[i]; g_defer[i] = nullptr; }
+    g_defer_set = false;
+    return v;
+}
 
 static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
                             const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
@@ -842,6 +853,14 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
+    {       // deferred weight gradients (ggpm_backward_defer_stash): the stashes go to the caller's stacked buffers
+        float* ext[4];
+        if (ggpm_take_defer_stash(ext)) {
+            if (!frozen || !ext[1] || !ext[2]) return GGPM_ERR_ARG;
+            DMP = ext[0]; DZP = ext[1]; DQ = ext[2];
+            weight_grads = 0;
+        }
+    }
 
     {
         GgpmPackArgs pk = {};
@@ -1050,6 +1069,38 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
     }
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows) {
+    const size_t Hp = (size_t)ggpm_padded_hidden(H);
+    return 256 * Hp * sizeof(float) + ggpm_gemm_workspace_bytes(H, H, rows) + 256;
+}
+
+// The hidden-half weight gradients of MANY sparse backward calls at once: their stashes stacked row-wise (one block per
+// call, the same block order in every buffer), see ggpm_backward_defer_stash.
+extern "C" int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const float* DMP, const float* Gs,
+                                             const float* DZP, const float* Ss, const float* DQ, const float* Hs,
+                                             float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
+                                             int ld_dwh, float* work, size_t work_bytes, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (rows <= 0 || rows_q <= 0 || H <= 0 || !DMP || !Gs || !DZP || !Ss || !DQ || !Hs || !dWz_h || !dUr || !dbu ||
+        !dWh_h || !work)
+        return GGPM_ERR_ARG;
+    if (work_bytes < ggpm_weight_grads_stacked_workspace_bytes(H, rows > rows_q ? rows : rows_q)) return GGPM_ERR_WORKSPACE;
+    const int Hp = ggpm_padded_hidden(H);
+    float* csws = work;
+    float* skws = work + (size_t)256 * Hp;
+    const size_t skbytes = work_bytes - (size_t)256 * Hp * sizeof(float);
+    const ggpm_gemm_problem gp[3] = {{DMP, Hp, Gs, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                                     {DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                                     {DQ, Hp, Hs, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0}};
+    const int Ks[3] = {rows, rows, rows_q};
+    int rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
+    if (rc) return rc;
+    rc = ggpm_colsum(DQ, Hp, rows_q, H, dbu, csws, stream);
+    if (rc) return rc;
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

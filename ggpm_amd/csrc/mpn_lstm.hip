@@ -706,6 +706,15 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep; w += 4 * HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
+    {       // deferred weight gradients (ggpm_backward_defer_stash): the stashes go to the caller's stacked buffers
+        float* ext[4];
+        if (ggpm_take_defer_stash(ext)) {
+            if (!frozen || !ext[1] || !ext[2] || !ext[3]) return GGPM_ERR_ARG;
+            DI = ext[0]; DO = ext[1]; DU = ext[2]; DQ = ext[3];
+            weight_grads = 0;
+        }
+    }
+    (void)skws; (void)skbytes;
 
     {
         GgpmPackArgs pk = {};
@@ -837,6 +846,31 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+// The hidden-half weight gradients of MANY sparse backward calls at once (see ggpm_gru_weight_grads_stacked).
+extern "C" int ggpm_lstm_weight_grads_stacked(int rows, int rows_q, int H, const float* DI, const float* DO,
+                                              const float* DU, const float* Ss, const float* DQ, const float* Hs,
+                                              float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu,
+                                              float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
+                                              ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (rows <= 0 || rows_q <= 0 || H <= 0 || !DI || !DO || !DU || !Ss || !DQ || !Hs || !dWi_h || !dWo_h || !dWu_h ||
+        !dWf_h || !work)
+        return GGPM_ERR_ARG;
+    if (work_bytes < ggpm_weight_grads_stacked_workspace_bytes(H, rows > rows_q ? rows : rows_q)) return GGPM_ERR_WORKSPACE;
+    const int Hp = ggpm_padded_hidden(H);
+    float* skws = work + (size_t)256 * Hp;
+    const size_t skbytes = work_bytes - (size_t)256 * Hp * sizeof(float);
+    const ggpm_gemm_problem gp[4] = {{DI, Hp, Ss, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                                     {DO, Hp, Ss, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                                     {DU, Hp, Ss, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                                     {DQ, Hp, Hs, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0}};
+    const int Ks[4] = {rows, rows, rows, rows_q};
+    const int rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream);
+    if (rc) return rc;
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

@@ -270,6 +270,29 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
                               float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work, size_t work_bytes,
                               ggpm_stream_t stream);
 
+/* Deferred hidden-half weight gradients for a SEQUENCE of sparse backward calls (the decode steps of one batch,
+ * ggpm/decoder.py:201-222 -> ggpm/encoder.py:165-179 once per step; ggpm_amd/atom_decode.py): every step contracts a few
+ * hundred rows against the same four H x H matrices, so instead of three or four small contractions per step the
+ * gate-gradient stashes of all steps are kept, stacked row-wise, and contracted ONCE.
+ *   ggpm_backward_defer_stash(s0, s1, s2, s3): the NEXT ggpm_gru_sparse_backward / ggpm_lstm_sparse_backward call of this
+ *   thread writes its stashes to caller memory and leaves dW*_h / dUr / dbu untouched.  GRU: s0 = DMP, s1 = DZP
+ *   ([depth][E1][Hp] each, pairing with the forward's Gs / Ss), s2 = DQ ([depth][E1][Hp], slot t pairs with Hs slot t; give
+ *   the block depth+1 slots, the last one zero, so that it lines up with Hs), s3 unused.  LSTM: s0..s2 = DI, DO, DU (pair with
+ *   Ss), s3 = DQ (pairs with Hs, as above).  One call consumes the setting.
+ *   ggpm_*_weight_grads_stacked: rows = total stash rows (sum over the calls of depth*E1), rows_q = total rows of the
+ *   DQ / Hs stacks (sum of (depth+1)*E1); every buffer holds the calls' blocks in the same order.  Outputs are
+ *   overwritten.  work: ggpm_weight_grads_stacked_workspace_bytes(H, max(rows, rows_q)). */
+void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
+size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows);
+int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const float* DMP, const float* Gs, const float* DZP,
+                                  const float* Ss, const float* DQ, const float* Hs, float* dWz_h, int ld_dwz, float* dUr,
+                                  int ld_dur, float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
+                                  ggpm_stream_t stream);
+int ggpm_lstm_weight_grads_stacked(int rows, int rows_q, int H, const float* DI, const float* DO, const float* DU,
+                                   const float* Ss, const float* DQ, const float* Hs, float* dWi_h, int ld_dwi,
+                                   float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
+                                   size_t work_bytes, ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ decoder score-head losses
  * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in
  * (ggpm/decoder.py:66-69,143-157,268-271): z[m,:] = logits[m,:] + mask[mask_row[m],:] (mask / mask_row both null for
