@@ -433,7 +433,7 @@ class VaeWorkload:
         return metrics
 
     def measure(self):
-        steps, warm = min(self.a.steps, 10), len(self.items)      # one pass over the pool: every batch shape seen
+        steps, warm = min(self.a.steps, 30), 2 * len(self.items)      # two passes over the pool: every batch shape seen, clocks up
         for i in range(warm):
             m = self.step(i)
         torch.cuda.synchronize()

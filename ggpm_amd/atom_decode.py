@@ -68,6 +68,7 @@ class AtomPlan:
         frozen = np.ones((self.T, n_gmess), dtype=np.uint8)
         frozen_loc: List[np.ndarray] = []                     # compact steps: mask over the step's local rows
         self.nloc, self.floc_off = [], [0]
+        self._raw, self._ct = [], {}                          # per step (rows, mask, incoming-message table, pool table)
         aoff, boff, ioff = P["atom_off"], P["bond_off"], P["inst_off"]
         self.aoff, self.ioff = aoff, ioff
         # candidate atoms of all steps, grouped by atoms-per-candidate k first, then by step: one contiguous block per k
@@ -107,7 +108,6 @@ class AtomPlan:
             self.nloc.append(n)
             self.floc_off.append(self.floc_off[-1] + (n + 15) // 16 * 16)
             put(("rows", t), rows)                             # local -> level row
-            put(("live", t), np.where(fl == 0, rows, -1))      # ... of the recomputed rows only (-1: skip)
             # incoming messages of the step's atoms (rows local to the step) and the transpose (rows = messages)
             atab = P["g_agraph"][aoff[t]:aoff[t + 1]]
             acnt = (atab > 0).sum(axis=1)
@@ -126,6 +126,7 @@ class AtomPlan:
             put(("pool_rp", t), rp); put(("pool_col", t), col)
             rpT, colT = _transpose(np.repeat(np.arange(len(ptab)), pcnt), loc[loc >= 0], len(atoms))
             put(("poolT_rp", t), rpT); put(("poolT_col", t), colT)
+            self._raw.append((rows, fl, atab, loc))
             here = []
             for (cands, icls, nth, _) in st["assm"]:
                 k, n = len(icls), len(cands)
@@ -145,6 +146,7 @@ class AtomPlan:
             base += len(cand_pos[k])
         self.n_cand = base
         kbase = {k: b for k, b, _ in self.cand_blocks}
+        self._cand_pos, self._per_step_cands, self._kbase = cand_pos, per_step_cands, kbase
         self.step_cands = []                                  # per step: [(flat row offset, count)] + transposed scatter
         for t, here in enumerate(per_step_cands):
             segs = [(kbase[k] + start, n) for (k, start, n) in here]
@@ -171,6 +173,80 @@ class AtomPlan:
         return (np.concatenate([[0], np.cumsum(depth * n)]).tolist(),
                 np.concatenate([[0], np.cumsum((depth + 1) * n)]).tolist())
 
+    def compact_tables(self, depth: int, gates: int):
+        """Host tables of the compact form that depend on the iteration count / the number of gates (cached).
+
+        Every step leaves the final states of its n rows in slot ``depth`` of its block of the stacked state buffer.  ``F
+        id`` = foff[t] + i numbers those rows over all steps; ``H id`` is the row of the same state in the stacked
+        [(depth + 1) * n_t]-row blocks.  A message's state at time t is the final state of the last step <= t that
+        recomputed it (zero if none did): that look-up is resolved here, once, so the device never needs a level-wide
+        state -- a step's frozen rows are gathered straight from the earlier steps' blocks (``srcH``) and the read-out of
+        ALL steps (incoming messages -> atoms -> pooled clusters / attachment candidates) is one CSR over the stacked
+        blocks (``agr``), i.e. a handful of launches behind the loop instead of a handful per step."""
+        key = (depth, gates)
+        if key in self._ct:
+            return self._ct[key]
+        T, E1 = self.T, self.E1
+        n = np.asarray(self.nloc, dtype=np.int64)
+        foff = np.concatenate([[0], np.cumsum(n)])
+        Ftot = int(foff[-1])
+        stepof = np.repeat(np.arange(T), n)
+        Hid = (depth + 1) * foff[stepof] + depth * n[stepof] + (np.arange(Ftot) - foff[stepof])
+        last = np.full(E1, -1, dtype=np.int64)
+        tabs, where, fill = [], {}, [0]
+
+        def put(key_, a):
+            a = np.asarray(a, dtype=np.int32).reshape(-1)
+            where[key_] = (fill[0], len(a))
+            fill[0] += len(a)
+            tabs.append(a)
+
+        agr_r, agr_c, pool_r, pool_c = [], [], [], []
+        for t, (rows, fl, atab, loc) in enumerate(self._raw):
+            sf = np.where(fl == 1, last[rows], -1)
+            put(("srcF", t), sf)
+            put(("srcH", t), np.where(sf >= 0, Hid[np.maximum(sf, 0)], -1))
+            live = np.nonzero(fl == 0)[0]
+            last[rows[live]] = foff[t] + live
+            r, c = np.nonzero(atab > 0)
+            f = last[atab[r, c]]
+            agr_r.append(self.aoff[t] + r[f >= 0]); agr_c.append(f[f >= 0])
+            r, c = np.nonzero(loc >= 0)
+            pool_r.append(self.ioff[t] + r); pool_c.append(self.aoff[t] + loc[r, c])
+        cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        agr_r, agr_c, pool_r, pool_c = cat(agr_r), cat(agr_c), cat(pool_r), cat(pool_c)
+        ns_tot, n_inst = int(self.aoff[-1]), int(self.ioff[-1])
+        rp = lambda r_, nrows: np.concatenate([[0], np.cumsum(np.bincount(r_, minlength=nrows))])
+        put("agr_rp", rp(agr_r, ns_tot)); put("agr_col", Hid[agr_c])                 # rows ascend already (step order)
+        a, b = _transpose(agr_r, agr_c, Ftot); put("agrT_rp", a); put("agrT_col", b)
+        put("pool_rp", rp(pool_r, n_inst)); put("pool_col", pool_c)
+        a, b = _transpose(pool_r, pool_c, ns_tot); put("poolT_rp", a); put("poolT_col", b)
+        cidx = np.full(max(self.n_cand, 1), -1, dtype=np.int64)
+        for t, here in enumerate(self._per_step_cands):
+            for (k, start, cnt) in here:
+                pos = np.asarray(self._cand_pos[k][start:start + cnt], dtype=np.int64)
+                cidx[self._kbase[k] + start:self._kbase[k] + start + cnt] = np.where(pos >= 0, self.aoff[t] + pos, -1)
+        put("cand_idx", cidx)
+        ok = np.nonzero(cidx >= 0)[0]
+        a, b = _transpose(ok, cidx[ok], ns_tot); put("candT_rp", a); put("candT_col", b)
+        xrows = np.concatenate([self.gate_rows(t, gates) for t in range(T)]).astype(np.int64)
+        put("xrows", xrows)
+        a, b = _transpose(np.arange(len(xrows)), xrows, gates * E1); put("xT_rp", a); put("xT_col", b)
+        ct = dict(ints=np.concatenate(tabs), where=where, foff=foff.tolist(), Ftot=Ftot, dev={})
+        self._ct[key] = ct
+        return ct
+
+    def compact_device(self, depth: int, gates: int, device):
+        """-> (tables dict, {key: device address}) of compact_tables on ``device`` (uploaded once)."""
+        ct = self.compact_tables(depth, gates)
+        if device not in ct["dev"]:
+            h = torch.from_numpy(ct["ints"])
+            if torch.device(device).type == "cuda":
+                h = h.pin_memory()
+            d = h.to(device, non_blocking=True)
+            ct["dev"][device] = (d, h, {k: d.data_ptr() + 4 * off for k, (off, _) in ct["where"].items()})
+        return ct, ct["dev"][device][2]
+
     def gate_rows(self, t: int, gates: int) -> np.ndarray:
         """Rows of the step's compact set inside the stacked [gates * E1, Hp] gate-input matrix."""
         off, n = self.where[("rows", t)]
@@ -192,22 +268,8 @@ class AtomPlan:
                     for k, m in self.cand_meta.items()}
             for m in meta.values():
                 m["icls"] = m["icls"].to(torch.int32)
-            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta, keep=(hi, hf, hl),
-                             gate_rows={})
+            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta, keep=(hi, hf, hl))
         return self._dev
-
-    def gate_rows_device(self, gates: int):
-        """Per step: device pointer of gate_rows(t, gates) (3 gates for the GRU, 4 for the LSTM); built on first use."""
-        D = self._dev
-        if gates not in D["gate_rows"]:
-            parts = [self.gate_rows(t, gates) for t in range(self.T)]
-            offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
-            h = torch.from_numpy(np.concatenate(parts))
-            if D["ints"].is_cuda:
-                h = h.pin_memory()
-            d = h.to(D["device"], non_blocking=True)
-            D["gate_rows"][gates] = (d, h, [d.data_ptr() + 4 * int(o) for o in offs[:-1]])
-        return D["gate_rows"][gates][2]
 
 
 def compact_enabled() -> bool:
@@ -219,7 +281,8 @@ def _vp(addr: int) -> ctypes.c_void_p:
 
 
 class _AtomDecode(torch.autograd.Function):
-    """(pooled cluster vectors of all visits [n_inst, Hp], attachment-candidate atom vectors [n_cand, Hp])."""
+    """(pooled cluster vectors of all visits [n_inst, Hp], attachment-candidate atom vectors [n_cand, Hp]) -- the
+    full-level form: every step runs over all E1 rows of the level with a frozen mask (GGPM_ATOM_COMPACT=0)."""
 
     @staticmethod
     def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, *params):
@@ -242,25 +305,11 @@ class _AtomDecode(torch.autograd.Function):
         X = torch.empty(G, E1, Hp, **f32)
         for k, (W, b) in enumerate(gates):
             F_.gemm(0, 1, E1, H, I, hmess, F_._ld(hmess), W, W.stride(0), X[k], Hp, Hp, bias=b)
-        compact = compact_enabled()
+        Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
+        Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
+        Qs = torch.empty(T, depth, E1, Hp, **f32)
+        St = torch.empty(T, 5, depth, E1, Hp, **f32)
         zero = torch.zeros(E1, Hp, **f32)
-        if compact:
-            # level-wide state, updated in place step by step; the stashes live per step at the step's own row count
-            Hg, Cg = zero, (torch.zeros(E1, Hp, **f32) if lstm else None)
-            xrows = plan.gate_rows_device(G)
-            Xflat = X.view(G * E1, Hp)
-            # the steps' stashes stacked row-wise, one buffer per kind: the backward contracts them in one go
-            roff, qoff = plan.row_offsets(depth)
-            Hs_all = torch.empty(qoff[-1], Hp, **f32)
-            Cs_all = torch.empty(qoff[-1], Hp, **f32) if lstm else None
-            Qs_all = torch.empty(roff[-1], Hp, **f32)
-            St_all = torch.empty(5, roff[-1], Hp, **f32)
-            Xl = []
-        else:
-            Hs = torch.empty(T, depth + 1, E1, Hp, **f32)
-            Cs = torch.empty(T, depth + 1, E1, Hp, **f32) if lstm else None
-            Qs = torch.empty(T, depth, E1, Hp, **f32)
-            St = torch.empty(T, 5, depth, E1, Hp, **f32)
         ns_tot, n_inst = plan.aoff[-1], plan.ioff[-1]
         NODE = torch.empty(ns_tot, Hp, **f32)
         NEI = torch.empty(ns_tot, Hp, **f32)
@@ -269,55 +318,26 @@ class _AtomDecode(torch.autograd.Function):
         wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H) if lstm else lib.ggpm_gru_pack_floats(H)), **f32)
         s = F_._stream()
         frz = D["frozen"]
-        frz_loc = D["frozen_loc"].data_ptr()
         ldF, ldwo = F_._ld(fn_all), Wout.stride(0)
         h_prev, c_prev = zero, zero
-
-        def sparse_forward(n, h_in, c_in, fz, x, rp, col, hs, cs, qs, st):
-            if lstm:
-                _lib.check(lib.ggpm_lstm_sparse_forward(
-                    n, H, depth, P(h_in), P(c_in), fz, P(x[0]), P(x[1]), P(x[2]), P(x[3]), P(Wi[:, I:]),
-                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
-                    rp, col, P(hs), P(cs), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s),
-                    "lstm_sparse_forward")
-            else:
-                _lib.check(lib.ggpm_gru_sparse_forward(
-                    n, H, depth, P(h_in), fz, P(x[0]), P(x[1]), P(x[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
-                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), rp, col, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]),
-                    P(st[3]), P(st[4]), P(wpack), 1, s), "gru_sparse_forward")
-
         for t in range(T):
             a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
             ns, ni = a1 - a0, i1 - i0
-            if compact:
-                n = plan.nloc[t]
-                rows = _vp(ptr[("rows", t)])
-                h_in = torch.empty(n, Hp, **f32)
-                _lib.check(lib.ggpm_gather_rows(P(Hg), Hp, rows, n, Hp, P(h_in), Hp, 0, 0, s), "gather_rows")
-                c_in = None
-                if lstm:
-                    c_in = torch.empty(n, Hp, **f32)
-                    _lib.check(lib.ggpm_gather_rows(P(Cg), Hp, rows, n, Hp, P(c_in), Hp, 0, 0, s), "gather_rows")
-                x = torch.empty(G, n, Hp, **f32)
-                _lib.check(lib.ggpm_gather_rows(P(Xflat), Hp, _vp(xrows[t]), G * n, Hp, P(x), Hp, 0, 0, s), "gather_rows")
-                hs = Hs_all[qoff[t]:qoff[t + 1]].view(depth + 1, n, Hp)
-                cs = Cs_all[qoff[t]:qoff[t + 1]].view(depth + 1, n, Hp) if lstm else None
-                qs = Qs_all[roff[t]:roff[t + 1]].view(depth, n, Hp)
-                st = St_all[:, roff[t]:roff[t + 1]].view(5, depth, n, Hp)
-                sparse_forward(n, h_in, c_in, _vp(frz_loc + plan.floc_off[t]), x, _vp(ptr[("lpred_rp", t)]),
-                               _vp(ptr[("lpred_col", t)]), hs, cs, qs, st)
-                live = _vp(ptr[("live", t)])
-                _lib.check(lib.ggpm_scatter_rows(P(hs[depth]), Hp, live, n, Hp, P(Hg), Hp, 0, s), "scatter_rows")
-                if lstm:
-                    _lib.check(lib.ggpm_scatter_rows(P(cs[depth]), Hp, live, n, Hp, P(Cg), Hp, 0, s), "scatter_rows")
-                Xl.append(x[3] if lstm else x[1])           # the backward reads the forget / reset gate's input only
-                h_prev = Hg
+            st = St[t]
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_forward(
+                    E1, H, depth, P(h_prev), P(c_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(X[3]), P(Wi[:, I:]),
+                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
+                    _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), P(Hs[t]), P(Cs[t]), P(Qs[t]), P(st[0]), P(st[1]),
+                    P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s), "lstm_sparse_forward")
+                c_prev = Cs[t, depth]
             else:
-                sparse_forward(E1, h_prev, c_prev, P(frz[t]), X, _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
-                               Hs[t], Cs[t] if lstm else None, Qs[t], St[t])
-                if lstm:
-                    c_prev = Cs[t, depth]
-                h_prev = Hs[t, depth]
+                _lib.check(lib.ggpm_gru_sparse_forward(
+                    E1, H, depth, P(h_prev), P(frz[t]), P(X[0]), P(X[1]), P(X[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
+                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
+                    P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(wpack), 1, s),
+                    "gru_sparse_forward")
+            h_prev = Hs[t, depth]
             nei, node = NEI[a0:a1], NODE[a0:a1]
             _lib.check(lib.ggpm_segment_sum(P(h_prev), Hp, _vp(ptr[("agr_rp", t)]), _vp(ptr[("agr_col", t)]), ns, H,
                                             P(nei), Hp, 0, Hp, s), "segment_sum")
@@ -330,11 +350,8 @@ class _AtomDecode(torch.autograd.Function):
             for j, (row0, n) in enumerate(plan.step_cands[t]):
                 _lib.check(lib.ggpm_gather_rows(P(node), Hp, _vp(ptr[("cand_pos", t, j)]), n, H, P(cand[row0:row0 + n]),
                                                 Hp, 0, Hp, s), "gather_rows")
-        ctx.plan, ctx.meta, ctx.drop, ctx.compact = plan, (cell, depth, H, Fdim, I), drop, compact
-        if compact:
-            ctx.save_for_backward(fn_all, hmess, NODE, NEI, Hs_all, Qs_all, St_all, *([Cs_all] if lstm else []), *params, *Xl)
-        else:
-            ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
+        ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
+        ctx.save_for_backward(fn_all, hmess, X, Hs, Qs, St, NODE, NEI, *([Cs] if lstm else []), *params)
         ctx.keep = D
         return pooled, cand
 
@@ -344,22 +361,14 @@ class _AtomDecode(torch.autograd.Function):
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
         lstm = cell == "LSTM"
         sv = list(ctx.saved_tensors)
-        compact, T = ctx.compact, plan.T
-        if compact:
-            fn_all, hmess, NODE, NEI, Hs_all, Qs_all, St_all = sv[:7]
-            Cs_all = sv[7] if lstm else None
-            k0 = 8 if lstm else 7
-            npar = 10 if lstm else 9
-            params, Xl = sv[k0:k0 + npar], sv[k0 + npar:]
-        else:
-            fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
-            Cs = sv[8] if lstm else None
-            params = sv[9:] if lstm else sv[8:]
+        fn_all, hmess, X, Hs, Qs, St, NODE, NEI = sv[:8]
+        Cs = sv[8] if lstm else None
+        params = sv[9:] if lstm else sv[8:]
         D = ctx.keep
         ptr, P = D["ptr"], F_._p
         dev = hmess.device
         Hp = F_.padded_hidden(H)
-        E1 = plan.E1
+        E1, T = plan.E1, plan.T
         f32 = dict(dtype=torch.float32, device=dev)
         G = 4 if lstm else 3
         if lstm:
@@ -373,47 +382,15 @@ class _AtomDecode(torch.autograd.Function):
         ns_tot = plan.aoff[-1]
         DPRE = torch.empty(ns_tot, Hp, **f32)
         dX_tot = torch.zeros(G, E1, Hp, **f32)
-        dH = torch.zeros(E1, Hp, **f32)
-        dC = torch.zeros(E1, Hp, **f32) if lstm else None
-        if compact:
-            nmax = max(plan.nloc)
-            xrows = plan.gate_rows_device(G)
-            dXflat = dX_tot.view(G * E1, Hp)
-            frz_loc = D["frozen_loc"].data_ptr()
-            roff, qoff = plan.row_offsets(depth)
-            # gate-gradient stashes of all steps, stacked like the forward's (DQ with a zero slot per step at the end so
-            # that it lines up with the depth + 1 state slots): contracted once behind the loop
-            stacked = os.environ.get("GGPM_ATOM_STACKED_WGRADS", "1") != "0"        # (0: contract per step; dev A/B)
-            if stacked:
-                DG_all = torch.empty(3 if lstm else 2, roff[-1], Hp, **f32)
-                DQ_all = torch.zeros(qoff[-1], Hp, **f32)
-        else:
-            nmax = E1
-            dX = torch.empty(G, E1, Hp, **f32)
-            dH2 = torch.empty(E1, Hp, **f32)
-            dC2 = torch.empty(E1, Hp, **f32) if lstm else None
+        dX = torch.empty(G, E1, Hp, **f32)
+        dH, dH2 = torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)
+        dC, dC2 = (torch.zeros(E1, Hp, **f32), torch.empty(E1, Hp, **f32)) if lstm else (None, None)
         nh = 4 if lstm else 3                                   # hidden-half weight gradients (+ GRU: b_u)
         acc = [torch.zeros(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.zeros(H, **f32)])
         tmp = [torch.empty(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.empty(H, **f32)])
-        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
+        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         ldwo = Wout.stride(0)
-
-        def sparse_backward(n, fz, xg, rp, col, rpT, colT, hs, cs, qs, st, dhd, dcd, dhin, dcin, dx):
-            if lstm:
-                _lib.check(lib.ggpm_lstm_sparse_backward(
-                    n, H, depth, fz, P(xg), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0),
-                    P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), rp, col, rpT, colT, P(hs), P(cs),
-                    P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dhd), P(dcd), P(dhin), P(dcin), P(dx[0]),
-                    P(dx[1]), P(dx[2]), P(dx[3]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[2]), H, P(tmp[3]), H, P(work),
-                    work.numel() * 4, s), "lstm_sparse_backward")
-            else:
-                _lib.check(lib.ggpm_gru_sparse_backward(
-                    n, H, depth, fz, P(xg), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]),
-                    Wh.stride(0), rp, col, rpT, colT, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]),
-                    P(dhd), P(dhin), P(dx[0]), P(dx[1]), P(dx[2]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[3]), P(tmp[2]), H,
-                    P(work), work.numel() * 4, s), "gru_sparse_backward")
-
         for t in range(T - 1, -1, -1):
             a0, a1, i0, i1 = plan.aoff[t], plan.aoff[t + 1], plan.ioff[t], plan.ioff[t + 1]
             ns, ni = a1 - a0, i1 - i0
@@ -432,51 +409,26 @@ class _AtomDecode(torch.autograd.Function):
             # d(state after step t) = what step t+1 passed back + the read-out's share
             _lib.check(lib.ggpm_segment_sum(P(d_nei), Hp, _vp(ptr[("agrT_rp", t)]), _vp(ptr[("agrT_col", t)]), E1, H,
                                             P(dH), Hp, 1, 0, s), "segment_sum")
-            if compact:
-                n = plan.nloc[t]
-                rows = _vp(ptr[("rows", t)])
-                dhd, dhin = torch.empty(n, Hp, **f32), torch.empty(n, Hp, **f32)
-                _lib.check(lib.ggpm_gather_rows(P(dH), Hp, rows, n, Hp, P(dhd), Hp, 0, 0, s), "gather_rows")
-                dcd = dcin = None
-                if lstm:
-                    dcd, dcin = torch.empty(n, Hp, **f32), torch.empty(n, Hp, **f32)
-                    _lib.check(lib.ggpm_gather_rows(P(dC), Hp, rows, n, Hp, P(dcd), Hp, 0, 0, s), "gather_rows")
-                dx = torch.empty(G, n, Hp, **f32)
-                if stacked:
-                    dg = [DG_all[k, roff[t]:roff[t + 1]] for k in range(DG_all.shape[0])] + [DQ_all[qoff[t]:qoff[t + 1]]]
-                    lib.ggpm_backward_defer_stash(P(dg[0]), P(dg[1]), P(dg[2]), P(dg[3]) if lstm else None)
-                sparse_backward(n, _vp(frz_loc + plan.floc_off[t]), Xl[t], _vp(ptr[("lpred_rp", t)]),
-                                _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]),
-                                Hs_all[qoff[t]:qoff[t + 1]], Cs_all[qoff[t]:qoff[t + 1]] if lstm else None,
-                                Qs_all[roff[t]:roff[t + 1]], St_all[:, roff[t]:roff[t + 1]], dhd, dcd, dhin, dcin, dx)
-                # d(state before step t): the frozen rows' carried gradient, zero on the recomputed rows
-                _lib.check(lib.ggpm_scatter_rows(P(dhin), Hp, rows, n, Hp, P(dH), Hp, 0, s), "scatter_rows")
-                if lstm:
-                    _lib.check(lib.ggpm_scatter_rows(P(dcin), Hp, rows, n, Hp, P(dC), Hp, 0, s), "scatter_rows")
-                _lib.check(lib.ggpm_scatter_rows(P(dx), Hp, _vp(xrows[t]), G * n, Hp, P(dXflat), Hp, 1, s), "scatter_rows")
-                if not stacked:
-                    torch._foreach_add_(acc, tmp)
+            st = St[t]
+            if lstm:
+                _lib.check(lib.ggpm_lstm_sparse_backward(
+                    E1, H, depth, P(frz[t]), P(X[3]), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0),
+                    P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), _vp(ptr[("pred_rp", t)]),
+                    _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Cs[t]),
+                    P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH), P(dC), P(dH2), P(dC2), P(dX[0]),
+                    P(dX[1]), P(dX[2]), P(dX[3]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[2]), H, P(tmp[3]), H, P(work),
+                    work.numel() * 4, s), "lstm_sparse_backward")
+                dC, dC2 = dC2, dC
             else:
-                sparse_backward(E1, P(frz[t]), X[3] if lstm else X[1], _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]),
-                                _vp(ptr[("succ_rp", t)]), _vp(ptr[("succ_col", t)]), Hs[t], Cs[t] if lstm else None, Qs[t],
-                                St[t], dH, dC, dH2, dC2, dX)
-                if lstm:
-                    dC, dC2 = dC2, dC
-                dH, dH2 = dH2, dH
-                torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
+                _lib.check(lib.ggpm_gru_sparse_backward(
+                    E1, H, depth, P(frz[t]), P(X[1]), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]),
+                    Wh.stride(0), _vp(ptr[("pred_rp", t)]), _vp(ptr[("pred_col", t)]), _vp(ptr[("succ_rp", t)]),
+                    _vp(ptr[("succ_col", t)]), P(Hs[t]), P(Qs[t]), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dH),
+                    P(dH2), P(dX[0]), P(dX[1]), P(dX[2]), P(tmp[0]), H, P(tmp[1]), H, P(tmp[3]), P(tmp[2]), H, P(work),
+                    work.numel() * 4, s), "gru_sparse_backward")
+            dH, dH2 = dH2, dH
+            torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
         # ---- parameter gradients, once
-        if compact and stacked:
-            R, RQ = roff[-1], qoff[-1]
-            wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
-            ws = torch.empty((wsb + 3) // 4, **f32)
-            if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h
-                _lib.check(lib.ggpm_lstm_weight_grads_stacked(
-                    R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H,
-                    P(acc[1]), H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s), "lstm_weight_grads_stacked")
-            else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
-                _lib.check(lib.ggpm_gru_weight_grads_stacked(
-                    R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H,
-                    P(acc[1]), H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s), "gru_weight_grads_stacked")
         x_ld = F_._ld(hmess)
 
         def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
@@ -501,6 +453,220 @@ class _AtomDecode(torch.autograd.Function):
         return (None,) * 9 + tuple(grads)
 
 
+class _AtomDecodeCompact(torch.autograd.Function):
+    """Same outputs as ``_AtomDecode`` on compact row sets (module docstring, ``AtomPlan.compact_tables``): inside the step
+    loop only ``gather frozen rows -> sparse_forward`` (backward: ``sparse_backward -> scatter-add to the rows' sources``);
+    gate inputs of all steps gathered once, read-out of all steps batched behind the loop, weight gradients contracted
+    once over the stacked stashes."""
+
+    @staticmethod
+    def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, *params):
+        lib = _lib.load()
+        dev = hmess.device
+        D = plan.to_device(dev)
+        ptr, P = D["ptr"], F_._p
+        Hp = F_.padded_hidden(H)
+        E1, T = plan.E1, plan.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        lstm = cell == "LSTM"
+        G = 4 if lstm else 3
+        ct, cp = plan.compact_device(depth, G, dev)
+        if lstm:
+            Wi, bi, Wo_g, bo_g, Wu, bu_g, Wf, bf, Wout, bout = params
+            gates = ((Wi, bi), (Wo_g, bo_g), (Wu, bu_g), (Wf, bf))
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
+            gates = ((Wz, bz), (Wr, None), (Wh, bh))
+        s = F_._stream()
+        # hoisted gate input projections of ALL bond messages, then the rows every step needs, step by step
+        X = torch.empty(G, E1, Hp, **f32)
+        for k, (W, b) in enumerate(gates):
+            F_.gemm(0, 1, E1, H, I, hmess, F_._ld(hmess), W, W.stride(0), X[k], Hp, Hp, bias=b)
+        foff, Ftot = ct["foff"], ct["Ftot"]
+        X_all = torch.empty(G * Ftot, Hp, **f32)
+        _lib.check(lib.ggpm_gather_rows(P(X), Hp, _vp(cp["xrows"]), G * Ftot, Hp, P(X_all), Hp, 0, 0, s), "gather_rows")
+        roff, qoff = plan.row_offsets(depth)
+        Hs_all = torch.empty(qoff[-1], Hp, **f32)
+        Cs_all = torch.empty(qoff[-1], Hp, **f32) if lstm else None
+        Qs_all = torch.empty(roff[-1], Hp, **f32)
+        St_all = torch.empty(5, roff[-1], Hp, **f32)
+        wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H) if lstm else lib.ggpm_gru_pack_floats(H)), **f32)
+        frz_loc = D["frozen_loc"].data_ptr()
+        for t in range(T):
+            n = plan.nloc[t]
+            src = _vp(cp[("srcH", t)])
+            h_in = torch.empty(n, Hp, **f32)
+            _lib.check(lib.ggpm_gather_rows(P(Hs_all), Hp, src, n, Hp, P(h_in), Hp, 0, 0, s), "gather_rows")
+            x = X_all[G * foff[t]:G * foff[t + 1]].view(G, n, Hp)
+            hs, qs = Hs_all[qoff[t]:qoff[t + 1]], Qs_all[roff[t]:roff[t + 1]]
+            st = St_all[:, roff[t]:roff[t + 1]]
+            fz, rp, col = _vp(frz_loc + plan.floc_off[t]), _vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)])
+            if lstm:
+                c_in = torch.empty(n, Hp, **f32)
+                _lib.check(lib.ggpm_gather_rows(P(Cs_all), Hp, src, n, Hp, P(c_in), Hp, 0, 0, s), "gather_rows")
+                _lib.check(lib.ggpm_lstm_sparse_forward(
+                    n, H, depth, P(h_in), P(c_in), fz, P(x[0]), P(x[1]), P(x[2]), P(x[3]), P(Wi[:, I:]),
+                    Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]), Wu.stride(0), P(Wf[:, I:]), Wf.stride(0),
+                    rp, col, P(hs), P(Cs_all[qoff[t]:qoff[t + 1]]), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]),
+                    P(wpack), 1, s), "lstm_sparse_forward")
+            else:
+                _lib.check(lib.ggpm_gru_sparse_forward(
+                    n, H, depth, P(h_in), fz, P(x[0]), P(x[1]), P(x[2]), P(Wz[:, I:]), Wz.stride(0), P(Ur),
+                    Ur.stride(0), P(bu), P(Wh[:, I:]), Wh.stride(0), rp, col, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]),
+                    P(st[3]), P(st[4]), P(wpack), 1, s), "gru_sparse_forward")
+        # ---- read-out of all steps at once: incoming messages (at their step's time) -> atoms -> clusters / candidates
+        ns_tot, n_inst = plan.aoff[-1], plan.ioff[-1]
+        NEI = torch.empty(ns_tot, Hp, **f32)
+        NODE = torch.empty(ns_tot, Hp, **f32)
+        pooled = torch.empty(n_inst, Hp, **f32)
+        cand = torch.empty(max(plan.n_cand, 1), Hp, **f32)
+        ldF, ldwo = F_._ld(fn_all), Wout.stride(0)
+        _lib.check(lib.ggpm_segment_sum(P(Hs_all), Hp, _vp(cp["agr_rp"]), _vp(cp["agr_col"]), ns_tot, H, P(NEI), Hp, 0, Hp, s),
+                   "segment_sum")
+        F_.gemm_ksegments(1, ns_tot, H, [fn_all, NEI], [ldF, Hp], [Wout, Wout[:, Fdim:]], [ldwo, ldwo], [Fdim, H], NODE, Hp,
+                          Hp, bias=bout, act=F_.ACT_RELU)
+        if drop is not None:
+            _lib.check(lib.ggpm_dropout(P(NODE), ns_tot, H, Hp, drop[0], drop[1], drop[2], 0, s), "dropout")
+        _lib.check(lib.ggpm_segment_sum(P(NODE), Hp, _vp(cp["pool_rp"]), _vp(cp["pool_col"]), n_inst, H, P(pooled), Hp, 0, Hp,
+                                        s), "segment_sum")
+        _lib.check(lib.ggpm_gather_rows(P(NODE), Hp, _vp(cp["cand_idx"]), max(plan.n_cand, 1), H, P(cand), Hp, 0, Hp, s),
+                   "gather_rows")
+        ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
+        ctx.save_for_backward(fn_all, hmess, NODE, NEI, X_all, Hs_all, Qs_all, St_all, *([Cs_all] if lstm else []), *params)
+        ctx.keep = (D, ct, cp)
+        return pooled, cand
+
+    @staticmethod
+    def backward(ctx, d_pooled, d_cand):
+        lib = _lib.load()
+        plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
+        lstm = cell == "LSTM"
+        sv = list(ctx.saved_tensors)
+        fn_all, hmess, NODE, NEI, X_all, Hs_all, Qs_all, St_all = sv[:8]
+        Cs_all = sv[8] if lstm else None
+        params = sv[9:] if lstm else sv[8:]
+        D, ct, cp = ctx.keep
+        ptr, P = D["ptr"], F_._p
+        dev = hmess.device
+        Hp = F_.padded_hidden(H)
+        E1, T = plan.E1, plan.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        G = 4 if lstm else 3
+        if lstm:
+            Wi, bi, Wo_g, bo_g, Wu, bu_g, Wf, bf, Wout, bout = params
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
+        d_pooled, d_cand = d_pooled.contiguous(), d_cand.contiguous()
+        s = F_._stream()
+        foff, Ftot = ct["foff"], ct["Ftot"]
+        roff, qoff = plan.row_offsets(depth)
+        ns_tot, ldwo = plan.aoff[-1], Wout.stride(0)
+        # ---- read-out of all steps, backwards: clusters / candidates -> atoms -> the final states they read
+        d_node = torch.empty(ns_tot, Hp, **f32)
+        _lib.check(lib.ggpm_segment_sum(P(d_pooled), Hp, _vp(cp["poolT_rp"]), _vp(cp["poolT_col"]), ns_tot, H, P(d_node), Hp, 0,
+                                        Hp, s), "segment_sum")
+        if plan.n_cand > 0:
+            _lib.check(lib.ggpm_segment_sum(P(d_cand), Hp, _vp(cp["candT_rp"]), _vp(cp["candT_col"]), ns_tot, H, P(d_node), Hp,
+                                            1, 0, s), "segment_sum")
+        DPRE = torch.empty(ns_tot, Hp, **f32)
+        _lib.check(lib.ggpm_act_backward(P(d_node), P(NODE), ns_tot, H, Hp, F_.ACT_RELU, 0, P(DPRE), s), "act_backward")
+        if drop is not None:                # d(dropout . relu) = mask * scale * relu' (the saved output is the dropped one)
+            _lib.check(lib.ggpm_dropout(P(DPRE), ns_tot, H, Hp, drop[0], drop[1], drop[2], 0, s), "dropout")
+        d_nei = torch.empty(ns_tot, Hp, **f32)
+        F_.gemm(0, 0, ns_tot, H, H, DPRE, Hp, Wout[:, Fdim:], ldwo, d_nei, Hp, Hp)
+        dF = torch.empty(Ftot, Hp, **f32)            # gradient of every step's final states (zero where nothing reads them)
+        _lib.check(lib.ggpm_segment_sum(P(d_nei), Hp, _vp(cp["agrT_rp"]), _vp(cp["agrT_col"]), Ftot, H, P(dF), Hp, 0, Hp, s),
+                   "segment_sum")
+        dCF = torch.zeros(Ftot, Hp, **f32) if lstm else None
+        dX_all = torch.empty(G * Ftot, Hp, **f32)
+        # gate-gradient stashes of all steps, stacked like the forward's (DQ with a zero slot per step at the end so that it
+        # lines up with the depth + 1 state slots): contracted once behind the loop
+        DG_all = torch.empty(3 if lstm else 2, roff[-1], Hp, **f32)
+        DQ_all = torch.zeros(qoff[-1], Hp, **f32)
+        nh = 4 if lstm else 3                                   # hidden-half weight gradients (+ GRU: b_u)
+        acc = [torch.empty(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.empty(H, **f32)])
+        nmax = max(plan.nloc)
+        wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
+        work = torch.empty((wb + 3) // 4, **f32)
+        frz_loc = D["frozen_loc"].data_ptr()
+        for t in range(T - 1, -1, -1):
+            n = plan.nloc[t]
+            dhd, dhin = dF[foff[t]:foff[t + 1]], torch.empty(n, Hp, **f32)
+            dx = dX_all[G * foff[t]:G * foff[t + 1]].view(G, n, Hp)
+            xg = X_all[G * foff[t]:G * foff[t + 1]].view(G, n, Hp)[3 if lstm else 1]
+            hs, qs, st = Hs_all[qoff[t]:qoff[t + 1]], Qs_all[roff[t]:roff[t + 1]], St_all[:, roff[t]:roff[t + 1]]
+            fz = _vp(frz_loc + plan.floc_off[t])
+            csr = (_vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]))
+            srcF = _vp(cp[("srcF", t)])
+            if lstm:
+                dcin = torch.empty(n, Hp, **f32)
+                lib.ggpm_backward_defer_stash(P(DG_all[0, roff[t]:]), P(DG_all[1, roff[t]:]), P(DG_all[2, roff[t]:]),
+                                              P(DQ_all[qoff[t]:]))
+                _lib.check(lib.ggpm_lstm_sparse_backward(
+                    n, H, depth, fz, P(xg), P(Wi[:, I:]), Wi.stride(0), P(Wo_g[:, I:]), Wo_g.stride(0), P(Wu[:, I:]),
+                    Wu.stride(0), P(Wf[:, I:]), Wf.stride(0), *csr, P(hs), P(Cs_all[qoff[t]:qoff[t + 1]]), P(qs), P(st[0]),
+                    P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dhd), P(dCF[foff[t]:foff[t + 1]]), P(dhin), P(dcin), P(dx[0]),
+                    P(dx[1]), P(dx[2]), P(dx[3]), P(acc[0]), H, P(acc[1]), H, P(acc[2]), H, P(acc[3]), H, P(work),
+                    work.numel() * 4, s), "lstm_sparse_backward")
+                _lib.check(lib.ggpm_scatter_rows(P(dcin), Hp, srcF, n, Hp, P(dCF), Hp, 1, s), "scatter_rows")
+            else:
+                lib.ggpm_backward_defer_stash(P(DG_all[0, roff[t]:]), P(DG_all[1, roff[t]:]), P(DQ_all[qoff[t]:]), None)
+                _lib.check(lib.ggpm_gru_sparse_backward(
+                    n, H, depth, fz, P(xg), P(Wz[:, I:]), Wz.stride(0), P(Ur), Ur.stride(0), P(Wh[:, I:]), Wh.stride(0),
+                    *csr, P(hs), P(qs), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(st[4]), P(dhd), P(dhin), P(dx[0]),
+                    P(dx[1]), P(dx[2]), P(acc[0]), H, P(acc[1]), H, P(acc[3]), P(acc[2]), H, P(work), work.numel() * 4, s),
+                    "gru_sparse_backward")
+            # the frozen rows' gradient goes to the step that produced their state (rows recomputed here: none)
+            _lib.check(lib.ggpm_scatter_rows(P(dhin), Hp, srcF, n, Hp, P(dF), Hp, 1, s), "scatter_rows")
+        # ---- parameter gradients, once
+        dX_tot = torch.empty(G, E1, Hp, **f32)
+        _lib.check(lib.ggpm_segment_sum(P(dX_all), Hp, _vp(cp["xT_rp"]), _vp(cp["xT_col"]), G * E1, Hp, P(dX_tot), Hp, 0, 0, s),
+                   "segment_sum")
+        R, RQ = roff[-1], qoff[-1]
+        wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
+        ws = torch.empty((wsb + 3) // 4, **f32)
+        if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h; St_all[0] = S
+            _lib.check(lib.ggpm_lstm_weight_grads_stacked(
+                R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
+                H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s), "lstm_weight_grads_stacked")
+        else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
+            _lib.check(lib.ggpm_gru_weight_grads_stacked(
+                R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
+                H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s), "gru_weight_grads_stacked")
+        return (None,) * 9 + _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot)
+
+
+def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot):
+    """Parameter gradients of the atom-level decode from the summed gate-input gradients, the accumulated hidden halves
+    and the stacked read-out rows (shared by both forms)."""
+    if lstm:
+        Wi, bi, Wo_g, bo_g, Wu, bu_g, Wf, bf, Wout, bout = params
+    else:
+        Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
+    x_ld = F_._ld(hmess)
+
+    def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
+        dW = torch.empty_like(W)
+        F_.gemm(1, 0, H, I, E1, dX_tot[k], Hp, hmess, x_ld, dW, dW.stride(0), I, splitk=True)
+        if hidden is not None:
+            dW[:, I:] = hidden
+        return dW
+
+    dWout = torch.empty_like(Wout)
+    F_.gemm(1, 0, H, Fdim, ns_tot, DPRE, Hp, fn_all, F_._ld(fn_all), dWout, dWout.stride(0), Fdim, splitk=True)
+    F_.gemm(1, 0, H, H, ns_tot, DPRE, Hp, NEI, Hp, dWout[:, Fdim:], dWout.stride(0), H, splitk=True)
+    dbout = F_.colsum(DPRE, ns_tot, H)
+    if lstm:
+        grads = []
+        for k, W in enumerate((Wi, Wo_g, Wu, Wf)):
+            grads += [full(W, k, acc[k]), F_.colsum(dX_tot[k], E1, H)]
+        grads += [dWout, dbout]
+    else:          # acc order of the GRU: Wz_h, U_r, Wh_h, b_u
+        grads = [full(Wz, 0, acc[0]), F_.colsum(dX_tot[0], E1, H), full(Wr, 1, None), acc[1], acc[3],
+                 full(Wh, 2, acc[2]), F_.colsum(dX_tot[2], E1, H), dWout, dbout]
+    return tuple(grads)
+
+
 def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: torch.Tensor, fn_all: torch.Tensor):
     """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``."""
     from .rnn import LSTM
@@ -515,5 +681,6 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
     if graph_encoder.training and wo[2].p > 0:
         seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64)
         drop = (float(wo[2].p), int(seed[0]), int(seed[1]))
-    return _AtomDecode.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
-                             rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)
+    fn = _AtomDecodeCompact if compact_enabled() else _AtomDecode
+    return fn.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
+                    rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)

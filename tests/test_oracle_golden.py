@@ -310,8 +310,6 @@ def test_atom_plan_compact_row_sets_match_the_level_wide_tables():
         fl = plan.frozen_loc[plan.floc_off[t]:plan.floc_off[t] + n]
         assert np.array_equal(fl, plan.frozen[t][rows])                       # same mask on the rows of the set
         assert set(np.nonzero(plan.frozen[t] == 0)[0]) <= set(rows.tolist())  # every recomputed row is in the set
-        live = arr(("live", t))
-        assert np.array_equal(live, np.where(fl == 0, rows, -1))
         for loc, glob in (("lpred", "pred"), ("lsucc", "succ")):
             rp, col = arr((loc + "_rp", t)), arr((loc + "_col", t))
             grp, gcol = arr((glob + "_rp", t)), arr((glob + "_col", t))
@@ -323,6 +321,47 @@ def test_atom_plan_compact_row_sets_match_the_level_wide_tables():
             assert all(grp[r + 1] == grp[r] for r in np.nonzero(~inside)[0])  # rows outside the set have no entries
         gr = plan.gate_rows(t, 3)
         assert np.array_equal(gr, np.concatenate([k * E1 + rows for k in range(3)]))
+
+    # compact_tables: "the state of message r at time t" resolved on the host.  Emulate the level-wide loop with random
+    # states (a step overwrites the rows it recomputes) and compare what the tables read with what the loop would read.
+    depth, G = 5, 3
+    ct = plan.compact_tables(depth, G)
+
+    def tab(key):
+        off, n = ct["where"][key]
+        return ct["ints"][off:off + n].astype(np.int64)
+
+    rng = np.random.default_rng(0)
+    foff, Ftot = ct["foff"], ct["Ftot"]
+    assert Ftot == sum(plan.nloc)
+    Fval = rng.standard_normal(Ftot)                       # final state of (step, local row); only live rows are ever read
+    state = np.zeros(E1)
+    nei_loop = np.zeros(plan.aoff[-1])
+    n = np.asarray(plan.nloc)
+    for t in range(plan.T):
+        rows = arr(("rows", t))
+        fl = plan.frozen_loc[plan.floc_off[t]:plan.floc_off[t] + n[t]]
+        srcF, srcH = tab(("srcF", t)), tab(("srcH", t))
+        want_in = np.where(fl == 1, state[rows], 0.0)       # frozen rows enter with the level-wide state, the others with 0
+        got_in = np.where(srcF >= 0, Fval[np.maximum(srcF, 0)], 0.0)
+        assert np.array_equal(np.where(fl == 1, got_in, 0.0), want_in)
+        assert np.all(srcF[fl == 0] == -1)
+        st = np.searchsorted(foff, srcF[srcF >= 0], side="right") - 1          # F id -> row of the stacked state blocks
+        assert np.array_equal(srcH[srcF >= 0], (depth + 1) * np.asarray(foff)[st] + depth * n[st] + srcF[srcF >= 0] - np.asarray(foff)[st])
+        live = np.nonzero(fl == 0)[0]
+        state[rows[live]] = Fval[foff[t] + live]
+        grp, gcol = arr(("agr_rp", t)), arr(("agr_col", t))                   # per-step table of the full-level form
+        for a in range(plan.aoff[t + 1] - plan.aoff[t]):
+            nei_loop[plan.aoff[t] + a] = state[gcol[grp[a]:grp[a + 1]]].sum()
+    rpT, colT = tab("agrT_rp"), tab("agrT_col")
+    nei_tab = np.zeros(plan.aoff[-1])
+    for f in range(Ftot):
+        nei_tab[colT[rpT[f]:rpT[f + 1]]] += Fval[f]
+    assert np.allclose(nei_tab, nei_loop, rtol=0, atol=1e-12)
+    xr = tab("xrows")
+    assert np.array_equal(xr, np.concatenate([plan.gate_rows(t, G) for t in range(plan.T)]))
+    rpT, colT = tab("xT_rp"), tab("xT_col")
+    assert len(rpT) == G * E1 + 1 and all(np.all(xr[colT[rpT[r]:rpT[r + 1]]] == r) for r in range(G * E1))
 
 
 @pytest.mark.parametrize("name", vae_case_names())
