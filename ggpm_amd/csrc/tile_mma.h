@@ -27,7 +27,10 @@ constexpr int GGPM_PF = 4;        // weight-fragment prefetch depth (k chunks)
 #ifndef GGPM_CHAIN_MAX
 #define GGPM_CHAIN_MAX 3          // loops with fewer products than this chain their ring across a wave's tiles
 #endif
-template <int NOPS> struct GgpmPf { static constexpr int value = NOPS >= 3 ? GGPM_PF3 : GGPM_PF; };
+#ifndef GGPM_PF1
+#define GGPM_PF1 GGPM_PF          // ... of the single-product loops
+#endif
+template <int NOPS> struct GgpmPf { static constexpr int value = NOPS >= 3 ? GGPM_PF3 : (NOPS == 1 ? GGPM_PF1 : GGPM_PF); };
 
 // Packed weight tile order: [out tile t][k chunk kc][lane 0..63][4 floats].
 __device__ __forceinline__ size_t ggpm_pack_index(int t, int kc, int KC, int lane) {
@@ -89,10 +92,15 @@ __device__ __forceinline__ void ggpm_wave_gemm_ring(const float* const (&tiles)[
             const int kq = kc + d + PF;
             const bool over = kq >= KC;
             const int kn = over ? (chain ? kq - KC : KC - 1) : kq;
+#ifndef GGPM_ABL_NOLOAD            // (dev ablations, timing only: the weight stream / the matrix pipe alone)
 #pragma unroll
             for (int o = 0; o < NOPS; ++o)
                 ring.r[d][o] = *reinterpret_cast<const f32x4*>((over && chain ? wn[o] : wp[o]) + (size_t)kn * 256);
+#else
+            (void)kn; (void)wn;
+#endif
             __builtin_amdgcn_sched_barrier(0);   // keep the refill loads HERE (PF chunks ahead of their use)
+#ifndef GGPM_ABL_NOMFMA
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -100,6 +108,12 @@ __device__ __forceinline__ void ggpm_wave_gemm_ring(const float* const (&tiles)[
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
                         acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[o][s], b[o][r][s], acc[o][r], 0, 0, 0);
+#else
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) asm volatile("" :: "v"(a[o]), "v"(b[o][r]));
+#endif
         }
     }
     // remainder (rem = KC % PF chunks): their fragments sit in ring slots [0, rem)
@@ -142,6 +156,10 @@ __device__ __forceinline__ void ggpm_wave_gemm_ring(const float* const (&tiles)[
         case 1: rotate(std::integral_constant<int, 1>{}); break;
         case 2: rotate(std::integral_constant<int, 2>{}); break;
         case 3: rotate(std::integral_constant<int, 3>{}); break;
+        case 4: if constexpr (PF > 4) rotate(std::integral_constant<int, 4>{}); break;
+        case 5: if constexpr (PF > 5) rotate(std::integral_constant<int, 5>{}); break;
+        case 6: if constexpr (PF > 6) rotate(std::integral_constant<int, 6>{}); break;
+        case 7: if constexpr (PF > 7) rotate(std::integral_constant<int, 7>{}); break;
         default: break;
     }
 }
