@@ -9,8 +9,13 @@
 // gradient contractions there, event-ordered.  GRU message function, dropout 0 (the host keeps the op-by-op path
 // for everything else).
 #include "common.h"
+#include <condition_variable>
 #include <cstring>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 hipEvent_t ggpm_wgrad_event(int i);          // small pool of re-recordable events (mpn_gru.hip)
 
@@ -169,6 +174,90 @@ inline bool use_tables() {
     return on;
 }
 
+// ---- launch worker of the second stream -----------------------------------------------------------------------------------
+// A step issues ~285 launches, ~90 of them on the second stream (index transposes beside the forward, every weight-gradient
+// contraction of the backward).  They are independent of what the calling thread issues next, so a worker thread issues
+// them: the caller records the ordering event on its own stream, queues a closure and goes on with the latency-critical
+// depth loops; the worker waits on the event (on the second stream) and launches.  The drivers drain the queue before
+// they return (and before anything waits on the second stream), so no closure outlives the buffers it names.
+// GGPM_SIDE_WORKER=0: the calling thread issues everything itself, in the same order.
+class SideWorker {
+public:
+    static SideWorker* get() {
+        static const bool on = !(getenv("GGPM_SIDE_WORKER") && atoi(getenv("GGPM_SIDE_WORKER")) == 0);
+        if (!on) return nullptr;
+        static SideWorker w;
+        return &w;
+    }
+    void post(std::function<int()> job) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
+    // blocks until everything posted so far has been issued; -> the first error of those jobs
+    int drain() {
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_.wait(lk, [&] { return q_.empty() && !busy_; });
+        const int e = err_;
+        err_ = GGPM_OK;
+        return e;
+    }
+    void use_device(int dev) {
+        std::lock_guard<std::mutex> lk(mu_);
+        want_dev_ = dev;
+    }
+
+private:
+    SideWorker() : th_([this] { run(); }) {}
+    ~SideWorker() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_one();
+        if (th_.joinable()) th_.join();
+    }
+    void run() {
+        int dev = -1;
+        for (;;) {
+            std::function<int()> job;
+            int want;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;          // stop requested and nothing left
+                job = std::move(q_.front());
+                q_.pop_front();
+                busy_ = true;
+                want = want_dev_;
+            }
+            if (want != dev && want >= 0) { (void)hipSetDevice(want); dev = want; }
+            int rc = job();
+            if (!rc && hipGetLastError() != hipSuccess) rc = GGPM_ERR_LAUNCH;       // (the error state is per thread)
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (rc && !err_) err_ = rc;
+                busy_ = false;
+                if (q_.empty()) idle_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, idle_;
+    std::deque<std::function<int()>> q_;
+    bool busy_ = false, stop_ = false;
+    int err_ = GGPM_OK, want_dev_ = -1;
+    std::thread th_;          // last member: starts when everything above is constructed
+};
+
+// every return path of a driver leaves the worker idle (the closures name caller buffers)
+struct DrainGuard {
+    SideWorker* wk;
+    ~DrainGuard() { if (wk) (void)wk->drain(); }
+};
+
 #define CK(expr)                    \
     do {                            \
         const int rc__ = (expr);    \
@@ -311,11 +400,13 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     // CSRs, four index columns, iota) is built on the second stream beside the atom level and joined before the
     // attachment level, and the transposes (read by the backward only) follow there.
     ggpm_stream_t ts = side_stream ? side_stream : stream;
+    SideWorker* wk = side_stream ? SideWorker::get() : nullptr;
+    DrainGuard guard = {wk};
+    hipEvent_t ev_in = nullptr;
     if (side_stream) {
-        hipEvent_t ev = ggpm_wgrad_event(60);
-        if (!ev) return GGPM_ERR_LAUNCH;
-        (void)hipEventRecord(ev, s);                 // the caller's index tensors are ready from here on
-        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+        ev_in = ggpm_wgrad_event(60);
+        if (!ev_in) return GGPM_ERR_LAUNCH;
+        (void)hipEventRecord(ev_in, s);              // the caller's index tensors are ready from here on
     }
     CK(ggpm_padded_to_csr(gbgraph, d.E1g, d.Kgb, S.gpred.rowptr, S.gpred.col, stream));
     CK(ggpm_padded_to_csr(gagraph, d.N1g, d.Kga, S.gagr.rowptr, S.gagr.col, stream));
@@ -327,31 +418,33 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
         if (!ev_atom || !ev_tree) return GGPM_ERR_LAUNCH;
         (void)hipEventRecord(ev_atom, s);
     }
-    CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, ts));
-    CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, ts));
-    CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, ts));
-    if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, ts));
-    CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, ts));
-    CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, ts));
-    CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, ts));
-    CK(ggpm_extract_column(tfnode, d.N1t, 2, 1, S.attach_id, ts));
-    {
-        const int nio = (d.E1t > d.N1t ? d.E1t : d.N1t) + 1;
-        const int n = nio > d.B + 1 ? nio : d.B + 1;
-        iota_k<<<ggpm_ceil_div(n, 256), 256, 0, (hipStream_t)ts>>>(S.iota, n);
-    }
-    // inputs of the two tree-side levels that do not depend on the level below: embedding rows, one-hot bond positions
-    CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, ts));
-    CK(drop(d, S.finput_i, d.N1t, He, d.Hep, DS_EI, ts));
-    CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, ts));
-    CK(drop(d, S.finput_t, d.N1t, He, d.Hep, DS_EC, ts));
-    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, ts));
-    CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, ts));
-    if (side_stream) {
-        (void)hipEventRecord(ev_tree, (hipStream_t)side_stream);
-        (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_atom, 0);     // the atom CSRs, for their transposes
-    }
-    {
+    // everything the second stream does in the forward, as one closure (issued by the launch worker when there is one)
+    auto tree_layout = [=]() -> int {
+        if (side_stream) (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_in, 0);
+        CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, ts));
+        CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, ts));
+        CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, ts));
+        if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, ts));
+        CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, ts));
+        CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, ts));
+        CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, ts));
+        CK(ggpm_extract_column(tfnode, d.N1t, 2, 1, S.attach_id, ts));
+        {
+            const int nio = (d.E1t > d.N1t ? d.E1t : d.N1t) + 1;
+            const int n = nio > d.B + 1 ? nio : d.B + 1;
+            iota_k<<<ggpm_ceil_div(n, 256), 256, 0, (hipStream_t)ts>>>(S.iota, n);
+        }
+        // inputs of the two tree-side levels that do not depend on the level below: embedding rows, one-hot bond positions
+        CK(ggpm_gather_rows(P[P_EI], He, S.attach_id, d.N1t, He, S.finput_i, d.Hep, 0, d.Hep, ts));
+        CK(drop(d, S.finput_i, d.N1t, He, d.Hep, DS_EI, ts));
+        CK(ggpm_gather_rows(P[P_EC], He, S.motif_id, d.N1t, He, S.finput_t, d.Hep, 0, d.Hep, ts));
+        CK(drop(d, S.finput_t, d.N1t, He, d.Hep, DS_EC, ts));
+        CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_i, d.ld_t, H, d.ld_t, ts));
+        CK(ggpm_onehot(S.attr0, d.E1t, 20, S.hmess_t, d.ld_t, H, d.ld_t, ts));
+        if (side_stream) {
+            (void)hipEventRecord(ev_tree, (hipStream_t)side_stream);
+            (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_atom, 0);     // the atom CSRs, for their transposes
+        }
         CK(transpose(S.gpred, nullptr, ts));
         if (use_tables()) CK(ggpm_csr_table4(S.gpred.rowptrT, S.gpred.colT, d.E1g, S.gpred.tabT, ts));
         CK(transpose(S.gagr, nullptr, ts));
@@ -363,6 +456,15 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
         CK(transpose(S.root, roots, ts));
         CK(transpose(S.motif, S.motif_id, ts));
         CK(transpose(S.attach, S.attach_id, ts));
+        return GGPM_OK;
+    };
+    if (wk) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        wk->use_device(dev);
+        wk->post(tree_layout);
+    } else {
+        CK(tree_layout());
     }
 
     // ---- atom level (embed_graph, graph_encoder)
@@ -373,6 +475,7 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     CK(drop(d, hatom, d.N1g, H, Hp, DS_WO_ATOM, stream));
 
     // ---- attachment level (embed_inter, inter_encoder)
+    if (wk) CK(wk->drain());                                       // (ev_tree is recorded once the closure has run)
     if (side_stream) (void)hipStreamWaitEvent(s, ev_tree, 0);      // tree-side layout built beside the atom level
     CK(ggpm_segment_sum(hatom, Hp, S.tcgr.rowptr, S.tcgr.col, d.N1t, H, S.pooled, Hp, 0, Hp, stream));
     CK(linear2(d.N1t, H, S.finput_i, d.Hep, He, S.pooled, Hp, H, P[P_WI], P[P_BI], GGPM_ACT_RELU, 0, S.hnode_i, Hp,
@@ -445,15 +548,27 @@ void layout_work(Arena& A, const Dims& d, BwdWork& w) {
 struct Streams {
     ggpm_stream_t main, side;
     int n_ev;
+    SideWorker* wk;          // issues the second stream's launches when set (see SideWorker)
     // order the second stream behind everything issued on the main stream so far
     int side_after_main() {
         if (!side) return GGPM_OK;
         hipEvent_t ev = ggpm_wgrad_event(n_ev++ & 31);
         if (!ev) return GGPM_ERR_LAUNCH;
         (void)hipEventRecord(ev, (hipStream_t)main);
-        (void)hipStreamWaitEvent((hipStream_t)side, ev, 0);
+        ggpm_stream_t sd = side;
+        return on_side([sd, ev]() -> int {
+            (void)hipStreamWaitEvent((hipStream_t)sd, ev, 0);
+            return GGPM_OK;
+        });
+    }
+    // run `f` (launches on w()) in issue order with the other second-stream work
+    template <class F>
+    int on_side(F f) {
+        if (!wk) return f();
+        wk->post(std::function<int()>(std::move(f)));
         return GGPM_OK;
     }
+    int drain() { return wk ? wk->drain() : GGPM_OK; }
     ggpm_stream_t w() const { return side ? side : main; }      // where weight gradients go
 };
 
@@ -477,11 +592,16 @@ int linear2_wgrad(int M, int N, const float* dpre, int ldp, const float* x1, int
                   int K2, float* dW, float* db, BwdWork& w, Streams& st) {
     CK(st.side_after_main());
     const int ldw = K1 + K2;
-    CK(ggpm_gemm(1, 0, N, K1, M, dpre, ldp, x1, ld1, dW, ldw, K1, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
-    CK(ggpm_gemm(1, 0, N, K2, M, dpre, ldp, x2, ld2, dW + K1, ldw, K2, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
-                 st.w()));
-    if (db) CK(ggpm_colsum(dpre, ldp, M, N, db, w.csws, st.w()));
-    return GGPM_OK;
+    const ggpm_stream_t sw = st.w();
+    float* const skws = w.skws;
+    float* const csws = w.csws;
+    const size_t skb = w.skws_bytes;
+    return st.on_side([=]() -> int {
+        CK(ggpm_gemm(1, 0, N, K1, M, dpre, ldp, x1, ld1, dW, ldw, K1, nullptr, 0, GGPM_ACT_NONE, 0, skws, skb, sw));
+        CK(ggpm_gemm(1, 0, N, K2, M, dpre, ldp, x2, ld2, dW + K1, ldw, K2, nullptr, 0, GGPM_ACT_NONE, 0, skws, skb, sw));
+        if (db) CK(ggpm_colsum(dpre, ldp, M, N, db, csws, sw));
+        return GGPM_OK;
+    });
 }
 
 // backward of one level given dHD = d(h_D); dx (the gradient of the level's message inputs) is optional
@@ -508,20 +628,29 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             CK(ggpm_gemm_ksegments(0, E1, I, 4, A, lda, W, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
         }
         CK(st.side_after_main());
-        ggpm_wgrad_lo_depth(blo);
-        CK(ggpm_lstm_weight_grads(E1, H, depth, L.Hs, L.St, level_work, w.level_work_bytes, dW[0] + I, I + H, dW[1] + I,
-                                  I + H, dW[2] + I, I + H, dW[3] + I, I + H, st.w()));
-        if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
-            GgpmGemmProblem gp[4];
-            for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
-            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, st.w()));
-        } else {
-            for (int k = 0; k < 4; ++k)
-                CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dW[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
-                             w.skws_bytes, st.w()));
-        }
-        for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, db[k], w.csws, st.w()));
-        return GGPM_OK;
+        const ggpm_stream_t sw = st.w();
+        const BwdWork wc = w;
+        float* const dW0 = dW[0]; float* const dW1 = dW[1]; float* const dW2 = dW[2]; float* const dW3 = dW[3];
+        float* const db0 = db[0]; float* const db1 = db[1]; float* const db2 = db[2]; float* const db3 = db[3];
+        const float* Hs = L.Hs; const float* St = L.St;
+        return st.on_side([=]() -> int {
+            float* const dWk[4] = {dW0, dW1, dW2, dW3};
+            float* const dbk[4] = {db0, db1, db2, db3};
+            ggpm_wgrad_lo_depth(blo);
+            CK(ggpm_lstm_weight_grads(E1, H, depth, Hs, St, level_work, wc.level_work_bytes, dWk[0] + I, I + H, dWk[1] + I,
+                                      I + H, dWk[2] + I, I + H, dWk[3] + I, I + H, sw));
+            if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
+                GgpmGemmProblem gp[4];
+                for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
+                CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, sw));
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0,
+                                 wc.skws, wc.skws_bytes, sw));
+            }
+            for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, dbk[k], wc.csws, sw));
+            return GGPM_OK;
+        });
     }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
@@ -571,25 +700,32 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         CK(ggpm_gemm_ksegments(0, E1, I, 3, A, lda, B, ldb, K, dx, lddx, lddx, nullptr, 0, GGPM_ACT_NONE, 0, st.main));
     }
     CK(st.side_after_main());
-    if (!overlap) ggpm_wgrad_lo_depth(blo);
-    if (!overlap)
-        CK(ggpm_gru_weight_grads(E1, H, depth, L.Hs, L.St, L.St + ds, level_work, w.level_work_bytes, dWz + I, I + H, dUr,
-                                 H, G[lp(level, L_BU)], dWh + I, I + H, st.w()));
-    if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
-        const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
-                                       {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
-                                       {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
-        CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, st.w()));
-    } else {
-        CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes, st.w()));
-        CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws, w.skws_bytes,
-                     st.w()));
-        CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, w.skws,
-                     w.skws_bytes, st.w()));
-    }
-    CK(ggpm_colsum(dX, Hp, E1, H, G[lp(level, L_BZ)], w.csws, st.w()));
-    CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, G[lp(level, L_BH)], w.csws, st.w()));
-    return GGPM_OK;
+    const ggpm_stream_t sw = st.w();
+    const BwdWork wc = w;
+    const float* Hs = L.Hs; const float* St = L.St;
+    float* const dbu = G[lp(level, L_BU)]; float* const dbz = G[lp(level, L_BZ)]; float* const dbh = G[lp(level, L_BH)];
+    return st.on_side([=]() -> int {
+        if (!overlap) {
+            ggpm_wgrad_lo_depth(blo);
+            CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
+                                     dbu, dWh + I, I + H, sw));
+        }
+        if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
+            const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                           {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                           {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
+            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, sw));
+        } else {
+            CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes, sw));
+            CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes,
+                         sw));
+            CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws,
+                         wc.skws_bytes, sw));
+        }
+        CK(ggpm_colsum(dX, Hp, E1, H, dbz, wc.csws, sw));
+        CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, dbh, wc.csws, sw));
+        return GGPM_OK;
+    });
 }
 
 }  // namespace
@@ -630,7 +766,14 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     float* const* P = params;
     float* const* G = grads;
     const int H = d.H, Hp = d.Hp, He = d.He;
-    Streams st = {stream, side_stream, 0};
+    // (the opt-in overlapped weight gradients interleave both streams from the calling thread: no worker then)
+    Streams st = {stream, side_stream, 0, (side_stream && wgrad_overlap_mode() == 0) ? SideWorker::get() : nullptr};
+    DrainGuard guard = {st.wk};
+    if (st.wk) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        st.wk->use_device(dev);
+    }
     const int Nmax = d.N1g > d.N1t ? d.N1g : d.N1t, Emax = d.E1g > d.E1t ? d.E1g : d.E1t;
     float* dpre[5];
     for (int i = 0; i < 5; ++i) dpre[i] = w.dpre + (size_t)i * Nmax * Hp;
@@ -657,8 +800,13 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     } else {
         (void)hipMemsetAsync(w.d_hnode_t, 0, nt, s);
         (void)hipMemsetAsync(w.d_nei_t, 0, nt, s);
-        (void)hipMemsetAsync(G[P_WROOT], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
-        (void)hipMemsetAsync(G[P_BROOT], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
+        float* const gw = G[P_WROOT]; float* const gb = G[P_BROOT];
+        const ggpm_stream_t sw = st.w();
+        CK(st.on_side([=]() -> int {
+            (void)hipMemsetAsync(gw, 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)sw);
+            (void)hipMemsetAsync(gb, 0, (size_t)H * sizeof(float), (hipStream_t)sw);
+            return GGPM_OK;
+        }));
     }
 
     // ---- motif level: W_o, message function, W_c / E_c
@@ -668,8 +816,13 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
         CK(linear2_dx(d.N1t, H, H, dpre[0], Hp, P[lwo(d.lstm, 0)], w.d_hnode_t, Hp, 1, w.d_nei_t, Hp, 1, stream));
         CK(linear2_wgrad(d.N1t, H, dpre[0], Hp, S.hnode_t, Hp, H, S.lv[0].nei, Hp, H, G[lwo(d.lstm, 0)], G[lbo(d.lstm, 0)], w, st));
     } else {
-        (void)hipMemsetAsync(G[lwo(d.lstm, 0)], 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)st.w());
-        (void)hipMemsetAsync(G[lbo(d.lstm, 0)], 0, (size_t)H * sizeof(float), (hipStream_t)st.w());
+        float* const gw = G[lwo(d.lstm, 0)]; float* const gb = G[lbo(d.lstm, 0)];
+        const ggpm_stream_t sw = st.w();
+        CK(st.on_side([=]() -> int {
+            (void)hipMemsetAsync(gw, 0, (size_t)H * 2 * H * sizeof(float), (hipStream_t)sw);
+            (void)hipMemsetAsync(gb, 0, (size_t)H * sizeof(float), (hipStream_t)sw);
+            return GGPM_OK;
+        }));
     }
     CK(ggpm_segment_sum(w.d_nei_t, Hp, S.tagr.rowptrT, S.tagr.colT, d.E1t, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1t, d.It, d.depthT, S.hmess_t, d.ld_t, P, G, 0, S.tpred, S.lv[0], w.d_h, dXl[0], lwork[0],
@@ -681,7 +834,11 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     CK(linear2_dx(d.N1t, H, He, dpre[1], Hp, P[P_WC], w.d_finput, d.Hep, 0, w.d_hinter, Hp, d_hinter ? 1 : 0, stream));
     CK(drop(d, w.d_finput, d.N1t, He, d.Hep, DS_EC, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[1], Hp, S.finput_t, d.Hep, He, hinter, Hp, H, G[P_WC], G[P_BC], w, st));
-    CK(ggpm_segment_sum(w.d_finput, d.Hep, S.motif.rowptrT, S.motif.colT, d.n_motif, He, G[P_EC], He, 0, He, st.w()));
+    {
+        const float* src = w.d_finput; const int32_t* rp = S.motif.rowptrT; const int32_t* cl = S.motif.colT;
+        float* const g = G[P_EC]; const ggpm_stream_t sw = st.w(); const int Hep = d.Hep, rows = d.n_motif;
+        CK(st.on_side([=]() -> int { return ggpm_segment_sum(src, Hep, rp, cl, rows, He, g, He, 0, He, sw); }));
+    }
 
     // ---- attachment level: W_o, message function, W_i / E_i, pooling over atoms
     CK(ggpm_act_backward(w.d_hinter, hinter, d.N1t, H, Hp, GGPM_ACT_RELU, 1, dpre[2], stream));
@@ -698,13 +855,18 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     CK(linear2_dx(d.N1t, H, He, dpre[3], Hp, P[P_WI], d_finput_i, d.Hep, 0, w.d_pooled, Hp, 0, stream));
     CK(drop(d, d_finput_i, d.N1t, He, d.Hep, DS_EI, stream));
     CK(linear2_wgrad(d.N1t, H, dpre[3], Hp, S.finput_i, d.Hep, He, S.pooled, Hp, H, G[P_WI], G[P_BI], w, st));
-    CK(ggpm_segment_sum(d_finput_i, d.Hep, S.attach.rowptrT, S.attach.colT, d.n_attach, He, G[P_EI], He, 0, He, st.w()));
+    {
+        const int32_t* rp = S.attach.rowptrT; const int32_t* cl = S.attach.colT;
+        float* const g = G[P_EI]; const ggpm_stream_t sw = st.w(); const int Hep = d.Hep, rows = d.n_attach;
+        CK(st.on_side([=]() -> int { return ggpm_segment_sum(d_finput_i, Hep, rp, cl, rows, He, g, He, 0, He, sw); }));
+    }
     if (d_hatom) (void)hipMemcpyAsync(w.d_hatom, d_hatom, ng, hipMemcpyDeviceToDevice, s);
     CK(ggpm_segment_sum(w.d_pooled, Hp, S.tcgr.rowptrT, S.tcgr.colT, d.N1g, H, w.d_hatom, Hp, d_hatom ? 1 : 0,
                         d_hatom ? 0 : Hp, stream));
 
     }   // phase != 2
     if (phase == 1) {      // everything but the atom level's parameter gradients is issued (second stream: in flight)
+        CK(st.drain());
         GGPM_CHECK_LAUNCH();
         return GGPM_OK;
     }
@@ -720,6 +882,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],
                       nullptr, 0, w, st, wgrad_overlap_mode()));
 
+    CK(st.drain());
     if (side_stream) {      // every gradient buffer is complete once the main stream has passed this point
         hipEvent_t ev = ggpm_wgrad_event(62);
         if (!ev) return GGPM_ERR_LAUNCH;
