@@ -805,6 +805,27 @@ __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ w
     if (rl == 0 && n < N) out[n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// short matrices (M <= CS_ONE_MAX rows: the bias gradients of the read-outs and of the small levels): ONE launch, block =
+// 64 columns x 16 row lanes, fixed summation order -- the two-stage form spends two launch latencies on a few KB
+constexpr int CS_ONE_MAX = 2048;
+__global__ void __launch_bounds__(1024) colsum_one(const float* __restrict__ A, int lda, int M, int N,
+                                                   float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, n = blockIdx.x * 64 + c;
+    const int rl = threadIdx.x >> 6;
+    float v = 0.f;
+    if (n < N)
+        for (int m = rl; m < M; m += 16) v += A[(size_t)m * lda + n];
+    red[rl][c] = v;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        out[n] = t;
+    }
+}
+
 __global__ void act_backward_k(const float* __restrict__ dy, const float* __restrict__ y, int rows, int cols,
                                int ld, int act, int zero_row0, float* __restrict__ dpre) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1082,6 +1103,11 @@ extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, fl
     GGPM_CLEAR_STALE_ERROR();
     if (!A || !out || !ws || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (M <= CS_ONE_MAX) {
+        colsum_one<<<ggpm_ceil_div(N, 64), 1024, 0, s>>>(A, lda, M, N, out);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     int chunks = ggpm_ceil_div(M, 128);          // >= 128 rows per chunk, at most CS_ROWS chunks
     if (chunks > CS_ROWS) chunks = CS_ROWS;
     dim3 g1(ggpm_ceil_div(N, 64), chunks);

@@ -939,6 +939,20 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
         g.check_grad(k, grad, rel=TOL)
 
 
+@pytest.mark.parametrize("M,N,ld", [(1, 1, 4), (37, 300, 304), (600, 250, 256), (2048, 62, 64), (2049, 300, 304),
+                                    (40000, 300, 304)])
+def test_colsum_matches_numpy(M, N, ld):
+    """ggpm_colsum (bias gradients): the one-launch form for short matrices and the two-stage form, against float64."""
+    from ggpm_amd import functional as F_
+    dev = _dev()
+    rng = np.random.default_rng(M + N)
+    a = rng.standard_normal((M, ld)).astype(np.float32)
+    got = F_.colsum(torch.from_numpy(a).to(dev), M, N).cpu().numpy()
+    want = a[:, :N].astype(np.float64).sum(0)
+    assert got.shape == (N,)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.sqrt(M)) * max(1.0, np.abs(want).max())
+
+
 def test_scatter_rows_inverts_gather_rows():
     """ggpm_scatter_rows (unique indices, -1 = skip; store and accumulate) against numpy; with ggpm_gather_rows it is
     the round trip of the compact decode steps."""
