@@ -418,6 +418,11 @@ def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_t
 # a second HIP stream beside the next level's depth loop and accumulate straight into ``param.grad``; the main
 # stream re-joins at the end of the backward pass (autograd engine callback), so after ``loss.backward()``
 # returns every later main-stream consumer (clip_grad_norm_, all-reduce, optimizer) is ordered behind them.
+# Contract: a parameter whose gradient is published this way must be consumed ONLY by the ops of this module inside the
+# backward pass (true for every parameter of the encoder / decoder classes of this package, tied embeddings included:
+# both users go through these ops).  A stock torch op on the same leaf would have autograd's AccumulateGrad add to
+# ``.grad`` on the main stream while the second stream may still be writing it -- route such a use through
+# GGPM_SIDE_STREAM=0, which keeps every gradient on the main stream and inside autograd.
 _SIDE = {}
 
 
