@@ -415,7 +415,13 @@ class HierMPNDecoder(ScoreHeads):
         """All messages of one tree-side level at once: ``sparse_forward`` over every real message row with the
         time-ordered predecessor table, iterated ``depth`` = longest chain times (see DecodeSchedule._level_plan)."""
         E1 = dag.shape[0] + 1
-        rows = torch.arange(1, E1, dtype=torch.long, device=hmess.device)
+        rows = getattr(dag, "_ggpm_rows", None)            # (the same object every step: F_._sparse_structure's key)
+        if rows is None:
+            rows = torch.arange(1, E1, dtype=torch.long, device=hmess.device)
+            try:
+                dag._ggpm_rows = rows
+            except AttributeError:
+                pass
         I, H = rnn.input_size, rnn.hidden_size
         if isinstance(h0, tuple):
             i, o, u, f = rnn.W_i[0], rnn.W_o[0], rnn.W[0], rnn.W_f[0]

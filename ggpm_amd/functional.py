@@ -123,24 +123,52 @@ def prefetch_transposes(csrs: Sequence["CSR"]) -> None:
         c._T_event = ev
 
 
+_MEMO_ON = os.environ.get("GGPM_INDEX_MEMO", "1") != "0"
+
+
+def _memo_get(t: torch.Tensor, slot: str, key):
+    """Index structures derived from an index tensor are remembered ON that tensor object (index tensors are never
+    written in place here): a batch whose tables stay resident -- a DecodeSchedule on the device, the encoder's graph
+    tensors -- pays for their CSRs and transposes once, not once per step."""
+    if not _MEMO_ON:
+        return None
+    m = getattr(t, slot, None)
+    return m[1] if m is not None and m[0] == key else None
+
+
+def _memo_put(t: torch.Tensor, slot: str, key, value):
+    try:
+        setattr(t, slot, (key, value))
+    except AttributeError:
+        pass
+    return value
+
+
 def csr_from_padded(padded: torch.Tensor, ncols: int) -> CSR:
     """agraph/bgraph/cgraph (int64 [rows, width], 0 = no entry) -> CSR over the real entries."""
     _need_gpu(padded)
     assert padded.dtype == torch.int64 and padded.dim() == 2
+    hit = _memo_get(padded, "_ggpm_csr", ncols)
+    if hit is not None:
+        return hit
+    owner = padded
     padded = padded.contiguous()
     rows, width = padded.shape
     rowptr = torch.empty(rows + 1, dtype=torch.int32, device=padded.device)
     col = torch.empty(max(rows * width, 1), dtype=torch.int32, device=padded.device)
     _lib.check(_lib.load().ggpm_padded_to_csr(_p(padded), rows, width, _p(rowptr), _p(col), _stream()),
                "padded_to_csr")
-    return CSR(rowptr, col, rows, ncols)
+    return _memo_put(owner, "_ggpm_csr", ncols, CSR(rowptr, col, rows, ncols))
 
 
 def csr_from_index(idx: torch.Tensor, ncols: int) -> CSR:
     """One entry per row (col = idx[row]); its transpose lists, per id, the rows that use it."""
+    hit = _memo_get(idx, "_ggpm_csr_index", ncols)
+    if hit is not None:
+        return hit
     rows = idx.numel()
     rowptr = torch.arange(rows + 1, dtype=torch.int32, device=idx.device)
-    return CSR(rowptr, idx, rows, ncols)
+    return _memo_put(idx, "_ggpm_csr_index", ncols, CSR(rowptr, idx, rows, ncols))
 
 
 def extract_column(mat: torch.Tensor, column: int) -> torch.Tensor:
@@ -724,6 +752,18 @@ def _scatter_rows(full_rows: int, sub: torch.Tensor, index: torch.Tensor) -> tor
     return out
 
 
+def _sparse_structure(E1: int, submess: torch.Tensor, bgraph_sub: torch.Tensor):
+    """(frozen mask [E1] uint8, predecessor CSR over all E1 rows) of a sparse_forward call, remembered on ``bgraph_sub``."""
+    key = (E1, submess.data_ptr(), submess.numel())
+    hit = _memo_get(bgraph_sub, "_ggpm_sparse", key)
+    if hit is not None:
+        return hit
+    frozen = torch.ones(E1, dtype=torch.uint8, device=submess.device)
+    frozen.index_fill_(0, submess, 0)
+    pred = csr_from_padded(_scatter_rows(E1, bgraph_sub, submess), ncols=E1)
+    return _memo_put(bgraph_sub, "_ggpm_sparse", key, (frozen, pred, submess))      # (keeps `submess` alive: the key names it)
+
+
 class _GruSparse(torch.autograd.Function):
     """GRU.sparse_forward (ggpm/rnn.py:52-59): recompute the rows `submess` of the message state `depth` times."""
 
@@ -735,9 +775,7 @@ class _GruSparse(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=h_in.device)
         save = any(ctx.needs_input_grad)
         hp = _as_padded_state(h_in, H, Hp)
-        frozen = torch.ones(E1, dtype=torch.uint8, device=h_in.device)
-        frozen.index_fill_(0, submess, 0)
-        pred = csr_from_padded(_scatter_rows(E1, bgraph_sub, submess), ncols=E1)
+        frozen, pred, _ = _sparse_structure(E1, submess, bgraph_sub)
         Wz_x, Wz_h = _split_cols(W_z, I)
         Wh_x, Wh_h = _split_cols(W_h, I)
         ldx = _ld(x_sub)
@@ -834,9 +872,7 @@ class _LstmSparse(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=h_in.device)
         save = any(ctx.needs_input_grad)
         hp, cp = _as_padded_state(h_in, H, Hp), _as_padded_state(c_in, H, Hp)
-        frozen = torch.ones(E1, dtype=torch.uint8, device=h_in.device)
-        frozen.index_fill_(0, submess, 0)
-        pred = csr_from_padded(_scatter_rows(E1, bgraph_sub, submess), ncols=E1)
+        frozen, pred, _ = _sparse_structure(E1, submess, bgraph_sub)
         Ws, bs = (W_i, W_o, W_u, W_f), (b_i, b_o, b_u, b_f)
         ldx = _ld(x_sub)
         Xs = torch.empty(4, ms, Hp, **f32)
