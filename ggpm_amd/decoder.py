@@ -430,6 +430,47 @@ class HierMPNDecoder(ScoreHeads):
         return F_.gru_sparse(h0, hmess, rows, dag, rnn.W_z.weight, rnn.W_z.bias, rnn.W_r.weight, rnn.U_r.weight,
                              rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias, depth, I, H)
 
+    # ---- the atom level ahead of the encoder ---------------------------------------------------------------------------
+    # Teacher forcing makes the decoder's atom level (and its backward) independent of the latent vector: it reads the
+    # molecule's own bonds and the decoder's parameters only.  ``start_atom_level`` therefore issues it on its own stream
+    # BEFORE the encoder runs (HierPropertyVAE.forward), so that two chains of small latency-bound launches share the GPU
+    # instead of queueing behind each other; autograd runs a node's backward on the stream of its forward, so the backward
+    # overlaps the encoder's backward the same way.  GGPM_ATOM_AHEAD=0 switches it off.
+    _ATOM_STREAMS = {}
+
+    def start_atom_level(self, schedule, tensors) -> bool:
+        self._atom_ahead = None
+        if (schedule is None or os.environ.get("GGPM_ATOM_AHEAD", "1") == "0" or os.environ.get("GGPM_ATOM_DECODE", "1") == "0"
+                or os.environ.get("GGPM_DECODER_BATCHED", "1") == "0"):
+            return False
+        tree_tensors, graph_tensors = tensors
+        dev = tree_tensors[0].device
+        if dev.type != "cuda" or not (schedule.plan["all_live"] and schedule.plan["E1"] > 1):
+            return False
+        ap = schedule.atom_plan(graph_tensors[0].size(0), graph_tensors[1].size(0))
+        if not ap.ok:
+            return False
+        D = schedule.to_device(dev)._dev
+        main = torch.cuda.current_stream(dev)
+        side = self._ATOM_STREAMS.get(dev.index)
+        if side is None:
+            side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
+        self._atom_ahead = (schedule, pooled_all, cand, side)
+        return True
+
+    def _atom_level(self, schedule, D, graph_tensors):
+        """(pooled cluster vectors of all visits, attachment-candidate atom vectors, plan) through atom_decode."""
+        from .atom_decode import atom_decode
+        hmpn, T = self.hmpn, D["plan"]
+        graph_emb = hmpn.embed_graph(graph_tensors)
+        fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
+        ap = schedule.atom_plan(graph_tensors[0].size(0), graph_tensors[1].size(0))
+        pooled_all, cand = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all)
+        return pooled_all, cand, ap
+
     def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
         """Same vectors as ``_states_stepwise`` with the two tree-side levels de-sequentialised: only the atom level
         (diterG interacting iterations per step) keeps the step loop; the attachment and motif levels are ONE call each
@@ -441,22 +482,28 @@ class HierMPNDecoder(ScoreHeads):
         izeros = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
         n_gnodes = graph_tensors[0].size(0)
         hgraph = IE.HTuple(mess=rnn_cell.get_init_state(graph_tensors[1]))
-        graph_emb = hmpn.embed_graph(graph_tensors)
-        # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
-        # feature rows of all steps are selected by one gather each
-        fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
         pooled, assm_vecs, assm_dest = [], [], []
         off, aoff, boff = P["inst_off"], P["atom_off"], P["bond_off"]
+        ahead, self._atom_ahead = getattr(self, "_atom_ahead", None), None
         ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if os.environ.get("GGPM_ATOM_DECODE", "1") != "0" else None
         if ap is not None and ap.ok:                        # ---- atom level as ONE autograd node (atom_decode.py)
-            from .atom_decode import atom_decode
-            pooled_all, cand = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all)
+            if ahead is not None and ahead[0] is schedule:  # issued before the encoder on its own stream: join it here
+                _, pooled_all, cand, side = ahead
+                main = torch.cuda.current_stream(dev)
+                main.wait_stream(side)
+                pooled_all.record_stream(main); cand.record_stream(main)
+            else:
+                pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
             meta = ap.to_device(dev)["meta"]
             for k, base, n in ap.cand_blocks:
                 assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
                 assm_dest.append(meta[k]["dest"])
             steps = []
         else:
+            # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
+            # feature rows of all steps are selected by one gather each
+            graph_emb = hmpn.embed_graph(graph_tensors)
+            fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
             fmess_all = graph_emb[1].index_select(0, T["bonds_all"])
             steps = D["steps"]
         for t, st in enumerate(steps):                      # ---- atom level, step by step (fallback)

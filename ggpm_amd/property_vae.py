@@ -169,6 +169,7 @@ class HierPropertyVAE(nn.Module):
 
     def forward(self, mols, graphs, tensors, orders, homos=None, lumos=None, beta=0.0, perturb_z=True, schedule=None):
         tree_tensors, graph_tensors = tensors = make_cuda(tensors)
+        self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
         root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
         root_vecs, kl_div = rsample(root_vecs, self.R_mean, self.R_var, perturb_z)
         loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,
