@@ -479,7 +479,29 @@ class VaeWorkload:
                           "%.3f s, %d threads" % (cfg["batch"], len(times), med, cores)}
 
 
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout; libraries write there too (RCCL prints a version banner when the first
+    communicator comes up).  From here on fd 1 points at stderr and the result line goes to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -545,7 +567,7 @@ def main():
 
     if a.only_vae:
         vae = VaeWorkload(cfg, rnn, a, dev)
-        print(json.dumps({"vae_step": vae.measure()}), flush=True)
+        _emit({"vae_step": vae.measure()})
         return
     main_wl = Workload(cfg, rnn, a, rank, world, dev, gate_dtype=a.dtype)
     m = main_wl.measure(lib, rank)
@@ -629,7 +651,7 @@ def main():
             else:
                 result["lstm"]["cpu_baseline"] = cb
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        _emit(result)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
