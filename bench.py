@@ -221,6 +221,11 @@ class Workload:
         # rank r draws the batches r, r+W, ... of the seed-indexed synthetic set (10 000 molecules = 313 batches)
         self.pool = make_batches(a.pool, cfg["batch"], seed0=1000 + rank * 313, gen=cfg["gen"], n_motif=n_motif,
                                  n_attach=n_attach)
+        if world > 1:
+            # balance the ranks by message count, not molecule count -- every rank steps through ITS batches in
+            # size order, so the batches the ranks work on at the same time are of similar size and the all-reduce waits
+            # less for the straggler (one rank: order unchanged, the same batches either way)
+            self.pool.sort(key=lambda tg: int(tg[1][1].shape[0]))
         self.dev_batches = [make_cuda(b) for b in self.pool]      # int64 index tensors resident in HBM before timing
         torch.manual_seed(0)
         self.model = HierEncoderVAE(make_args(rnn, cfg["hidden"], cfg["depth"], cfg["latent"], n_motif, n_attach)).to(dev)
