@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p, POINTER
 
 from . import build as _build
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, I, P]),
     "ggpm_gather_rows": (I, [P, I, P, I, I, P, I, I, I, P]),
     "ggpm_scatter_rows": (I, [P, I, P, I, I, P, I, I, P]),
+    "ggpm_adam_step": (I, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, I, P]),
     "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
     "ggpm_gru_pack_floats": (c_size_t, [I]),

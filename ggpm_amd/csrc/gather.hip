@@ -2,6 +2,7 @@
 // One wave owns one destination row and walks its (short) list; lanes stride the feature dimension
 // with 16-byte accesses when the strides allow it, so every load/store is a coalesced row segment.
 #include "common.h"
+#include <cmath>
 
 namespace {
 
@@ -174,6 +175,51 @@ __global__ void dropout_k(float* __restrict__ x, int rows, int cols, int ld, uns
     *p = ((h >> 8) >= thresh) ? *p * scale : 0.f;
 }
 }  // namespace
+
+namespace {
+// Adam (torch.optim.Adam's arithmetic, vae_train.py:60) over one flat fp32 buffer: 16 B per lane, grid-stride.
+__global__ void __launch_bounds__(256) adam_flat_k(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float b1,
+                                                   float b2, float eps, float wd, float step_size, float inv_bc2_sqrt) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = ggpm_ld4(p + 4 * i), gg = ggpm_ld4(g + 4 * i), mm = ggpm_ld4(m + 4 * i), vv = ggpm_ld4(v + 4 * i);
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = wd != 0.f ? G[k] + wd * P[k] : G[k];
+            M[k] = M[k] + (1.f - b1) * (gr - M[k]);
+            V[k] = b2 * V[k] + (1.f - b2) * gr * gr;
+            P[k] -= step_size * M[k] / (sqrtf(V[k]) * inv_bc2_sqrt + eps);
+        }
+        ggpm_st4(p + 4 * i, pp); ggpm_st4(m + 4 * i, mm); ggpm_st4(v + 4 * i, vv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // tail of up to three elements
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float gr = wd != 0.f ? g[i] + wd * p[i] : g[i];
+        const float mk = m[i] + (1.f - b1) * (gr - m[i]);
+        const float vk = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mk; v[i] = vk;
+        p[i] -= step_size * mk / (sqrtf(vk) * inv_bc2_sqrt + eps);
+    }
+}
+}  // namespace
+
+extern "C" int ggpm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!p || !g || !m || !v || n == 0 || step < 1) return GGPM_ERR_ARG;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return GGPM_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    size_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    adam_flat_k<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size,
+                                                                 inv_bc2_sqrt);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
 
 extern "C" int ggpm_dropout(float* x, int rows, int cols, int ld, float p, unsigned int seed_lo, unsigned int seed_hi,
                             int site, ggpm_stream_t stream) {

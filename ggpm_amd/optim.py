@@ -9,6 +9,8 @@ writes into it directly, so nothing is packed or copied for the optimizer either
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -26,6 +28,11 @@ class FlatAdam:
                 off += n
         self.flat = torch.nn.Parameter(flat)
         self.opt = torch.optim.Adam([self.flat], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=flat.is_cuda)
+        # on the GPU the step is ONE launch of ggpm_adam_step over the flat buffer (torch's fused Adam issues three
+        # multi-tensor launches for it); learning-rate schedulers keep working through ``param_groups``
+        self._hip = flat.is_cuda and os.environ.get("GGPM_HIP_ADAM", "1") != "0"
+        if self._hip:
+            self._m, self._v, self._t = torch.zeros_like(flat), torch.zeros_like(flat), 0
 
     @property
     def param_groups(self):
@@ -33,6 +40,16 @@ class FlatAdam:
 
     def step(self) -> None:
         """Call after ``sync.all_reduce()`` (which also gathers stray gradients into the flat buffer on one rank)."""
+        if self._hip:
+            from . import _lib
+            from . import functional as F_
+            g, grp = self.sync.flat, self.opt.param_groups[0]
+            self._t += 1
+            _lib.check(_lib.load().ggpm_adam_step(F_._p(self.flat.data), F_._p(g), F_._p(self._m), F_._p(self._v),
+                                                  self.flat.numel(), float(grp["lr"]), float(grp["betas"][0]),
+                                                  float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
+                                                  self._t, F_._stream()), "adam_step")
+            return
         self.flat.grad = self.sync.flat
         self.opt.step()
 

@@ -135,6 +135,11 @@ int ggpm_scatter_rows(const float* src, int ld_src, const int32_t* idx, int rows
  * inject the same mask into the oracle. */
 int ggpm_dropout(float* x, int rows, int cols, int ld, float p, unsigned int seed_lo, unsigned int seed_hi, int site,
                  ggpm_stream_t stream);
+/* One Adam step (torch.optim.Adam's arithmetic; ggpm/../vae_train.py:60,83 `optimizer.step()`) over ONE flat fp32 buffer that
+ * all parameters are views of; p, g, m, v 16-byte aligned, n elements; step counts from 1.
+ *   m += (1-b1)(g' - m); v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  g' = g + wd p */
+int ggpm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, ggpm_stream_t stream);
 int ggpm_onehot(const int32_t* idx, int rows, int classes, float* out, int ld_out, int col_off, int zero_to,
                 ggpm_stream_t stream);
 /* embed_graph (ggpm/encoder.py:119-126) in one launch: hnode[N1, ld_n] = onehot(fnode), hmess[E1, ld_m] =

@@ -956,6 +956,27 @@ def test_colsum_matches_numpy(M, N, ld):
     assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.sqrt(M)) * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("n,wd", [(1, 0.0), (7, 0.0), (4096, 0.0), (300 * 620 + 3, 0.0), (1000, 0.01)])
+def test_adam_step_matches_torch_adam(n, wd):
+    """ggpm_adam_step (one launch over the flat parameter buffer, ggpm_amd/optim.py) against torch.optim.Adam, five steps."""
+    from ggpm_amd import _lib, functional as F_
+    dev = _dev()
+    torch.manual_seed(n)
+    p0 = torch.randn(n, device=dev)
+    grads = [torch.randn(n, device=dev) * (0.1 + k) for k in range(5)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lib = _lib.load()
+    for t, g in enumerate(grads, 1):
+        ref.grad = g.clone()
+        opt.step()
+        _lib.check(lib.ggpm_adam_step(F_._p(p), F_._p(g), F_._p(m), F_._p(v), n, 1e-2, 0.9, 0.999, 1e-8, wd, t, F_._stream()),
+                   "adam_step")
+        err = float((p - ref.detach()).abs().max())
+        assert err <= 2e-6 * max(1.0, float(ref.detach().abs().max())), (t, err)
+
+
 def test_scatter_rows_inverts_gather_rows():
     """ggpm_scatter_rows (unique indices, -1 = skip; store and accumulate) against numpy; with ggpm_gather_rows it is
     the round trip of the compact decode steps."""
