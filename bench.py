@@ -274,6 +274,7 @@ class Workload:
     def timed(self, steps, first):
         """EXACTLY `steps` steps between two fences; max over ranks.  -> (elapsed s, host enqueue s)"""
         import torch.distributed as dist
+        _settle_gc()
         self.fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -442,13 +443,20 @@ class VaeWorkload:
         for i in range(warm):
             m = self.step(i)
         torch.cuda.synchronize()
+        _settle_gc()
         t0 = time.perf_counter()
+        marks = [t0]
         for i in range(steps):
-            m = self.step(warm + i)
+            m = self.step(warm + i)              # (ends with the metrics' .item(): the host is in step with the GPU)
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         B = self.cfg["batch"]
-        log("full VAE step (%s): %.2f ms/step, loss %.3f" % (self.rnn, 1e3 * dt / steps, m["Loss"]))
+        raw = [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
+        per = sorted(raw)
+        log("full VAE step (%s): %.2f ms/step (per step: min %.2f, median %.2f, max %.2f at step %d; reserved %.1f GB), loss %.3f"
+            % (self.rnn, 1e3 * dt / steps, per[0], per[len(per) // 2], per[-1], raw.index(per[-1]),
+               torch.cuda.memory_reserved() / 1e9, m["Loss"]))
         return {"ms_per_step": round(1e3 * dt / steps, 3), "value": round(steps * B / dt, 2), "unit": "molecules/s",
                 "steps": steps, "warmup": warm, "rnn_type": self.rnn,
                 "workload": "HierPropertyVAE fwd (perturb_z) + bwd + Adam on the configs[1] batches: latent=%d, diterT=%d, "
@@ -485,6 +493,16 @@ class VaeWorkload:
 
 
 _REAL_STDOUT = None
+
+
+def _settle_gc():
+    """Before a timed region: collect what the warm-up left behind and move the survivors (model, batches, the decode
+    schedules' thousands of small index tables) to the permanent generation, so that a full collection falling into the
+    timed steps does not walk them again (one such pass cost 90 ms of a 30-step VAE measurement)."""
+    import gc
+    if os.environ.get("GGPM_BENCH_GC_FREEZE", "1") != "0":
+        gc.collect()
+        gc.freeze()
 
 
 def _claim_stdout():

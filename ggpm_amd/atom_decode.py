@@ -272,6 +272,9 @@ class AtomPlan:
         return self._dev
 
 
+_PACK_ONCE = os.environ.get("GGPM_PACK_ONCE", "1") != "0"      # (0: every decode step packs its weights again; dev A/B)
+
+
 def compact_enabled() -> bool:
     return os.environ.get("GGPM_ATOM_COMPACT", "1") != "0"
 
@@ -501,6 +504,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
             hs, qs = Hs_all[qoff[t]:qoff[t + 1]], Qs_all[roff[t]:roff[t + 1]]
             st = St_all[:, roff[t]:roff[t + 1]]
             fz, rp, col = _vp(frz_loc + plan.floc_off[t]), _vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)])
+            if t > 0 and _PACK_ONCE:
+                lib.ggpm_weights_packed(1)          # same weights, same `wpack`: packed by the first step
             if lstm:
                 c_in = torch.empty(n, Hp, **f32)
                 _lib.check(lib.ggpm_gather_rows(P(Cs_all), Hp, src, n, Hp, P(c_in), Hp, 0, 0, s), "gather_rows")
@@ -598,6 +603,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
             fz = _vp(frz_loc + plan.floc_off[t])
             csr = (_vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]))
             srcF = _vp(cp[("srcF", t)])
+            if t < T - 1 and _PACK_ONCE:
+                lib.ggpm_weights_packed(1)          # same weights, same `work`: the transposes were packed by the first call
             if lstm:
                 dcin = torch.empty(n, Hp, **f32)
                 lib.ggpm_backward_defer_stash(P(DG_all[0, roff[t]:]), P(DG_all[1, roff[t]:]), P(DG_all[2, roff[t]:]),

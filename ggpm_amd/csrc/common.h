@@ -80,6 +80,8 @@ int ggpm_take_wgrad_lo();
 // ggpm_backward_defer_stash (include/ggpm_hip.h): caller-owned gate-gradient stashes for the next sparse backward of this
 // thread.  -> true (and the pointers) once.
 bool ggpm_take_defer_stash(float* (&out)[4]);
+// ggpm_weights_packed (include/ggpm_hip.h): the next level / sparse call of this thread finds its packed weights in place.
+bool ggpm_take_weights_packed();
 
 // Gate-product dtype of the level calls issued by this thread: 0 fp32 (default), 1 bf16 operands.  Set by the encoder
 // drivers from ggpm_enc_dims.gate_dtype for the duration of their call (mpn_gru.hip).

@@ -683,6 +683,9 @@ extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float
     g_defer[0] = s0; g_defer[1] = s1; g_defer[2] = s2; g_defer[3] = s3;
     g_defer_set = s0 != nullptr;
 }
+namespace { thread_local bool g_packed = false; }
+extern "C" void ggpm_weights_packed(int yes) { g_packed = yes != 0; }
+bool ggpm_take_weights_packed() { const bool v = g_packed; g_packed = false; return v; }
 bool ggpm_take_defer_stash(float* (&out)[4]) {
     const bool v = g_defer_set;
     for (int i = 0; i < 4; ++i) { out[i] = g_defer[i]; g_defer[i] = nullptr; }
@@ -697,6 +700,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
                             float* wpack, int save_for_backward, const float* h_in, const unsigned char* frozen,
                             ggpm_stream_t stream, const int32_t* pred_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
+    const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xz || !Xr || !Xh || !Wz_h || !Ur || !bu || !Wh_h || !pred_rowptr ||
         !pred_col || !Hs || !Qs || !wpack)
         return GGPM_ERR_ARG;
@@ -712,7 +716,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         GgpmPackArgs pk = {};
         pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
         pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = bu; pk.bias_out = pbu; pk.bf16 = bf16;
-        ggpm_launch_pack(pk, 3, s);
+        if (!weights_packed) ggpm_launch_pack(pk, 3, s);
     }
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
     const int tg0 = pick_tg(E1, Hp / 16);
@@ -829,6 +833,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  const unsigned char* frozen, float* dHin, ggpm_stream_t stream,
                                  ggpm_stream_t side_stream = nullptr, const int32_t* succ_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
+    const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
         !dWz_h || !dUr || !dbu || !dWh_h || !work)
@@ -839,7 +844,12 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 
+    // (the packed transposes come first: their place does not depend on E1, so a sequence of calls that shares one
+    // `work` buffer and one set of weights packs them once -- ggpm_weights_packed)
     float* w = work;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWzT = w; float* pWhT = w + mstep; float* pUrT = w + 2 * mstep; w += 3 * HH;
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
     float* DQ = w; w += (size_t)depth * slot;
@@ -847,9 +857,6 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dGb[0] = w; w += slot; dGb[1] = w; w += slot;
     float* DSD = w; w += slot;
     float* carry = w; w += slot;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
-    float* pWzT = w; float* pWhT = w + mstep; float* pUrT = w + 2 * mstep; w += 3 * HH;
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
@@ -866,7 +873,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         GgpmPackArgs pk = {};
         pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
         pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWzT; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
-        ggpm_launch_pack(pk, 3, s);
+        if (!weights_packed) ggpm_launch_pack(pk, 3, s);
     }
     // dXz / dXh are started (not accumulated) by the first backward depth; so is dXr when that depth has a dS/dG product
     if (depth == 1 && !frozen) (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
@@ -1035,11 +1042,11 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* w = work;
+    float* w = work + 3 * HH;             // (layout of gru_backward_impl)
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
     float* DQ = w; w += (size_t)depth * slot;
-    w += 6 * slot + 3 * HH;
+    w += 6 * slot;
     float* csws = w; w += (size_t)256 * Hp;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);

@@ -566,6 +566,7 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
                              int save_for_backward, const float* h_in, const float* c_in,
                              const unsigned char* frozen, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
+    const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xi || !Xo || !Xu || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h ||
         !pred_rowptr || !pred_col || !Hs || !Cs || !Qs || !wpack)
         return GGPM_ERR_ARG;
@@ -582,7 +583,7 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
         pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
         pk.H = H; pk.Hp = Hp; pk.transpose = 0; pk.dst = wpack; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
-        ggpm_launch_pack(pk, 4, s);
+        if (!weights_packed) ggpm_launch_pack(pk, 4, s);
     }
     const int tg = pick_tg(E1, Hp / 16);
     if (frozen) {      // sparse_forward: start from the caller's (h, c); qf^0 = Wf_h h^0 by one B launch
@@ -683,6 +684,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
                                   size_t work_bytes, int weight_grads, const unsigned char* frozen,
                                   const float* dCD, float* dHin, float* dCin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
+    const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Cs || !Qs || !Ss || !Is || !Os || !Us || !Fs || !dHD || !dXi || !dXo || !dXu ||
         !dXf || !dWi_h || !dWo_h || !dWu_h || !dWf_h || !work)
@@ -693,7 +695,11 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 
+    // (the packed transposes come first: their place does not depend on E1 -- ggpm_weights_packed)
     float* w = work;
+    const int bf16 = ggpm_gate_dtype();
+    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep; w += 4 * HH;
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
@@ -701,9 +707,6 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     float* dSb[2]; float* dFb[2];
     dSb[0] = w; w += slot; dSb[1] = w; w += slot; dFb[0] = w; w += slot; dFb[1] = w; w += slot;
     float* carry_h = w; w += slot; float* carry_c = w; w += slot;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
-    float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep; w += 4 * HH;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     {       // deferred weight gradients (ggpm_backward_defer_stash): the stashes go to the caller's stacked buffers
@@ -721,7 +724,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         pk.W[0] = Wi_h; pk.ldw[0] = ld_wi; pk.W[1] = Wo_h; pk.ldw[1] = ld_wo; pk.W[2] = Wu_h; pk.ldw[2] = ld_wu;
         pk.W[3] = Wf_h; pk.ldw[3] = ld_wf;
         pk.H = H; pk.Hp = Hp; pk.transpose = 1; pk.dst = pWiT; pk.bias = nullptr; pk.bias_out = nullptr; pk.bf16 = bf16;
-        ggpm_launch_pack(pk, 4, s);
+        if (!weights_packed) ggpm_launch_pack(pk, 4, s);
     }
     // dXi / dXo / dXu / dXf are started (not accumulated) by the first backward depth
     if (frozen) {
@@ -817,12 +820,12 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* w = work;
+    float* w = work + 4 * HH;             // (layout of lstm_backward_impl)
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
     float* DQ = w; w += (size_t)depth * slot;
-    w += 6 * slot + 4 * HH;
+    w += 6 * slot;
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = (depth - lo + 1) * E1;

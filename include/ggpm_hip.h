@@ -286,7 +286,11 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
  *   Ss), s3 = DQ (pairs with Hs, as above).  One call consumes the setting.
  *   ggpm_*_weight_grads_stacked: rows = total stash rows (sum over the calls of depth*E1), rows_q = total rows of the
  *   DQ / Hs stacks (sum of (depth+1)*E1); every buffer holds the calls' blocks in the same order.  Outputs are
- *   overwritten.  work: ggpm_weight_grads_stacked_workspace_bytes(H, max(rows, rows_q)). */
+ *   overwritten.  work: ggpm_weight_grads_stacked_workspace_bytes(H, max(rows, rows_q)).
+ *   ggpm_weights_packed(1): the NEXT forward / backward / sparse call of this thread skips packing its gate weights: `wpack`
+ *   (forward) resp. the head of `work` (backward) still holds the fragments an earlier call with the SAME weights and
+ *   the same buffer left there -- the decode steps share one set of weights.  One call consumes the setting. */
+void ggpm_weights_packed(int yes);
 void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
 size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows);
 int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const float* DMP, const float* Gs, const float* DZP,
