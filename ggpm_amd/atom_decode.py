@@ -272,6 +272,40 @@ class AtomPlan:
         return self._dev
 
 
+class DecodeSteps(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_decode_steps (host arrays of per-step sizes / device pointers)."""
+    _fields_ = [("T", ctypes.c_int), ("H", ctypes.c_int), ("depth", ctypes.c_int), ("lstm", ctypes.c_int),
+                ("n", ctypes.c_void_p), ("foff", ctypes.c_void_p), ("roff", ctypes.c_void_p), ("qoff", ctypes.c_void_p),
+                ("srcH", ctypes.c_void_p), ("srcF", ctypes.c_void_p), ("frozen", ctypes.c_void_p),
+                ("pred_rowptr", ctypes.c_void_p), ("pred_col", ctypes.c_void_p), ("succ_rowptr", ctypes.c_void_p),
+                ("succ_col", ctypes.c_void_p)]
+
+
+def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
+    """The ggpm_decode_steps descriptor of (plan, device, depth, cell), built once (it only names resident tables)."""
+    key = ("steps", depth, bool(lstm), H)
+    hit = ct["dev"].get((D["device"], key))
+    if hit is not None:
+        return hit
+    T, ptr = plan.T, D["ptr"]
+    roff, qoff = plan.row_offsets(depth)
+    arr32 = (ctypes.c_int32 * T)(*plan.nloc)
+    a64 = lambda v: (ctypes.c_int64 * (T + 1))(*[int(x) for x in v])
+    pa = lambda vals: (ctypes.c_void_p * T)(*[int(v) for v in vals])
+    frz = D["frozen_loc"].data_ptr()
+    keep = dict(n=arr32, foff=a64(ct["foff"]), roff=a64(roff), qoff=a64(qoff),
+                srcH=pa(cp[("srcH", t)] for t in range(T)), srcF=pa(cp[("srcF", t)] for t in range(T)),
+                frozen=pa(frz + plan.floc_off[t] for t in range(T)),
+                pred_rowptr=pa(ptr[("lpred_rp", t)] for t in range(T)), pred_col=pa(ptr[("lpred_col", t)] for t in range(T)),
+                succ_rowptr=pa(ptr[("lsucc_rp", t)] for t in range(T)), succ_col=pa(ptr[("lsucc_col", t)] for t in range(T)))
+    d = DecodeSteps(T, H, depth, int(lstm), *[ctypes.cast(keep[k], ctypes.c_void_p) for k in
+                                               ("n", "foff", "roff", "qoff", "srcH", "srcF", "frozen", "pred_rowptr",
+                                                "pred_col", "succ_rowptr", "succ_col")])
+    ct["dev"][(D["device"], key)] = (d, keep)
+    return d, keep
+
+
+_DRIVER = os.environ.get("GGPM_DECODE_DRIVER", "1") != "0"    # (0: the step loops are issued from Python; dev A/B, tests)
 _PACK_ONCE = os.environ.get("GGPM_PACK_ONCE", "1") != "0"      # (0: every decode step packs its weights again; dev A/B)
 
 
@@ -432,28 +466,7 @@ class _AtomDecode(torch.autograd.Function):
             dH, dH2 = dH2, dH
             torch._foreach_add_([dX_tot] + acc, [dX] + tmp)
         # ---- parameter gradients, once
-        x_ld = F_._ld(hmess)
-
-        def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
-            dW = torch.empty_like(W)
-            F_.gemm(1, 0, H, I, E1, dX_tot[k], Hp, hmess, x_ld, dW, dW.stride(0), I, splitk=True)
-            if hidden is not None:
-                dW[:, I:] = hidden
-            return dW
-
-        dWout = torch.empty_like(Wout)
-        F_.gemm(1, 0, H, Fdim, ns_tot, DPRE, Hp, fn_all, F_._ld(fn_all), dWout, dWout.stride(0), Fdim, splitk=True)
-        F_.gemm(1, 0, H, H, ns_tot, DPRE, Hp, NEI, Hp, dWout[:, Fdim:], dWout.stride(0), H, splitk=True)
-        dbout = F_.colsum(DPRE, ns_tot, H)
-        if lstm:
-            grads = []
-            for k, W in enumerate((Wi, Wo_g, Wu, Wf)):
-                grads += [full(W, k, acc[k]), F_.colsum(dX_tot[k], E1, H)]
-            grads += [dWout, dbout]
-        else:          # tmp / acc order of the GRU: Wz_h, U_r, Wh_h, b_u
-            grads = [full(Wz, 0, acc[0]), F_.colsum(dX_tot[0], E1, H), full(Wr, 1, None), acc[1], acc[3],
-                     full(Wh, 2, acc[2]), F_.colsum(dX_tot[2], E1, H), dWout, dbout]
-        return (None,) * 9 + tuple(grads)
+        return (None,) * 9 + _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot)
 
 
 class _AtomDecodeCompact(torch.autograd.Function):
@@ -495,7 +508,19 @@ class _AtomDecodeCompact(torch.autograd.Function):
         St_all = torch.empty(5, roff[-1], Hp, **f32)
         wpack = torch.empty(int(lib.ggpm_lstm_pack_floats(H) if lstm else lib.ggpm_gru_pack_floats(H)), **f32)
         frz_loc = D["frozen_loc"].data_ptr()
-        for t in range(T):
+        if lstm:
+            hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
+        else:
+            hw = ((Wz, I), (Ur, 0), (Wh, I))
+        W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
+        ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
+        if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
+            desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
+            tmp = torch.empty(2 * max(plan.nloc), Hp, **f32)
+            _lib.check(lib.ggpm_decode_steps_forward(
+                ctypes.byref(desc), W_arr, ld_arr, None if lstm else P(bu), P(X_all), P(Hs_all), P(Cs_all) if lstm else None,
+                P(Qs_all), P(St_all), St_all.stride(0), P(wpack), P(tmp), s), "decode_steps_forward")
+        for t in (() if _DRIVER else range(T)):
             n = plan.nloc[t]
             src = _vp(cp[("srcH", t)])
             h_in = torch.empty(n, Hp, **f32)
@@ -594,7 +619,21 @@ class _AtomDecodeCompact(torch.autograd.Function):
         wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         frz_loc = D["frozen_loc"].data_ptr()
-        for t in range(T - 1, -1, -1):
+        if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
+            if lstm:
+                hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
+            else:
+                hw = ((Wz, I), (Ur, 0), (Wh, I))
+            W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
+            ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
+            desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
+            tmp = torch.empty(2 * nmax, Hp, **f32)
+            dW_arr = (ctypes.c_void_p * 4)(*([a.data_ptr() for a in acc] + ([] if len(acc) == 4 else [0])))
+            _lib.check(lib.ggpm_decode_steps_backward(
+                ctypes.byref(desc), W_arr, ld_arr, P(X_all), P(Hs_all), P(Cs_all) if lstm else None, P(Qs_all), P(St_all),
+                St_all.stride(0), P(dF), P(dCF) if lstm else None, P(dX_all), P(DG_all), DG_all.stride(0), P(DQ_all), dW_arr,
+                P(work), work.numel() * 4, P(tmp), s), "decode_steps_backward")
+        for t in (() if _DRIVER else range(T - 1, -1, -1)):
             n = plan.nloc[t]
             dhd, dhin = dF[foff[t]:foff[t + 1]], torch.empty(n, Hp, **f32)
             dx = dX_all[G * foff[t]:G * foff[t + 1]].view(G, n, Hp)

@@ -302,6 +302,36 @@ int ggpm_lstm_weight_grads_stacked(int rows, int rows_q, int H, const float* DI,
                                    float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu, float* dWf_h, int ld_dwf, float* work,
                                    size_t work_bytes, ggpm_stream_t stream);
 
+/* The atom level's decode loop as ONE call per direction (ggpm/decoder.py:201-222 -> ggpm/encoder.py:235-239,165-179 once per
+ * step, on the compact row sets of ggpm_amd/atom_decode.py): per step `gather the frozen rows from the stacked state buffer ->
+ * ggpm_*_sparse_forward`, backwards `ggpm_*_sparse_backward (stashes deferred, see above) -> scatter-add of dHin to the rows'
+ * producers`.  All arrays of the descriptor are HOST arrays of length T (T + 1 for the offsets); the pointers in them are
+ * device pointers.  foff: first F id (one per (step, local row)) of a step; roff / qoff: first row of the step's [depth][n]
+ * resp. [depth + 1][n] block in the stacked stash / state buffers.  X_all: the steps' gate inputs [G][n][Hp] per step at row
+ * G * foff[t]; St_all: five stash kinds, `st_stride` floats apart; DG_all likewise (two kinds GRU, three LSTM).
+ * W / ldw: hidden halves, GRU {Wz_h, U_r, Wh_h} (+ bu), LSTM {Wi_h, Wo_h, Wu_h, Wf_h}.  tmp: 2 * max(n) * Hp floats.
+ * dW_unused: four H x H (ld H) scratch outputs the deferred backward leaves untouched (GRU: [3] = H floats). */
+typedef struct ggpm_decode_steps {
+    int T, H, depth, lstm;
+    const int32_t* n;
+    const int64_t *foff, *roff, *qoff;
+    const int32_t* const* srcH;          /* rows of Hs_all / Cs_all a step's frozen rows are read from (-1: zero) */
+    const int32_t* const* srcF;          /* the same as F ids (where the backward adds dHin / dCin) */
+    const unsigned char* const* frozen;
+    const int32_t* const* pred_rowptr;
+    const int32_t* const* pred_col;
+    const int32_t* const* succ_rowptr;
+    const int32_t* const* succ_col;
+} ggpm_decode_steps;
+int ggpm_decode_steps_forward(const ggpm_decode_steps* steps, const float* const* W, const int* ldw, const float* bu,
+                              const float* X_all, float* Hs_all, float* Cs_all, float* Qs_all, float* St_all, size_t st_stride,
+                              float* wpack, float* tmp, ggpm_stream_t stream);
+int ggpm_decode_steps_backward(const ggpm_decode_steps* steps, const float* const* W, const int* ldw, const float* X_all,
+                               const float* Hs_all, const float* Cs_all, const float* Qs_all, const float* St_all,
+                               size_t st_stride, float* dF, float* dCF, float* dX_all, float* DG_all, size_t dg_stride,
+                               float* DQ_all, float* const* dW_unused, float* work, size_t work_bytes, float* tmp,
+                               ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ decoder score-head losses
  * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in
  * (ggpm/decoder.py:66-69,143-157,268-271): z[m,:] = logits[m,:] + mask[mask_row[m],:] (mask / mask_row both null for
