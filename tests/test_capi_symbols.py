@@ -30,6 +30,33 @@ def test_library_builds_and_exports_every_symbol():
     assert lib.ggpm_gemm_workspace_bytes(300, 300, 100) == 0
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The two structs that cross the C ABI (ggpm_enc_dims, ggpm_decode_steps): a C program compiled against
+    include/ggpm_hip.h prints sizeof and every field offset; the ctypes mirrors must agree."""
+    import ctypes
+    import subprocess
+    from ggpm_amd.atom_decode import DecodeSteps
+    from ggpm_amd.fused import EncDims
+    structs = {"ggpm_enc_dims": EncDims, "ggpm_decode_steps": DecodeSteps}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('printf("\\n");')
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ggpm_hip.h"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % "\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    for line in filter(None, out):
+        name, *nums = line.split()
+        cls = structs[name]
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in nums] == want, (name, nums, want)
+
+
 def test_product_path_refuses_cpu_tensors():
     """No CPU fallback: the wrappers raise instead of silently computing elsewhere."""
     import pytest

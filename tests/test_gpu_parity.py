@@ -902,7 +902,7 @@ def _vae_names():
     return vae_case_names()
 
 
-@pytest.mark.parametrize("mode", ["batched", "batched_inline", "batched_full", "levels", "stepwise"])
+@pytest.mark.parametrize("mode", ["batched", "batched_inline", "batched_pyloop", "batched_full", "levels", "stepwise"])
 @pytest.mark.parametrize("name", _vae_names())
 def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     """The full VAE training step -- HierPropertyVAE.forward (ggpm/property_vae.py:47-62): encoder, rsample, the
@@ -912,12 +912,16 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     loop, three incremental-encoder calls per step), ``levels`` (the attachment and motif levels as ONE level call each
     over the decode-time DAG of their messages, the atom level stepping through the incremental encoder) and ``batched``
     (default: additionally the atom level's step loop as one autograd node on host-built index tables, atom_decode.py,
-    issued on its own stream ahead of the encoder; ``batched_inline`` keeps it in program order, ``batched_full`` runs
+    issued on its own stream ahead of the encoder; ``batched_inline`` keeps it in program order, ``batched_pyloop``
+    additionally issues the step loops from Python instead of through ggpm_decode_steps_*, ``batched_full`` runs
     its steps over all rows of the level instead of compact row sets)."""
     monkeypatch.setenv("GGPM_DECODER_BATCHED", "0" if mode == "stepwise" else "1")
     monkeypatch.setenv("GGPM_ATOM_DECODE", "1" if mode.startswith("batched") else "0")
     monkeypatch.setenv("GGPM_ATOM_COMPACT", "0" if mode == "batched_full" else "1")     # compact row sets per decode step
     monkeypatch.setenv("GGPM_ATOM_AHEAD", "1" if mode == "batched" else "0")
+    if mode == "batched_pyloop":        # the decode step loops issued from Python instead of csrc/decode.hip
+        import ggpm_amd.atom_decode as _ad
+        monkeypatch.setattr(_ad, "_DRIVER", False)
     from golden_utils import VaeGolden
     from ggpm_amd import synth
     from ggpm_amd.decoder import DecodeSchedule
