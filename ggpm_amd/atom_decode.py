@@ -569,6 +569,9 @@ class _AtomDecodeCompact(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_pooled, d_cand):
         lib = _lib.load()
+        # everything upstream of the atom level (heads, the two tree-side levels) has run its backward: their queued
+        # weight-gradient contractions can start now, beside this node and the encoder's backward
+        F_.flush_deferred_early()
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
         lstm = cell == "LSTM"
         sv = list(ctx.saved_tensors)

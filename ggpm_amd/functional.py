@@ -492,7 +492,7 @@ def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
 # backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
 # visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
 # parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
-_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None}
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None, "early": None}
 
 
 def defer_wgrads_enabled() -> bool:
@@ -529,38 +529,77 @@ def _add_to_grad(param, g) -> None:
         param.grad.add_(g)
 
 
-def _defer_flush() -> None:
+def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
+    """Form the queued parameter gradients.  ``side`` = None: the end-of-backward callback, on the stream the entries
+    were queued on.  ``side`` given (flush_deferred_early): on that stream, ordered behind everything the queueing
+    stream has been given so far; the queueing stream re-joins at the end of the backward pass."""
     lin, sums, gath = dict(_DEFER["linear"]), dict(_DEFER["sum"]), dict(_DEFER["gather"])
     _DEFER["linear"].clear()
     _DEFER["sum"].clear()
     _DEFER["gather"].clear()
     _DEFER["registered"] = False
-    with torch.cuda.stream(_DEFER["stream"]):
+    main = _DEFER["stream"]
+    if not (lin or sums or gath) or main is None:
+        return
+    stream = main
+    if side is not None:
+        side.wait_stream(main)
+        stream = side
+        _DEFER["early"] = side
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+    elif _DEFER["early"] is not None:      # an early flush may still be writing the same .grad buffers
+        main.wait_stream(_DEFER["early"])
+        _DEFER["early"] = None
+
+    def use(t):                            # queued on `main`, read on `side`: keep the allocator from recycling it early
+        if side is not None and isinstance(t, torch.Tensor):
+            t.record_stream(side)
+        return t
+
+    def publish(param, g):
+        if side is not None:
+            g.record_stream(main)
+        _add_to_grad(param, g)
+
+    with torch.cuda.stream(stream):
         for weight, bias, Ks, visits in lin.values():
             N = weight.shape[0]
             if len(visits) == 1:
-                dpre, xs = visits[0]
+                dpre, xs = use(visits[0][0]), [use(x) for x in visits[0][1]]
             else:
-                dpre = torch.cat([v[0] for v in visits], dim=0)
-                xs = [torch.cat([v[1][i][:, :K] for v in visits], dim=0) for i, K in enumerate(Ks)]
+                dpre = torch.cat([use(v[0]) for v in visits], dim=0)
+                xs = [torch.cat([use(v[1][i])[:, :K] for v in visits], dim=0) for i, K in enumerate(Ks)]
             M = dpre.shape[0]
             dW = torch.empty_like(weight)
             o = 0
             for x, K in zip(xs, Ks):
                 gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW[:, o:], dW.stride(0), K, splitk=True)
                 o += K
-            _add_to_grad(weight, dW)
+            publish(weight, dW)
             if bias is not None:
-                _add_to_grad(bias, colsum(dpre, M, N))
+                publish(bias, colsum(dpre, M, N))
         for param, grads in sums.values():
-            _add_to_grad(param, grads[0] if len(grads) == 1 else torch.stack(grads, dim=0).sum(dim=0))
+            publish(param, use(grads[0]) if len(grads) == 1 else torch.stack([use(g) for g in grads], dim=0).sum(dim=0))
         for table, width, visits in gath.values():       # embedding tables: d(table)[id] = sum of the rows that used id
-            dout = visits[0][0] if len(visits) == 1 else torch.cat([v[0] for v in visits], dim=0)
-            idx = visits[0][1] if len(visits) == 1 else torch.cat([v[1].reshape(-1) for v in visits], dim=0)
+            dout = use(visits[0][0]) if len(visits) == 1 else torch.cat([use(v[0]) for v in visits], dim=0)
+            idx = use(visits[0][1]) if len(visits) == 1 else torch.cat([use(v[1]).reshape(-1) for v in visits], dim=0)
             csrT = csr_from_index(idx.reshape(-1), ncols=table.shape[0]).T
             dtable = torch.empty(table.shape, dtype=torch.float32, device=dout.device)
             _segment_sum_raw(dout, csrT, width, dtable)
-            _add_to_grad(table, dtable)
+            publish(table, dtable)
+
+
+def flush_deferred_early() -> None:
+    """Called from inside a backward pass at a point after which only nodes WITHOUT deferred gradients have much left to
+    do (the decoder's atom level and the encoder, once the heads and the tree-side levels have run): the queued
+    contractions start now on the second stream, beside that work, instead of behind it.  Whatever is queued later still
+    goes through the end-of-backward flush.  GGPM_DEFER_EARLY=0 switches it off."""
+    if os.environ.get("GGPM_DEFER_EARLY", "1") == "0" or not side_stream_enabled():
+        return
+    main = _DEFER["stream"]
+    if main is None or not _DEFER["registered"]:
+        return
+    _defer_flush(side=_side_stream(main.device))
 
 
 # ----------------------------------------------------------------------------- persistent depth loops
