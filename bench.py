@@ -649,6 +649,10 @@ def main():
     vae = None
     if a.config == 1 and world == 1 and not a.no_vae and not a.host_input:
         try:
+            main_wl = other = None               # (their models, device batches and cached blocks are not the VAE row's business)
+            import gc
+            gc.unfreeze()
+            gc.collect()
             torch.cuda.empty_cache()
             vae = VaeWorkload(cfg, rnn, a, dev)
             result["vae_step"] = vae.measure()
