@@ -364,6 +364,25 @@ def test_atom_plan_compact_row_sets_match_the_level_wide_tables():
     assert len(rpT) == G * E1 + 1 and all(np.all(xr[colT[rpT[r]:rpT[r + 1]]] == r) for r in range(G * E1))
 
 
+def test_decode_schedule_with_its_plans_survives_pickling():
+    """The decoder's host bookkeeping (DecodeSchedule + AtomPlan + compact tables, ~40 ms of numpy per batch of 32) is
+    meant to be built by data-loader workers: it must cross a process boundary unchanged."""
+    import pickle
+    from ggpm_amd.decoder import DecodeSchedule
+    specs = synth.random_batch(5, 4, motifs=(2, 6), n_motif_vocab=30, n_attach_vocab=90)
+    tensors = synth.tensorize(specs)
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    plan = sch.atom_plan(tensors[1][0].shape[0], tensors[1][1].shape[0])
+    ct = plan.compact_tables(5, 4)
+    back = pickle.loads(pickle.dumps(sch))
+    plan2 = back.atom_plan(tensors[1][0].shape[0], tensors[1][1].shape[0])
+    assert plan2 is back._atom_plan and plan2.T == plan.T and plan2.nloc == plan.nloc
+    assert np.array_equal(plan2.ints, plan.ints) and np.array_equal(plan2.frozen_loc, plan.frozen_loc)
+    ct2 = plan2.compact_tables(5, 4)
+    assert np.array_equal(ct2["ints"], ct["ints"]) and ct2["where"] == ct["where"] and ct2["foff"] == ct["foff"]
+    assert all(np.array_equal(back.plan[k], v) if isinstance(v, np.ndarray) else True for k, v in sch.plan.items())
+
+
 @pytest.mark.parametrize("name", vae_case_names())
 def test_oracle_vae_step_matches_reference(name):
     """oracle/ref_decoder.py (HierPropertyVAE.forward: encoder, rsample, teacher-forced decoder with enum_attach, the
