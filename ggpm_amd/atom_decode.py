@@ -240,11 +240,8 @@ class AtomPlan:
         """-> (tables dict, {key: device address}) of compact_tables on ``device`` (uploaded once)."""
         ct = self.compact_tables(depth, gates)
         if device not in ct["dev"]:
-            h = torch.from_numpy(ct["ints"])
-            if torch.device(device).type == "cuda":
-                h = h.pin_memory()
-            d = h.to(device, non_blocking=True)
-            ct["dev"][device] = (d, h, {k: d.data_ptr() + 4 * off for k, (off, _) in ct["where"].items()})
+            d = F_.upload(ct["ints"], device)
+            ct["dev"][device] = (d, None, {k: d.data_ptr() + 4 * off for k, (off, _) in ct["where"].items()})
         return ct, ct["dev"][device][2]
 
     def gate_rows(self, t: int, gates: int) -> np.ndarray:
@@ -255,20 +252,13 @@ class AtomPlan:
 
     def to_device(self, device):
         if self._dev is None or self._dev["device"] != device:
-            cuda = torch.device(device).type == "cuda"
-            hi, hf = torch.from_numpy(self.ints), torch.from_numpy(self.frozen)
-            hl = torch.from_numpy(self.frozen_loc)
-            if cuda:
-                hi, hf, hl = hi.pin_memory(), hf.pin_memory(), hl.pin_memory()
-            di, df = hi.to(device, non_blocking=True), hf.to(device, non_blocking=True)
-            dl = hl.to(device, non_blocking=True)
+            di, df, dl = F_.upload(self.ints, device), F_.upload(self.frozen, device), F_.upload(self.frozen_loc, device)
             base = di.data_ptr()
             ptr = {k: base + 4 * off for k, (off, n) in self.where.items()}
-            meta = {k: {n: torch.from_numpy(v).to(device, non_blocking=True) for n, v in m.items()}
-                    for k, m in self.cand_meta.items()}
+            meta = {k: {n: F_.upload(v, device) for n, v in m.items()} for k, m in self.cand_meta.items()}
             for m in meta.values():
                 m["icls"] = m["icls"].to(torch.int32)
-            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta, keep=(hi, hf, hl))
+            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta)
         return self._dev
 
 

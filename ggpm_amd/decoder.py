@@ -282,10 +282,8 @@ class DecodeSchedule:
         tail = dict(topo_batch=put(tb), topo_label=put(tl), cls_batch=put(cb), cls_clab=put(cc), cls_ilab=put(ci),
                     assm_batch=put(np.repeat(np.asarray(ab, dtype=np.int64), self.max_cls_size)))
         flat = np.concatenate(chunks) if chunks else np.zeros(0, np.int64)
-        hostbuf = torch.from_numpy(flat)
-        if torch.device(device).type == "cuda":
-            hostbuf = hostbuf.pin_memory()
-        devbuf = hostbuf.to(device, non_blocking=True)
+        hostbuf = None
+        devbuf = F_.upload(flat, device)
         dev32 = devbuf.to(torch.int32)          # embedding ids are int32 for the gather kernels (one conversion per batch)
         view = lambda k: devbuf[where[k][0]:where[k][0] + where[k][1]]
         view32 = lambda k: dev32[where[k][0]:where[k][0] + where[k][1]]

@@ -123,6 +123,46 @@ def prefetch_transposes(csrs: Sequence["CSR"]) -> None:
         c._T_event = ev
 
 
+class _StagingRing:
+    """Pinned staging for host -> device uploads of numpy tables (decode schedules, atom plans): ``pin_memory()`` on a
+    fresh tensor is a cudaHostAlloc of several milliseconds per call -- more than the copy -- so the bytes go through a
+    small ring of pinned buffers that are allocated once and grow on demand."""
+
+    def __init__(self, slots: int = 4):
+        self.slots, self.bufs, self.events, self.i = slots, [None] * slots, [None] * slots, 0
+
+    def upload(self, a, device) -> torch.Tensor:
+        import numpy as np
+        a = np.ascontiguousarray(a)
+        out = torch.empty(a.shape, dtype=torch.from_numpy(a[:0].reshape(0)).dtype, device=device)
+        if a.size == 0:
+            return out
+        if torch.device(device).type != "cuda":
+            out.copy_(torch.from_numpy(a))
+            return out
+        k = self.i
+        self.i = (self.i + 1) % self.slots
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # slot reuse: its previous copy must have left the buffer
+        if self.bufs[k] is None or self.bufs[k].numel() < a.nbytes:
+            self.bufs[k] = torch.empty(max(a.nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self.bufs[k][:a.nbytes]
+        stage.copy_(torch.from_numpy(a.reshape(-1).view(np.uint8)))
+        out.view(-1).view(torch.uint8).copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
+_STAGING = _StagingRing()
+
+
+def upload(a, device) -> torch.Tensor:
+    """numpy array -> device tensor of the same dtype and shape through the pinned staging ring (asynchronous)."""
+    return _STAGING.upload(a, device)
+
+
 _MEMO_ON = os.environ.get("GGPM_INDEX_MEMO", "1") != "0"
 
 
