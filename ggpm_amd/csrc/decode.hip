@@ -37,28 +37,30 @@ extern "C" int ggpm_decode_steps_forward(const ggpm_decode_steps* d, const float
     const int H = d->H, Hp = ggpm_padded_hidden(H), G = d->lstm ? 4 : 3;
     int nmax = 0;
     for (int t = 0; t < d->T; ++t) nmax = d->n[t] > nmax ? d->n[t] : nmax;
-    float* h_in = tmp;
-    float* c_in = tmp + (size_t)nmax * Hp;
+    (void)tmp;
     for (int t = 0; t < d->T; ++t) {
         const int n = d->n[t];
         const Offs o = offs(d, t);
-        int rc = ggpm_gather_rows(Hs_all, Hp, d->srcH[t], n, Hp, h_in, Hp, 0, 0, stream);
-        if (rc) return rc;
         const float* x = X_all + (size_t)G * o.f0 * Hp;
         const size_t xs = (size_t)n * Hp;
         float* hs = Hs_all + o.q0 * Hp;
         float* qs = Qs_all + o.r0 * Hp;
         float* st[5];
         for (int k = 0; k < 5; ++k) st[k] = St_all + (size_t)k * st_stride + o.r0 * Hp;
+        // the step's start state straight into slot 0 of its block: frozen rows from the blocks of the steps that produced
+        // them, zero for the rows the step recomputes (srcH = -1) -- exactly the masked state sparse_forward would build
+        int rc = ggpm_gather_rows(Hs_all, Hp, d->srcH[t], n, Hp, hs, Hp, 0, 0, stream);
+        if (rc) return rc;
         if (t > 0) ggpm_weights_packed(1);      // same weights, same `wpack`: packed by the first step
         if (d->lstm) {
-            rc = ggpm_gather_rows(Cs_all, Hp, d->srcH[t], n, Hp, c_in, Hp, 0, 0, stream);
+            float* cs = Cs_all + o.q0 * Hp;
+            rc = ggpm_gather_rows(Cs_all, Hp, d->srcH[t], n, Hp, cs, Hp, 0, 0, stream);
             if (rc) return rc;
-            rc = ggpm_lstm_sparse_forward(n, H, d->depth, h_in, c_in, d->frozen[t], x, x + xs, x + 2 * xs, x + 3 * xs, W[0],
+            rc = ggpm_lstm_sparse_forward(n, H, d->depth, hs, cs, d->frozen[t], x, x + xs, x + 2 * xs, x + 3 * xs, W[0],
                                           ldw[0], W[1], ldw[1], W[2], ldw[2], W[3], ldw[3], d->pred_rowptr[t], d->pred_col[t],
-                                          hs, Cs_all + o.q0 * Hp, qs, st[0], st[1], st[2], st[3], st[4], wpack, 1, stream);
+                                          hs, cs, qs, st[0], st[1], st[2], st[3], st[4], wpack, 1, stream);
         } else {
-            rc = ggpm_gru_sparse_forward(n, H, d->depth, h_in, d->frozen[t], x, x + xs, x + 2 * xs, W[0], ldw[0], W[1], ldw[1],
+            rc = ggpm_gru_sparse_forward(n, H, d->depth, hs, d->frozen[t], x, x + xs, x + 2 * xs, W[0], ldw[0], W[1], ldw[1],
                                          bu, W[2], ldw[2], d->pred_rowptr[t], d->pred_col[t], hs, qs, st[0], st[1], st[2],
                                          st[3], st[4], wpack, 1, stream);
         }

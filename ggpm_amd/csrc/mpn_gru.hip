@@ -721,7 +721,8 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
     const int tg0 = pick_tg(E1, Hp / 16);
     if (frozen) {      // sparse_forward: start from the caller's state, q^0 = U_r h^0 + b_u by one B launch
-        sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
+        // (h_in == Hs: the caller put the masked start state -- frozen rows' states, zero elsewhere -- into slot 0 itself)
+        if (h_in != Hs) sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
         GruFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu; a0.bf16 = bf16;
         const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);

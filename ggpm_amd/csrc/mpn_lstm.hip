@@ -588,7 +588,8 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
     const int tg = pick_tg(E1, Hp / 16);
     if (frozen) {      // sparse_forward: start from the caller's (h, c); qf^0 = Wf_h h^0 by one B launch
         dim3 ig(ggpm_ceil_div(Hp, 256), E1);
-        lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
+        // (h_in == Hs and c_in == Cs: the caller put the masked start state into slot 0 itself)
+        if (h_in != Hs || c_in != Cs) lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
         LstmFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf; a0.bf16 = bf16;
         const size_t lb = lds_tiles(1, Hp);
