@@ -312,7 +312,7 @@ struct GruBwdArgs {
     // sparse_forward only: frozen rows pass their gradient straight through the depth loop (carry), and a final
     // gather-only launch (t = 0) yields the gradient of the incoming state for them.
     const unsigned char* frozen;
-    float* carry;                  // [E1,Hp] running dh of frozen rows (zeroed by the driver)
+    float* carry;                  // [E1,Hp] running dh of frozen rows (started by the first backward depth)
     int final_pass;                // t == 0: P1 + dq.U_r only, result to dHin
     float* dHin;                   // [E1,Hp]
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         if (row != 0 || a.frozen) {
             float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
             if (frz) {             // h_t = h_{t-1} for frozen rows: carry the whole dh to the previous depth
-                dh = dh + ggpm_ld4(a.carry + o);
+                if (!a.first) dh = dh + ggpm_ld4(a.carry + o);      // (the first backward depth starts the carry: no memset)
                 ggpm_st4(a.carry + o, dh);
                 dh = ggpm_zero4();   // nothing flows through gates (their stash is 0 anyway)
             }
@@ -878,7 +878,6 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     }
     // dXz / dXh are started (not accumulated) by the first backward depth; so is dXr when that depth has a dS/dG product
     if (depth == 1 && !frozen) (void)hipMemsetAsync(dXr, 0, slot * sizeof(float), s);
-    if (frozen) (void)hipMemsetAsync(carry, 0, slot * sizeof(float), s);
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product

@@ -229,7 +229,7 @@ struct LstmBwdArgs {
     // sparse_forward only (see mpn_gru.hip): frozen rows carry dh / dc through the loop; final gather-only launch
     const unsigned char* frozen;
     const float* dCD;                // gradient of c_D (sparse_forward returns the cell state too)
-    float *carry_h, *carry_c;        // [E1,Hp] each, zeroed by the driver
+    float *carry_h, *carry_c;        // [E1,Hp] each, started by the first backward depth
     int final_pass;
     float *dHin, *dCin;
     int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
@@ -371,8 +371,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             if (a.first) { dh = dhd; dc = dcd; }
             else { dh = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
             if (frz) {             // (h, c)_t = (h, c)_{t-1}: carry both gradients to the previous depth
-                dh = dh + ggpm_ld4(a.carry_h + o);
-                dc = dc + ggpm_ld4(a.carry_c + o);
+                if (!a.first) {        // (the first backward depth starts the carries: no memset)
+                    dh = dh + ggpm_ld4(a.carry_h + o);
+                    dc = dc + ggpm_ld4(a.carry_c + o);
+                }
                 ggpm_st4(a.carry_h + o, dh);
                 ggpm_st4(a.carry_c + o, dc);
                 dh = ggpm_zero4();
@@ -728,10 +730,6 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         if (!weights_packed) ggpm_launch_pack(pk, 4, s);
     }
     // dXi / dXo / dXu / dXf are started (not accumulated) by the first backward depth
-    if (frozen) {
-        (void)hipMemsetAsync(carry_h, 0, slot * sizeof(float), s);
-        (void)hipMemsetAsync(carry_c, 0, slot * sizeof(float), s);
-    }
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
