@@ -532,7 +532,7 @@ def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
 # backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
 # visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
 # parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
-_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None, "early": None}
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None, "early": None, "pending": []}
 
 
 def defer_wgrads_enabled() -> bool:
@@ -544,6 +544,7 @@ def _defer_register() -> None:
         _DEFER["linear"].clear()          # (leftovers of a backward pass that raised)
         _DEFER["sum"].clear()
         _DEFER["gather"].clear()
+        _DEFER["pending"], _DEFER["early"] = [], None
         _DEFER["registered"] = True
         _DEFER["stream"] = torch.cuda.current_stream()
         torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
@@ -577,8 +578,19 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
     _DEFER["linear"].clear()
     _DEFER["sum"].clear()
     _DEFER["gather"].clear()
-    _DEFER["registered"] = False
     main = _DEFER["stream"]
+    if side is None:
+        _DEFER["registered"] = False
+        if main is not None and _DEFER["early"] is not None:
+            # what the early flush computed on the second stream is handed to .grad HERE, on the queueing stream, once
+            # that stream is ordered behind it: every mutation of .grad stays on one stream, whatever order the engine
+            # ran the nodes in (autograd's own AccumulateGrad for tied / shared parameters included)
+            main.wait_stream(_DEFER["early"])
+            _DEFER["early"] = None
+            with torch.cuda.stream(main):
+                for param, g in _DEFER["pending"]:
+                    _add_to_grad(param, g)
+        _DEFER["pending"] = []
     if not (lin or sums or gath) or main is None:
         return
     stream = main
@@ -586,10 +598,6 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
         side.wait_stream(main)
         stream = side
         _DEFER["early"] = side
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
-    elif _DEFER["early"] is not None:      # an early flush may still be writing the same .grad buffers
-        main.wait_stream(_DEFER["early"])
-        _DEFER["early"] = None
 
     def use(t):                            # queued on `main`, read on `side`: keep the allocator from recycling it early
         if side is not None and isinstance(t, torch.Tensor):
@@ -597,9 +605,11 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
         return t
 
     def publish(param, g):
-        if side is not None:
+        if side is not None:               # computed early: published by the end-of-backward flush (see above)
             g.record_stream(main)
-        _add_to_grad(param, g)
+            _DEFER["pending"].append((param, g))
+        else:
+            _add_to_grad(param, g)
 
     with torch.cuda.stream(stream):
         for weight, bias, Ks, visits in lin.values():
@@ -639,7 +649,7 @@ def flush_deferred_early() -> None:
     main = _DEFER["stream"]
     if main is None or not _DEFER["registered"]:
         return
-    _defer_flush(side=_side_stream(main.device))
+    _defer_flush(side=_side_stream(main.device))       # (the end-of-backward callback stays registered: it publishes)
 
 
 # ----------------------------------------------------------------------------- persistent depth loops
