@@ -28,7 +28,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 import torch
@@ -51,9 +51,13 @@ def _transpose(rows: np.ndarray, cols: np.ndarray, ncols: int):
 class AtomPlan:
     """Host-built index tables of the atom-level decode loop (see the module docstring)."""
 
-    def __init__(self, schedule, n_gnodes: int, n_gmess: int):
+    def __init__(self, schedule, n_gnodes: int, n_gmess: int, full: Optional[bool] = None):
+        """``full``: also build the level-wide per-step tables of the full-level form (``_AtomDecode``; default: only when
+        GGPM_ATOM_COMPACT=0 -- the compact form does not read them and they are the larger half of the build and upload)."""
         P, steps = schedule.plan, schedule.steps
         self.T, self.N1, self.E1 = len(steps), n_gnodes, n_gmess
+        self.full = (not compact_enabled()) if full is None else bool(full)
+        full = self.full
         self.ok = all(len(st["atoms"]) > 0 for st in steps)          # (the reference keeps a stale node buffer otherwise)
         ints: List[np.ndarray] = []
         self.where = {}
@@ -65,7 +69,7 @@ class AtomPlan:
             fill[0] += len(a)
             ints.append(a)
 
-        frozen = np.ones((self.T, n_gmess), dtype=np.uint8)
+        frozen = np.ones((self.T if full else 0, n_gmess), dtype=np.uint8)
         frozen_loc: List[np.ndarray] = []                     # compact steps: mask over the step's local rows
         self.nloc, self.floc_off = [], [0]
         self._raw, self._ct = [], {}                          # per step (rows, mask, incoming-message table, pool table)
@@ -80,17 +84,18 @@ class AtomPlan:
         for t, st in enumerate(steps):
             bonds = np.asarray(st["bonds"], dtype=np.int64)
             atoms = np.asarray(st["atoms"], dtype=np.int64)
-            frozen[t, bonds] = 0
             # predecessor CSR over all E1 rows (only this step's bonds have entries) and its transpose
             order = np.argsort(bonds, kind="stable")
             tab = P["g_bgraph"][boff[t]:boff[t + 1]][order]
             cnt = (tab > 0).sum(axis=1)
-            counts = np.zeros(n_gmess, dtype=np.int64)
-            counts[bonds[order]] = cnt
-            rp, col = _csr_from_lists(counts, tab[tab > 0])
-            put(("pred_rp", t), rp); put(("pred_col", t), col)
-            rpT, colT = _transpose(np.repeat(bonds[order], cnt), tab[tab > 0], n_gmess)
-            put(("succ_rp", t), rpT); put(("succ_col", t), colT)
+            if full:
+                frozen[t, bonds] = 0
+                counts = np.zeros(n_gmess, dtype=np.int64)
+                counts[bonds[order]] = cnt
+                rp, col = _csr_from_lists(counts, tab[tab > 0])
+                put(("pred_rp", t), rp); put(("pred_col", t), col)
+                rpT, colT = _transpose(np.repeat(bonds[order], cnt), tab[tab > 0], n_gmess)
+                put(("succ_rp", t), rpT); put(("succ_col", t), colT)
             # the same two CSRs over the step's compact row set: its bonds + the frozen rows they read + the null row
             rows = np.union1d(np.union1d(bonds, tab[tab > 0]), [0]).astype(np.int64)
             n = len(rows)
@@ -110,22 +115,24 @@ class AtomPlan:
             put(("rows", t), rows)                             # local -> level row
             # incoming messages of the step's atoms (rows local to the step) and the transpose (rows = messages)
             atab = P["g_agraph"][aoff[t]:aoff[t + 1]]
-            acnt = (atab > 0).sum(axis=1)
-            rp, col = _csr_from_lists(acnt, atab[atab > 0])
-            put(("agr_rp", t), rp); put(("agr_col", t), col)
-            rpT, colT = _transpose(np.repeat(np.arange(len(atoms)), acnt), atab[atab > 0], n_gmess)
-            put(("agrT_rp", t), rpT); put(("agrT_col", t), colT)
+            if full:
+                acnt = (atab > 0).sum(axis=1)
+                rp, col = _csr_from_lists(acnt, atab[atab > 0])
+                put(("agr_rp", t), rp); put(("agr_col", t), col)
+                rpT, colT = _transpose(np.repeat(np.arange(len(atoms)), acnt), atab[atab > 0], n_gmess)
+                put(("agrT_rp", t), rpT); put(("agrT_col", t), colT)
             # pooled cluster vectors of the step's visits read the step's atom vectors (other atoms' rows are zero in
             # the node buffer the reference rebuilds every step)
             pos = np.full(n_gnodes, -1, dtype=np.int64)
             pos[atoms] = np.arange(len(atoms))
             ptab = P["pool"][ioff[t]:ioff[t + 1]]
             loc = np.where(ptab > 0, pos[ptab], -1)
-            pcnt = (loc >= 0).sum(axis=1)
-            rp, col = _csr_from_lists(pcnt, loc[loc >= 0])
-            put(("pool_rp", t), rp); put(("pool_col", t), col)
-            rpT, colT = _transpose(np.repeat(np.arange(len(ptab)), pcnt), loc[loc >= 0], len(atoms))
-            put(("poolT_rp", t), rpT); put(("poolT_col", t), colT)
+            if full:
+                pcnt = (loc >= 0).sum(axis=1)
+                rp, col = _csr_from_lists(pcnt, loc[loc >= 0])
+                put(("pool_rp", t), rp); put(("pool_col", t), col)
+                rpT, colT = _transpose(np.repeat(np.arange(len(ptab)), pcnt), loc[loc >= 0], len(atoms))
+                put(("poolT_rp", t), rpT); put(("poolT_col", t), colT)
             self._raw.append((rows, fl, atab, loc))
             here = []
             for (cands, icls, nth, _) in st["assm"]:
@@ -152,7 +159,7 @@ class AtomPlan:
             segs = [(kbase[k] + start, n) for (k, start, n) in here]
             self.step_cands.append(segs)
             ns = aoff[t + 1] - aoff[t]
-            for j, (k, start, n) in enumerate(here):
+            for j, (k, start, n) in enumerate(here if full else ()):
                 p = np.asarray(cand_pos[k][start:start + n], dtype=np.int64)
                 put(("cand_pos", t, j), p)
                 ok = p >= 0
@@ -252,7 +259,8 @@ class AtomPlan:
 
     def to_device(self, device):
         if self._dev is None or self._dev["device"] != device:
-            di, df, dl = F_.upload(self.ints, device), F_.upload(self.frozen, device), F_.upload(self.frozen_loc, device)
+            di, dl = F_.upload(self.ints, device), F_.upload(self.frozen_loc, device)
+            df = F_.upload(self.frozen, device) if self.full else None
             base = di.data_ptr()
             ptr = {k: base + 4 * off for k, (off, n) in self.where.items()}
             meta = {k: {n: F_.upload(v, device) for n, v in m.items()} for k, m in self.cand_meta.items()}
@@ -721,5 +729,8 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
         seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64)
         drop = (float(wo[2].p), int(seed[0]), int(seed[1]))
     fn = _AtomDecodeCompact if compact_enabled() else _AtomDecode
+    if fn is _AtomDecode and not plan.full:
+        raise RuntimeError("this AtomPlan was built without the level-wide tables (GGPM_ATOM_COMPACT changed after the plan "
+                           "was built?); build it with full=True")
     return fn.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
                     rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)

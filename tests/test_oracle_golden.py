@@ -297,7 +297,11 @@ def test_atom_plan_compact_row_sets_match_the_level_wide_tables():
     tensors = synth.tensorize(specs)
     sch = DecodeSchedule.from_specs(specs, tensors)
     E1 = tensors[1][1].shape[0]
-    plan = sch.atom_plan(tensors[1][0].shape[0], E1)
+    from ggpm_amd.atom_decode import AtomPlan
+    plan = AtomPlan(sch, tensors[1][0].shape[0], E1, full=True)        # (the level-wide tables are what this test compares with)
+    lean = AtomPlan(sch, tensors[1][0].shape[0], E1, full=False)       # what the compact form builds by default
+    assert lean.nloc == plan.nloc and np.array_equal(lean.frozen_loc, plan.frozen_loc) and len(lean.ints) < len(plan.ints)
+    assert np.array_equal(lean.compact_tables(5, 3)["ints"], plan.compact_tables(5, 3)["ints"])
 
     def arr(key):
         off, n = plan.where[key]
