@@ -436,6 +436,7 @@ class VaeWorkload:
         loss, metrics = self.model(None, None, dev_tensors, self.orders, None, None, beta=0.1, perturb_z=True, schedule=sch)
         loss.backward()
         self.opt.step()
+        metrics["Loss"]      # the training loop reads the metrics here (vae_train.py:86): one host read-back per step
         return metrics
 
     def measure(self):
@@ -479,7 +480,7 @@ class VaeWorkload:
                 "ms_per_step_index_structures_rebuilt": fresh,
                 "steps": steps, "warmup": warm, "rnn_type": self.rnn,
                 "workload": "HierPropertyVAE fwd (perturb_z) + bwd + Adam on the configs[1] batches: latent=%d, diterT=%d, "
-                            "diterG=%d, tie_embedding=%s, metrics read back with .item() every step like the reference; the batches' "
+                            "diterG=%d, tie_embedding=%s, metrics read back on the host every step (after optimizer.step(), where vae_train.py uses them); the batches' "
                             "index tensors AND decode schedules are resident on the device, and the index structures derived "
                             "from them are kept across steps (ms_per_step_index_structures_rebuilt: rebuilt every step)"
                             % (self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}

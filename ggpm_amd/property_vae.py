@@ -6,6 +6,8 @@ ggpm/property_vae.py:26-33; the two [B,H]x[H,latent] products run through the li
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -141,6 +143,62 @@ class HierEncoderVAE(nn.Module):
         return z, kl, (hroot[:, :H], hnode[:, :H], hinter[:, :H], hatom[:, :H])
 
 
+class StepMetrics(dict):
+    """The metrics dictionary ``HierPropertyVAE.forward`` returns (ggpm/property_vae.py:60-62 builds it with ``.item()``:
+    python floats).  Same keys, same values -- read on FIRST ACCESS: the six device scalars are stacked by one kernel when
+    the forward ends and copied to the host when a value is asked for, which in ``vae_train.py`` is after
+    ``loss.backward(); optimizer.step()`` (:81-86).  Reading them inside the forward, as the reference does, stops the host
+    in the middle of the step: the backward cannot be issued while the forward's tail still runs."""
+
+    _KEYS = ('Loss', 'KL:', 'Word', 'I-Word', 'Topo', 'Assm')
+
+    def __init__(self, values):
+        super().__init__()
+        vals = [v.detach().reshape(()).float() if isinstance(v, torch.Tensor) else None for v in values]
+        self._const = [None if isinstance(v, torch.Tensor) else float(v) for v in values]
+        dev = next((v.device for v in vals if v is not None), None)
+        self._dev = torch.stack([v if v is not None else torch.zeros((), device=dev) for v in vals]) if dev is not None else None
+        self._ready = False
+
+    def _fill(self):
+        if not self._ready:
+            host = self._dev.tolist() if self._dev is not None else [0.0] * len(self._KEYS)
+            for k, h, c in zip(self._KEYS, host, self._const):
+                dict.__setitem__(self, k, h if c is None else c)
+            self._ready = True
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def keys(self):
+        return list(self._KEYS)
+
+    def values(self):
+        self._fill()
+        return [dict.__getitem__(self, k) for k in self._KEYS]
+
+    def items(self):
+        self._fill()
+        return [(k, dict.__getitem__(self, k)) for k in self._KEYS]
+
+    def get(self, k, default=None):
+        return self[k] if k in self._KEYS else default
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
 class HierPropertyVAE(nn.Module):
     """reference ggpm/property_vae.py:11-62 -- encoder, latent heads, teacher-forced decoder; the class
     ``OPVNet.get_model('hier-prop')`` returns (ggpm/opvnet.py:4-9) and ``vae_train.py:78`` calls as
@@ -175,5 +233,7 @@ class HierPropertyVAE(nn.Module):
         loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,
                                                     schedule=schedule)
         loss = loss + beta * kl_div
+        if os.environ.get("GGPM_LAZY_METRICS", "1") != "0":
+            return loss, StepMetrics((loss, kl_div, wacc, iacc, tacc, sacc))
         return loss, {'Loss': loss.item(), 'KL:': kl_div.item(), 'Word': float(wacc), 'I-Word': float(iacc),
                       'Topo': float(tacc), 'Assm': float(sacc)}
