@@ -103,3 +103,19 @@ def test_flat_adam_equals_adam_over_the_parameter_list():
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.equal(p, q)
+
+
+def test_step_metrics_reads_on_first_access_and_behaves_like_the_reference_dict():
+    """ggpm_amd.property_vae.StepMetrics: the reference's metrics dictionary (ggpm/property_vae.py:60-62) with its values
+    copied from the tensors on first access; vae_train.py:86 builds ``np.array([metrics['Loss'], ...])`` from it."""
+    import numpy as np
+    import torch
+    from ggpm_amd.property_vae import StepMetrics
+    vals = (torch.tensor(98.875), torch.tensor(32.5), torch.tensor(0.25), torch.tensor(0.125), torch.tensor(0.5), 1)
+    m = StepMetrics(vals)
+    assert not m._ready and list(m) == ['Loss', 'KL:', 'Word', 'I-Word', 'Topo', 'Assm'] and len(m) == 6 and 'KL:' in m
+    assert not m._ready                                   # nothing above touched a value
+    arr = np.array([m['Loss'], m['KL:'], m['Word'], m['I-Word'], m['Topo'], m['Assm']])
+    assert m._ready and arr.tolist() == [98.875, 32.5, 0.25, 0.125, 0.5, 1.0]
+    assert dict(m.items()) == {'Loss': 98.875, 'KL:': 32.5, 'Word': 0.25, 'I-Word': 0.125, 'Topo': 0.5, 'Assm': 1.0}
+    assert all(isinstance(v, float) for v in m.values()) and m.get('nope', 7) == 7
