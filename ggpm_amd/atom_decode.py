@@ -172,7 +172,14 @@ class AtomPlan:
         self.frozen_loc = np.ones(self.floc_off[-1], dtype=np.uint8)
         for t, fl in enumerate(frozen_loc):
             self.frozen_loc[self.floc_off[t]:self.floc_off[t] + len(fl)] = fl
-        self._dev = None
+        self._dev = {}
+
+    def __getstate__(self):
+        """Host tables only: device copies and the descriptors that name them stay with the process that made them."""
+        st = dict(self.__dict__)
+        st["_dev"] = {}
+        st["_ct"] = {k: dict(v, dev={}) for k, v in self._ct.items()}
+        return st
 
     def row_offsets(self, depth: int):
         """-> (offsets of the steps' [depth, n] blocks, offsets of their [depth + 1, n] blocks), each of length T + 1."""
@@ -258,7 +265,12 @@ class AtomPlan:
         return np.concatenate([k * self.E1 + rows for k in range(gates)]).astype(np.int32)
 
     def to_device(self, device):
-        if self._dev is None or self._dev["device"] != device:
+        """Device copies of the tables, one set PER DEVICE (kept for the life of the plan: the raw addresses handed to
+        the C drivers -- ``ptr``, the cached ``ggpm_decode_steps`` descriptors under ``desc`` -- name exactly these
+        tensors and live in the same dict, so they can never outlast them)."""
+        device = torch.device(device)
+        D = self._dev.get(device)
+        if D is None:
             di, dl = F_.upload(self.ints, device), F_.upload(self.frozen_loc, device)
             df = F_.upload(self.frozen, device) if self.full else None
             base = di.data_ptr()
@@ -266,8 +278,19 @@ class AtomPlan:
             meta = {k: {n: F_.upload(v, device) for n, v in m.items()} for k, m in self.cand_meta.items()}
             for m in meta.values():
                 m["icls"] = m["icls"].to(torch.int32)
-            self._dev = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta)
-        return self._dev
+            D = self._dev[device] = dict(device=device, ints=di, frozen=df, frozen_loc=dl, ptr=ptr, meta=meta, desc={},
+                                         seen=set())
+        if device.type == "cuda":
+            # uploaded on whatever stream was current then (the atom-ahead stream, usually) and read on others: tell the
+            # allocator once per reading stream
+            cur = torch.cuda.current_stream(device)
+            if cur.cuda_stream not in D["seen"]:
+                D["seen"].add(cur.cuda_stream)
+                ts = [D["ints"], D["frozen_loc"]] + ([D["frozen"]] if D["frozen"] is not None else [])
+                ts += [v for m in D["meta"].values() for v in m.values()]
+                for t in ts:
+                    t.record_stream(cur)
+        return D
 
 
 class DecodeSteps(ctypes.Structure):
@@ -282,7 +305,7 @@ class DecodeSteps(ctypes.Structure):
 def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
     """The ggpm_decode_steps descriptor of (plan, device, depth, cell), built once (it only names resident tables)."""
     key = ("steps", depth, bool(lstm), H)
-    hit = ct["dev"].get((D["device"], key))
+    hit = D["desc"].get(key)
     if hit is not None:
         return hit
     T, ptr = plan.T, D["ptr"]
@@ -299,7 +322,7 @@ def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
     d = DecodeSteps(T, H, depth, int(lstm), *[ctypes.cast(keep[k], ctypes.c_void_p) for k in
                                                ("n", "foff", "roff", "qoff", "srcH", "srcF", "frozen", "pred_rowptr",
                                                 "pred_col", "succ_rowptr", "succ_col")])
-    ct["dev"][(D["device"], key)] = (d, keep)
+    D["desc"][key] = (d, keep)      # beside the tensors whose addresses it holds
     return d, keep
 
 

@@ -86,7 +86,7 @@ class DevicePrefetcher:
         return buf[:total]
 
     def _upload(self, slot: int, tensors):
-        from .nnutils import tree_chain_length
+        from .nnutils import attach_hint, tree_chain_length
         arrays, layout, total = batch_layout(tensors)
         tscope, gscope = tensors[0][-1], tensors[1][-1]
         chain = tree_chain_length(tensors[0][3])         # host data here: lets the tree-side levels stop at their fixed point
@@ -98,8 +98,8 @@ class DevicePrefetcher:
         def views(flat):
             tree, graph = unpack_views(flat, layout, tscope, gscope)
             if chain:
-                tree[3].ggpm_chain = chain
-            tree[0].ggpm_roots = flat.view(torch.int32)[2 * total:2 * total + B]     # what embed_root gathers by
+                attach_hint(tree[3], "ggpm_chain", chain)
+            attach_hint(tree[0], "ggpm_roots", flat.view(torch.int32)[2 * total:2 * total + B])     # what embed_root gathers by
             return tree, graph
 
         if not self.cuda:

@@ -51,6 +51,11 @@ class DecodeSchedule:
         self.batch_size = 0
         self._dev = None
 
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_dev"] = None          # (device views: rebuilt by to_device in the receiving process)
+        return st
+
     # ------------------------------------------------------------------ construction (host)
     @staticmethod
     def from_graphs(graphs, tensors, orders, vocab) -> "DecodeSchedule":

@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from . import functional as F_
-from .nnutils import to_cuda
+from .nnutils import read_hint, to_cuda
 from .rnn import GRU, LSTM
 
 NUM_BOND_TYPES = 4   # len(MolGraph.BOND_LIST), reference ggpm/mol_graph.py:14-15
@@ -221,7 +221,7 @@ class HierMPNEncoder(nn.Module):
         if prep is None and self._fused_ok(tree_tensors, graph_tensors):
             from . import fused
             if roots is None:
-                roots = getattr(tree_tensors[0], "ggpm_roots", None)         # make_cuda / DevicePrefetcher leave it there
+                roots = read_hint(tree_tensors[0], "ggpm_roots")         # make_cuda / DevicePrefetcher leave it there
                 if roots is None or roots.numel() != len(tree_tensors[-1]):
                     roots = _RING.upload([st for st, _ in tree_tensors[-1]], tree_tensors[0].device)
             return fused.hier_encoder(self, tree_tensors, graph_tensors, roots)

@@ -167,18 +167,20 @@ _MEMO_ON = os.environ.get("GGPM_INDEX_MEMO", "1") != "0"
 
 
 def _memo_get(t: torch.Tensor, slot: str, key):
-    """Index structures derived from an index tensor are remembered ON that tensor object (index tensors are never
-    written in place here): a batch whose tables stay resident -- a DecodeSchedule on the device, the encoder's graph
+    """Index structures derived from an index tensor are remembered ON that tensor object, keyed by its in-place
+    version counter: a batch whose tables stay resident -- a DecodeSchedule on the device, the encoder's graph
     tensors -- pays for their CSRs and transposes once, not once per step."""
     if not _MEMO_ON:
         return None
     m = getattr(t, slot, None)
-    return m[1] if m is not None and m[0] == key else None
+    # `_version` counts in-place writes: a resident index tensor that is refilled (``t.copy_(next_batch)``) must not
+    # be served the structures of its old contents
+    return m[2] if m is not None and m[0] == key and m[1] == t._version else None
 
 
 def _memo_put(t: torch.Tensor, slot: str, key, value):
     try:
-        setattr(t, slot, (key, value))
+        setattr(t, slot, (key, t._version, value))
     except AttributeError:
         pass
     return value
@@ -350,8 +352,7 @@ class _Linear(torch.autograd.Function):
             return dW_, db_
 
         wref, bias = ctx.weight_ref, ctx.bias_ref
-        leaf = (ctx.needs_input_grad[0] and getattr(wref, "is_leaf", False)
-                and (bias is None or (getattr(bias, "is_leaf", False) and ctx.needs_input_grad[1])))
+        leaf = (ctx.needs_input_grad[0] and (bias is None or ctx.needs_input_grad[1]) and can_publish(wref, bias))
         if leaf and defer_wgrads_enabled():       # one contraction per parameter at the end of the pass (see _DEFER)
             _defer_linear(wref, bias, dpre, list(xs), Ks)
             return (None, None, None, None, None, None, *dxs)
@@ -423,9 +424,8 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous() if dout.stride(1) != 1 else dout
-        if ctx.needs_input_grad[0] and getattr(ctx.table_ref, "is_leaf", False) and defer_wgrads_enabled():
-            _defer_register()       # one scatter over the rows of all visits at the end of the pass
-            _DEFER["gather"].setdefault(id(ctx.table_ref), (ctx.table_ref, ctx.width, []))[2].append((dout, ctx.idx))
+        if ctx.needs_input_grad[0] and can_publish(ctx.table_ref) and defer_wgrads_enabled():
+            _defer_gather(ctx.table_ref, ctx.width, dout, ctx.idx)      # one scatter over the rows of all visits at the end of the pass
             return None, None, None, None, None
         csrT = ctx.idx_csr.T
         dtable = torch.empty(ctx.tshape, dtype=torch.float32, device=dout.device)
@@ -532,27 +532,51 @@ def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
 # backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
 # visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
 # parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
-_DEFER = {"linear": {}, "sum": {}, "gather": {}, "registered": False, "stream": None, "early": None, "pending": []}
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "task": None, "stream": None, "early": None, "pending": []}
 
 
 def defer_wgrads_enabled() -> bool:
     return os.environ.get("GGPM_DEFER_WGRADS", "1") != "0"
 
 
+def _has_hooks(p) -> bool:
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
+def can_publish(*params) -> bool:
+    """True when the gradients of these parameters may be written to ``.grad`` by this module itself (deferred
+    contraction / second stream) instead of being returned through autograd: leaves that require grad and carry NO
+    hooks.  A parameter with a tensor hook or a post-accumulate-grad hook (stock DDP, hook-based clippers / reducers)
+    gets its gradient the ordinary way, through AccumulateGrad, so that the hooks fire."""
+    return all(p is None or (getattr(p, "is_leaf", False) and p.requires_grad and not _has_hooks(p)) for p in params)
+
+
 def _defer_register() -> None:
-    if not _DEFER["registered"]:
-        _DEFER["linear"].clear()          # (leftovers of a backward pass that raised)
+    """Queue the end-of-backward flush once per backward pass.  A pass is identified by the autograd engine's graph
+    task id: a pass that RAISED never ran its callbacks, so whatever it left queued is dropped when the next pass
+    registers (nothing sticky survives a failed backward)."""
+    task = torch._C._current_graph_task_id()
+    if _DEFER["task"] != task or task < 0:
+        _DEFER["linear"].clear()
         _DEFER["sum"].clear()
         _DEFER["gather"].clear()
         _DEFER["pending"], _DEFER["early"] = [], None
-        _DEFER["registered"] = True
+        _DEFER["task"] = task
         _DEFER["stream"] = torch.cuda.current_stream()
         torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
 
 
 def _defer_linear(weight, bias, dpre, xs, Ks) -> None:
     _defer_register()
-    _DEFER["linear"].setdefault(id(weight), (weight, bias, Ks, []))[3].append((dpre, xs))
+    # keyed by the parameter AND the column split it was visited with: a Linear used with two different K splits in one
+    # pass gets one contraction per split (both land in the same .grad)
+    key = (id(weight), tuple(Ks), id(bias) if bias is not None else 0)
+    _DEFER["linear"].setdefault(key, (weight, bias, tuple(Ks), []))[3].append((dpre, xs))
+
+
+def _defer_gather(table, width, dout, idx) -> None:
+    _defer_register()
+    _DEFER["gather"].setdefault((id(table), int(width)), (table, width, []))[2].append((dout, idx))
 
 
 def _defer_sum(param, grad) -> None:
@@ -580,7 +604,7 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
     _DEFER["gather"].clear()
     main = _DEFER["stream"]
     if side is None:
-        _DEFER["registered"] = False
+        _DEFER["task"] = None
         if main is not None and _DEFER["early"] is not None:
             # what the early flush computed on the second stream is handed to .grad HERE, on the queueing stream, once
             # that stream is ordered behind it: every mutation of .grad stays on one stream, whatever order the engine
@@ -647,7 +671,7 @@ def flush_deferred_early() -> None:
     if os.environ.get("GGPM_DEFER_EARLY", "1") == "0" or not side_stream_enabled():
         return
     main = _DEFER["stream"]
-    if main is None or not _DEFER["registered"]:
+    if main is None or _DEFER["task"] is None or _DEFER["task"] != torch._C._current_graph_task_id():
         return
     _defer_flush(side=_side_stream(main.device))       # (the end-of-backward callback stays registered: it publishes)
 
@@ -757,7 +781,7 @@ class _GruLevel(torch.autograd.Function):
         dWh_x, dWh_h = _split_cols(dW_h, I)
         wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
-        use_side = side_stream_enabled() and all(getattr(p, "is_leaf", False) for p in ctx.params)
+        use_side = side_stream_enabled() and can_publish(*ctx.params)
         overlapped = use_side and wgrad_overlap_enabled()
         if overlapped:
             # the h-half weight gradients run on the second stream in chunks of depths WHILE this level's depth
@@ -843,7 +867,7 @@ def _scatter_rows(full_rows: int, sub: torch.Tensor, index: torch.Tensor) -> tor
 
 def _sparse_structure(E1: int, submess: torch.Tensor, bgraph_sub: torch.Tensor):
     """(frozen mask [E1] uint8, predecessor CSR over all E1 rows) of a sparse_forward call, remembered on ``bgraph_sub``."""
-    key = (E1, submess.data_ptr(), submess.numel())
+    key = (E1, submess.data_ptr(), submess.numel(), submess._version)
     hit = _memo_get(bgraph_sub, "_ggpm_sparse", key)
     if hit is not None:
         return hit
@@ -939,7 +963,7 @@ class _GruSparse(torch.autograd.Function):
             gemm(0, 0, ms, I, H, dXs[1], Hp, W_r, W_r.stride(0), dx, ldx, I, accumulate=True)
             gemm(0, 0, ms, I, H, dXs[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
         pgrads = (dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h)
-        if defer_wgrads_enabled() and all(getattr(q, "is_leaf", False) and q.requires_grad for q in ctx.param_refs):
+        if defer_wgrads_enabled() and can_publish(*ctx.param_refs):
             for q, g in zip(ctx.param_refs, pgrads):      # summed once per parameter at the end of the pass (see _DEFER)
                 _defer_sum(q, g)
             pgrads = (None,) * 7
@@ -1040,7 +1064,7 @@ class _LstmSparse(torch.autograd.Function):
                 gemm(0, 0, ms, I, H, dXs[k], Hp, Ws[k][:, :I], Ws[k].stride(0), dx, ldx,
                      x_sub.shape[1] if k == 0 else I, accumulate=k > 0)
         pgrads = (dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3])
-        if defer_wgrads_enabled() and all(getattr(q, "is_leaf", False) and q.requires_grad for q in ctx.param_refs):
+        if defer_wgrads_enabled() and can_publish(*ctx.param_refs):
             for q, g in zip(ctx.param_refs, pgrads):      # summed once per parameter at the end of the pass (see _DEFER)
                 _defer_sum(q, g)
             pgrads = (None,) * 8
@@ -1110,7 +1134,7 @@ class _LstmLevel(torch.autograd.Function):
         dWh = [w[:, I:] for w in dWs]
         wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
-        use_side = side_stream_enabled() and all(getattr(p, "is_leaf", False) for p in ctx.params)
+        use_side = side_stream_enabled() and can_publish(*ctx.params)
         _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0),
                                           _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr),
                                           _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),

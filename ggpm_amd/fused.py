@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from . import functional as F_
+from .nnutils import read_hint
 
 _HEAD = ["E_c.0.weight", "E_i.0.weight", "W_c.0.weight", "W_c.0.bias", "W_i.0.weight", "W_i.0.bias", "W_root.0.weight",
          "W_root.0.bias"]
@@ -184,7 +185,7 @@ def hier_encoder(encoder, tree_tensors, graph_tensors, roots):
                    encoder.atom_size, encoder.E_c[0].weight.shape[0], encoder.E_i[0].weight.shape[0],
                    gf[0].shape[0], gf[1].shape[0], gf[2].shape[1], gf[3].shape[1],
                    tf[0].shape[0], tf[1].shape[0], tf[2].shape[1], tf[3].shape[1], tf[4].shape[1], roots.numel(), int(lstm),
-                   int(getattr(tf[3], "ggpm_chain", 0)), 0.0, 0, 0,
+                   int(read_hint(tf[3], "ggpm_chain", 0)), 0.0, 0, 0,
                    GATE_DTYPES[getattr(encoder, "gate_dtype", None) or os.environ.get("GGPM_GATE_DTYPE", "f32")])
     if encoder.training and encoder.dropout > 0:      # nn.Dropout semantics: active in training mode only
         seed = getattr(encoder, "_dropout_seed", None) or _dropout_seed()      # (tests pin the seed)

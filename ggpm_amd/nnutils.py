@@ -56,6 +56,21 @@ def tree_chain_length(bgraph) -> int:
     return 0            # never settled: a cycle
 
 
+def attach_hint(t: torch.Tensor, name: str, value) -> None:
+    """Leave a value derived from ``t``'s CONTENTS on the tensor object, stamped with its in-place version counter."""
+    setattr(t, name, value)
+    setattr(t, name + "_version", t._version)
+
+
+def read_hint(t, name: str, default=None):
+    """The value ``attach_hint`` left, unless the tensor was written in place since (a resident index tensor refilled
+    with the next batch must not carry the previous batch's chain length / root ids)."""
+    v = getattr(t, name, None)
+    if v is None or getattr(t, name + "_version", None) != getattr(t, "_version", None):
+        return default
+    return v
+
+
 def make_cuda(tensors):
     """(tree_tensors, graph_tensors) -> int64 device tensors, host ``scope`` list kept last.  While the predecessor
     table is still host data its longest dependency chain is measured and rides along as an attribute of the device
@@ -65,9 +80,9 @@ def make_cuda(tensors):
     tree_tensors = [make_tensor(x).long() for x in tree_tensors[:-1]] + [tree_tensors[-1]]
     graph_tensors = [make_tensor(x).long() for x in graph_tensors[:-1]] + [graph_tensors[-1]]
     if chain and isinstance(tree_tensors[3], torch.Tensor):
-        tree_tensors[3].ggpm_chain = chain
+        attach_hint(tree_tensors[3], "ggpm_chain", chain)
     # the molecules' root node ids (scope starts, what embed_root gathers by) ride along as a device tensor: batches
     # that stay resident then never pay the per-forward upload of that list (0.3 ms of host time per step)
-    if isinstance(tree_tensors[0], torch.Tensor) and not hasattr(tree_tensors[0], "ggpm_roots") and len(tree_tensors) > 4:
-        tree_tensors[0].ggpm_roots = make_tensor(np.asarray([st for st, _ in tree_tensors[-1]], dtype=np.int32))
+    if isinstance(tree_tensors[0], torch.Tensor) and read_hint(tree_tensors[0], "ggpm_roots") is None and len(tree_tensors) > 4:
+        attach_hint(tree_tensors[0], "ggpm_roots", make_tensor(np.asarray([st for st, _ in tree_tensors[-1]], dtype=np.int32)))
     return tree_tensors, graph_tensors

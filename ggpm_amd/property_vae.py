@@ -95,8 +95,7 @@ class _KLHead(torch.autograd.Function):
                 dict(A=dpv, lda=L, B=z_vecs, ldb=F_._ld(z_vecs), C=dWv, ldc=dWv.stride(0), n_pad=H)])
             return dWm, F_.colsum(dmean, B, L), dWv, F_.colsum(dpv, B, L)
 
-        leaf = all(getattr(q, "is_leaf", False) for q in ctx.params)
-        if F_.side_stream_enabled() and leaf and all(ctx.needs_input_grad[1:5]):
+        if F_.side_stream_enabled() and F_.can_publish(*ctx.params) and all(ctx.needs_input_grad[1:5]):
             main = torch.cuda.current_stream()
             side = F_._side_stream(z_vecs.device)
             side.wait_stream(main)

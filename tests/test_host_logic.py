@@ -1,0 +1,153 @@
+"""CPU: host-side bookkeeping of ggpm_amd.functional / nnutils that needs no kernel -- the index-structure memo's
+staleness guard, the hints make_cuda leaves on index tensors, and the deferred-gradient queue's behaviour around a
+backward pass that raises."""
+import contextlib
+
+import pytest
+import torch
+
+from ggpm_amd import functional as F_
+from ggpm_amd import nnutils
+
+
+def test_index_memo_is_invalidated_by_an_in_place_refill():
+    """A resident index tensor that is refilled with the next batch (``t.copy_(...)``) must not be served the CSR of its
+    old contents: the memo is keyed by the tensor's in-place version counter."""
+    t = torch.arange(12, dtype=torch.int64).view(4, 3)
+    assert F_._memo_get(t, "_ggpm_csr", 5) is None
+    F_._memo_put(t, "_ggpm_csr", 5, "old-structure")
+    assert F_._memo_get(t, "_ggpm_csr", 5) == "old-structure"
+    assert F_._memo_get(t, "_ggpm_csr", 6) is None            # other key (ncols)
+    t.copy_(torch.zeros(4, 3, dtype=torch.int64))               # refill in place
+    assert F_._memo_get(t, "_ggpm_csr", 5) is None
+    F_._memo_put(t, "_ggpm_csr", 5, "new-structure")
+    assert F_._memo_get(t, "_ggpm_csr", 5) == "new-structure"
+    t[0, 0] = 3                                                  # any in-place write counts
+    assert F_._memo_get(t, "_ggpm_csr", 5) is None
+
+
+def test_tensor_hints_do_not_survive_an_in_place_refill():
+    """``ggpm_chain`` (how many steps the tree-side levels need) and ``ggpm_roots`` describe the tensor's CONTENTS."""
+    t = torch.zeros(6, 4, dtype=torch.int64)
+    nnutils.attach_hint(t, "ggpm_chain", 7)
+    assert nnutils.read_hint(t, "ggpm_chain", 0) == 7
+    v = t.view_as(t)
+    assert nnutils.read_hint(v, "ggpm_chain", 0) == 0           # a fresh view object carries no hint (bench.py relies on it)
+    t.add_(1)
+    assert nnutils.read_hint(t, "ggpm_chain", 0) == 0           # stale: the full depth loop runs
+    nnutils.attach_hint(t, "ggpm_chain", 3)
+    assert nnutils.read_hint(t, "ggpm_chain", 0) == 3
+
+
+def test_tree_chain_length_is_bounded_by_the_motif_count():
+    from ggpm_amd import synth
+    specs = synth.random_batch(3, 4, motifs=(3, 6), n_motif_vocab=30, n_attach_vocab=90)
+    tree, graph = synth.tensorize(specs)
+    chain = nnutils.tree_chain_length(tree[3])          # (the host half of make_cuda; the upload needs the GPU)
+    assert 1 <= chain <= 6
+
+
+class _FakeStream:
+    device = torch.device("cpu")
+
+    def wait_stream(self, other):
+        pass
+
+
+class _Visit(torch.autograd.Function):
+    """Stands in for a decoder op: its backward queues a deferred parameter gradient and may raise afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, param, boom):
+        ctx.param, ctx.boom = param, boom
+        ctx.save_for_backward(x)
+        return x * param.detach().sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        F_._defer_sum(ctx.param, torch.full_like(ctx.param, float((g * x).sum())))
+        if ctx.boom:
+            raise RuntimeError("injected failure inside the backward pass")
+        return g * ctx.param.detach().sum(), None, None
+
+
+@pytest.fixture
+def fake_streams(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _FakeStream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    for k in ("linear", "sum", "gather"):
+        F_._DEFER[k].clear()
+    F_._DEFER.update(task=None, stream=None, early=None, pending=[])
+    yield
+    for k in ("linear", "sum", "gather"):
+        F_._DEFER[k].clear()
+    F_._DEFER.update(task=None, stream=None, early=None, pending=[])
+
+
+def test_deferred_gradients_survive_a_failed_backward(fake_streams):
+    """the autograd engine does not run queued callbacks when a backward raises.  The next pass must start
+    from a clean queue, flush at its end, and publish exactly its own gradients."""
+    p = torch.nn.Parameter(torch.ones(3))
+    x = torch.arange(4.0, requires_grad=True)
+
+    def step(boom):
+        p.grad = None
+        y = _Visit.apply(_Visit.apply(x, p, False), p, boom)      # two visits of the same parameter in one pass
+        y.sum().backward()
+
+    step(False)
+    want = p.grad.clone()
+    assert want.abs().sum() > 0 and not F_._DEFER["sum"] and F_._DEFER["task"] is None
+    with pytest.raises(RuntimeError, match="injected"):
+        step(True)
+    assert F_._DEFER["sum"], "the failed pass left its visit queued (the engine skipped the callback)"
+    leftovers = F_._DEFER["task"]
+    assert leftovers is not None
+    step(False)                                                    # a normal step after the failure
+    assert torch.equal(p.grad, want), (p.grad, want)               # not doubled by the failed pass's leftovers, not missing
+    assert not F_._DEFER["sum"] and F_._DEFER["task"] is None
+    step(False)
+    assert torch.equal(p.grad, want)
+
+
+def test_parameters_with_hooks_are_not_published_behind_autograd():
+    """a parameter with a tensor hook / post-accumulate-grad hook (stock DDP, hook-based clippers) must get
+    its gradient through AccumulateGrad so that the hooks fire."""
+    p = torch.nn.Parameter(torch.ones(2))
+    q = torch.nn.Parameter(torch.ones(2))
+    assert F_.can_publish(p, q, None)
+    h = q.register_hook(lambda g: g)
+    assert not F_.can_publish(p, q)
+    h.remove()
+    assert F_.can_publish(p, q)
+    h = p.register_post_accumulate_grad_hook(lambda t: None)
+    assert not F_.can_publish(p)
+    h.remove()
+    frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+    assert not F_.can_publish(frozen)
+    assert not F_.can_publish(p * 2)                               # not a leaf
+
+
+def test_deferred_linear_is_keyed_by_its_column_split(fake_streams):
+    """Two visits of one weight with different K splits must not be contracted with the first visit's split."""
+    w = torch.nn.Parameter(torch.ones(2, 6))
+
+    class _Q(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            F_._defer_linear(w, None, torch.ones(3, 2), [torch.ones(3, 6)], (6,))
+            F_._defer_linear(w, None, torch.ones(3, 2), [torch.ones(3, 2), torch.ones(3, 4)], (2, 4))
+            F_._defer_linear(w, None, torch.ones(5, 2), [torch.ones(5, 6)], (6,))
+            keys = sorted(k[1] for k in F_._DEFER["linear"])
+            assert keys == [(2, 4), (6,)]
+            assert sorted(len(v[3]) for v in F_._DEFER["linear"].values()) == [1, 2]
+            F_._DEFER["linear"].clear()                           # (the flush would need the GPU GEMM)
+            return g
+
+    x = torch.ones(2, requires_grad=True)
+    _Q.apply(x).sum().backward()
