@@ -225,6 +225,12 @@ class HierPropertyVAE(nn.Module):
         return rsample(z_vecs, W_mean, W_var, perturb)
 
     def forward(self, mols, graphs, tensors, orders, homos=None, lumos=None, beta=0.0, perturb_z=True, schedule=None):
+        if schedule is None and graphs is not None:
+            # the reference's call shape, ``model(*batch, beta=beta)`` (vae_train.py:78): derive the decoder's integer
+            # bookkeeping HERE, from the batch as it arrives (host arrays: no read-back), so that the atom level can be
+            # issued beside the encoder exactly as with a prepared schedule
+            from .decoder import DecodeSchedule
+            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab)
         tree_tensors, graph_tensors = tensors = make_cuda(tensors)
         self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
         root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]

@@ -315,6 +315,46 @@ def tensorize(batch: Sequence[MolSpec]):
     return tree, graph
 
 
+def networkx_batch(batch: Sequence[MolSpec], tensors):
+    """``(tree_batchG, graph_batchG)`` -- the networkx half of the tuple ``MolGraph.tensorize`` returns
+    (reference ggpm/mol_graph.py:199-236, node / edge attributes as ``label_tree`` leaves them, :121-178, with the
+    batch offsets of :214-221 applied).  Labels are the strings ``'m<i>'`` / ``'a<j>'`` that
+    :class:`ggpm_amd.vocab.IndexPairVocab` resolves, standing in for the SMILES keys of ``PairVocab``."""
+    import networkx as nx
+    tree_scope, graph_scope = tensors[0][-1], tensors[1][-1]
+    tree, graph = nx.DiGraph(), nx.DiGraph()
+    for b, m in enumerate(batch):
+        toff, aoff = tree_scope[b][0], graph_scope[b][0]
+        for a in range(m.n_atoms):
+            graph.add_node(aoff + a, label=m.atom_label[a], batch_id=b)
+        for (u, v), bt in m.bonds.items():
+            for x, y in ((u, v), (v, u)):
+                graph.add_edge(aoff + x, aoff + y, label=(bt, m.bond_pos[(x, y)]) if (x, y) in m.bond_pos else bt)
+        for i in range(m.n_motifs):
+            tree.add_node(toff + i, label=("m%d" % m.motif_label[i][0], "a%d" % m.motif_label[i][1]),
+                          smiles="m%d" % m.motif_label[i][0], ismiles="a%d" % m.motif_label[i][1], batch_id=b,
+                          inter_label=[(a + aoff, "a%d" % att) for a, att in m.inter_label[i]],
+                          cluster=[a + aoff for a in m.clusters[i]],
+                          assm_cands=[x + aoff for x in m.assm_cands[i]])
+        for (u, v), lab in m.tree_edge_label.items():
+            tree.add_edge(toff + u, toff + v, label=lab)
+    return tree, graph
+
+
+def train_batch(batch: Sequence[MolSpec], tensors=None):
+    """The 6-tuple a ``DataFolder`` batch holds and ``vae_train.py:78`` splats into the model
+    (``mols, graphs, tensors, orders, homos, lumos``; reference ggpm/mol_graph.py:233-236): tensors as numpy, as the
+    pickles of ``preprocess.py`` store them."""
+    if tensors is None:
+        tensors = tensorize(batch)
+    orders = []
+    for m, (off, _) in zip(batch, tensors[0][-1]):
+        orders.append([(x + off, y + off, z) for x, y, z in m.order[:-1]] + [(m.order[-1][0] + off, None, 0)])
+    n = len(batch)
+    return (["synthetic-%d" % i for i in range(n)], networkx_batch(batch, tensors), tensors, orders,
+            np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32))
+
+
 def batch_stats(tree, graph) -> dict:
     """Sizes (excluding the pad rows) and mean real predecessors per message."""
     out = {}

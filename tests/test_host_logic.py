@@ -151,3 +151,21 @@ def test_deferred_linear_is_keyed_by_its_column_split(fake_streams):
 
     x = torch.ones(2, requires_grad=True)
     _Q.apply(x).sum().backward()
+
+
+@pytest.mark.parametrize("name", ["vae_lstm_s41", "vae_gru_s42"])
+def test_state_dict_keys_are_the_references(name):
+    """The parameter names of the reference's own HierPropertyVAE (recorded with its gradients in the fixtures) are
+    exactly the drop-in's ``named_parameters``; ``state_dict`` adds only the two aliases the reference registers too
+    (``decoder.rnn_cell``, ``decoder.E_assm``, ggpm/decoder.py:31-32)."""
+    from golden_utils import VaeGolden
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    g = VaeGolden(name)
+    ref_names = {k.split("/", 1)[1] for k in g.z.files if k.startswith(("grad/", "gstat/"))}
+    model = HierPropertyVAE(g.args(IndexPairVocab(g.n_motif, g.n_attach)))
+    ours = {k for k, _ in model.named_parameters()}
+    assert ours == ref_names, (sorted(ours - ref_names), sorted(ref_names - ours))
+    extra = set(model.state_dict()) - ours
+    assert extra and all(k.startswith(("decoder.rnn_cell.", "decoder.E_assm.")) or (g.tie and k.startswith("decoder.hmpn.E_"))
+                         for k in extra), sorted(extra)
