@@ -7,7 +7,12 @@ into the flat all-reduce buffer):
 * parameters must stay BIT-identical across ranks after 6 steps on different batches, with GGPM_BUCKETED_ALLREDUCE at
   1 and at 0, and both settings must give the same parameters;
 * two encoder backwards in one step (gradient accumulation) must give the gradients of the path without the sink
-  (the driver overwrites its output buffers, so the second backward has to be added, not written, into the flat buffer).
+  (the driver overwrites its output buffers, so the second backward has to be added, not written, into the flat buffer);
+* the FULL model (``HierPropertyVAE`` with ``tie_embedding=True``: the tied ``E_c`` / ``E_i`` of ggpm/encoder.py:92-94
+  receive gradients from the encoder's driver AND from the decoder's deferred scatter) trained in the order of
+  vae_train.py:78-83 -- ``model(*batch, beta=beta)``, backward, all-reduce, ``clip_grad_norm_``, Adam -- for 4 steps on
+  different batches per rank: parameters stay BIT-identical across ranks, and the all-reduced gradient of the first step
+  equals the single-process gradient of the two ranks' batches concatenated.
 
 Prints one line per check and "DP-RANK-OK" at the end; any failed assertion ends the process with a non-zero code.
 """
@@ -33,10 +38,79 @@ def loss_of(model, batch):
     return 0.1 * kl + 1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() + hatom.sum())
 
 
+def full_vae_section(rank, world):
+    from ggpm_amd import synth
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(50, 150)
+
+    def specs_of(r, i):
+        return synth.random_batch(2000 + 313 * r + i, 6, motifs=(3, 7), n_motif_vocab=50, n_attach_vocab=150)
+
+    def build(rnn):
+        a = bench.make_args(rnn, 100, 5, 16, 50, 150)
+        a.vocab, a.diterT, a.diterG, a.tie_embedding = vocab, 1, 3, True
+        torch.manual_seed(0)
+        m = HierPropertyVAE(a).cuda()
+        for p in m.parameters():                       # vae_train.py:48-53
+            if p.dim() == 1:
+                torch.nn.init.constant_(p, 0)
+            else:
+                torch.nn.init.xavier_normal_(p)
+        return m
+
+    for rnn in ("GRU", "LSTM"):
+        model = build(rnn)
+        assert model.encoder.E_c[0].weight is model.decoder.hmpn.E_c[0].weight      # tied
+        broadcast_parameters(model)
+        sync = FlatGradSync(model.parameters(), encoder=model.encoder)
+        assert sync.encoder_params, "the gradient sink must be installed"
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for i in range(4):
+            batch = synth.train_batch(specs_of(rank, i))
+            sync.zero_grad()
+            model.train()
+            loss, metrics = model(*batch, beta=0.1, perturb_z=False)
+            loss.backward()
+            sync.all_reduce()
+            if i == 0:
+                reduced = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 20.0)
+            opt.step()
+            assert all(torch.isfinite(p).all() for p in model.parameters())
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "full VAE: parameters differ across ranks"
+        print("VAE %s tie_embedding: ranks bit-identical after 4 steps (loss %.4f)" % (rnn, metrics["Loss"]), flush=True)
+
+        # the reduced gradient of step 0 vs ONE process on the concatenation of all ranks' batches (no sink, no collective)
+        ref = build(rnn)
+        ref.load_state_dict(start)
+        ref.train()
+        cat = [m for r in range(world) for m in specs_of(r, 0)]
+        loss, _ = ref(*synth.train_batch(cat), beta=0.1, perturb_z=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k, p in ref.named_parameters():
+            want, got = p.grad, reduced[k]
+            scale = float(want.abs().max())
+            if scale < 1e-12:
+                assert float(got.abs().max()) < 1e-9, k
+                continue
+            worst = max(worst, float((want - got).abs().max()) / scale)
+        assert worst <= 1e-5, worst
+        print("VAE %s 2-rank all-reduced gradient vs 1-rank gradient of the concatenated batch: worst norm-wise diff %.3e"
+              % (rnn, worst), flush=True)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    full_vae_section(rank, world)
     for rnn in ("GRU", "LSTM"):
         pool = bench.make_batches(4, 8, seed0=1000 + rank * 313, gen=(4, 7), n_motif=50, n_attach=150)
         batches = [make_cuda(b) for b in pool]

@@ -26,3 +26,6 @@ def test_two_ranks_stay_bit_identical_through_the_gradient_sink(dp_rank_processe
     for cell in ("GRU", "LSTM"):
         assert "%s bucketed=1" % cell in outs[0][1] and "%s bucketed=0" % cell in outs[0][1]
         assert "%s two backwards per step" % cell in outs[0][1]
+        # the full model with tied embeddings (HierPropertyVAE, vae_train.py:78-83 order)
+        assert "VAE %s tie_embedding: ranks bit-identical" % cell in outs[0][1]
+        assert "VAE %s 2-rank all-reduced gradient vs 1-rank" % cell in outs[0][1]
