@@ -47,6 +47,76 @@ def _row0_mask(n: int, like: Tensor) -> Tensor:
     return m
 
 
+# ---------------------------------------------------------------- bf16 gate products (BASELINE configs[4])
+# ``gate_dtype`` of the functions below: "f32" = the reference's arithmetic.  "bf16" / "bf16w" restate the SAME cells
+# (ggpm/rnn.py:27-36 GRU, :88-91 LSTM) with the operands of every hidden x hidden product rounded to bf16
+# (round-to-nearest-even, what v_cvt_pk_bf16_f32 does) and the sum accumulated in the working dtype -- the arithmetic of
+# v_mfma_f32_16x16x32_bf16 -- so that the HIP bf16 path can be checked against an oracle that differs from it only by
+# summation order, instead of against itself.  Everything else (input halves, gate math, state) stays in the working
+# dtype.  Rounding points, per product y = x W^T:
+#   forward   y  = rne(x) rne(W)^T
+#   backward  dx = rne(dy) rne(W)            (the products of the backward depth kernels)
+#             dW = dy^T x                    "bf16":  weight gradients contracted from the unrounded stashes
+#             dW = rne(dy)^T rne(x)          "bf16w": bf16 operands in the tall weight-gradient contractions as well
+# The per-slot recurrent products of the reference, U_r(h_nei)[e,k] (rnn.py:31) and the hidden half of W_f([x, h_nei])[e,k]
+# (rnn.py:90), are applied once per MESSAGE and gathered, (U_r h)[bgraph[e,k]] -- the same numbers element for
+# element, but the gradient then reaches the product summed over a message's uses, which is where the kernels round it.
+def rne_bf16(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16Product(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, round_wgrad):
+        wr = rne_bf16(w)
+        ctx.save_for_backward(x, wr)
+        ctx.round_wgrad = round_wgrad
+        return rne_bf16(x) @ wr.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wr = ctx.saved_tensors
+        dyr = rne_bf16(dy)
+        dw = (dyr.t() @ rne_bf16(x)) if ctx.round_wgrad else (dy.t() @ x)
+        return dyr @ wr, dw, None
+
+
+def bf16_product(x: Tensor, w: Tensor, gate_dtype: str) -> Tensor:
+    return _Bf16Product.apply(x, w, gate_dtype == "bf16w")
+
+
+def gru_cell_bf16(p: Params, pre: str, x: Tensor, h: Tensor, bgraph: Tensor, gate_dtype: str) -> Tensor:
+    """GRU.GRU (ggpm/rnn.py:25-39) on the message state ``h`` [E, H] with bf16 gate products (see above)."""
+    I = x.shape[1]
+    Wz, Wh = p[pre + "W_z.weight"], p[pre + "W_h.weight"]
+    h_nei = gather_rows(h, bgraph)
+    q_nei = gather_rows(bf16_product(h, p[pre + "U_r.weight"], gate_dtype) + p[pre + "U_r.bias"], bgraph)
+    s = h_nei.sum(dim=1)
+    z = torch.sigmoid(x @ Wz[:, :I].t() + bf16_product(s, Wz[:, I:], gate_dtype) + p[pre + "W_z.bias"])
+    r = torch.sigmoid(_affine(p, pre + "W_r", x).unsqueeze(1) + q_nei)
+    g = (r * h_nei).sum(dim=1)
+    cand = torch.tanh(x @ Wh[:, :I].t() + bf16_product(g, Wh[:, I:], gate_dtype) + p[pre + "W_h.bias"])
+    return (1.0 - z) * s + z * cand
+
+
+def lstm_cell_bf16(p: Params, pre: str, x: Tensor, h: Tensor, c: Tensor, bgraph: Tensor, gate_dtype: str):
+    """LSTM.LSTM (ggpm/rnn.py:85-94) on the message state (h, c) with bf16 gate products (see above)."""
+    I = x.shape[1]
+    h_nei, c_nei = gather_rows(h, bgraph), gather_rows(c, bgraph)
+    s = h_nei.sum(dim=1)
+
+    def gate(name):
+        W = p[pre + name + ".0.weight"]
+        return x @ W[:, :I].t() + bf16_product(s, W[:, I:], gate_dtype) + p[pre + name + ".0.bias"]
+
+    i, o, u = torch.sigmoid(gate("W_i")), torch.sigmoid(gate("W_o")), torch.tanh(gate("W"))
+    Wf = p[pre + "W_f.0.weight"]
+    xf = x @ Wf[:, :I].t() + p[pre + "W_f.0.bias"]
+    f = torch.sigmoid(xf.unsqueeze(1) + gather_rows(bf16_product(h, Wf[:, I:], gate_dtype), bgraph))
+    c_new = i * u + (f * c_nei).sum(dim=1)
+    return o * torch.tanh(c_new), c_new
+
+
 # ---------------------------------------------------------------- GRU (ggpm/rnn.py:5-59)
 def gru_cell(p: Params, pre: str, x: Tensor, h_nei: Tensor) -> Tensor:
     """GRU.GRU -- ggpm/rnn.py:25-39."""
@@ -60,13 +130,16 @@ def gru_cell(p: Params, pre: str, x: Tensor, h_nei: Tensor) -> Tensor:
 
 
 def gru_forward(p: Params, pre: str, fmess: Tensor, bgraph: Tensor, depth: int,
-                trace: list | None = None) -> Tensor:
+                trace: list | None = None, gate_dtype: str = "f32") -> Tensor:
     """GRU.forward -- ggpm/rnn.py:41-50."""
     H = p[pre + "U_r.weight"].shape[0]
     h = torch.zeros(fmess.shape[0], H, dtype=fmess.dtype, device=fmess.device)
     mask = _row0_mask(h.shape[0], h)
     for _ in range(depth):
-        h = gru_cell(p, pre, fmess, gather_rows(h, bgraph)) * mask
+        if gate_dtype == "f32":
+            h = gru_cell(p, pre, fmess, gather_rows(h, bgraph)) * mask
+        else:
+            h = gru_cell_bf16(p, pre, fmess, h, bgraph, gate_dtype) * mask
         if trace is not None:
             trace.append(h)
     return h
@@ -88,14 +161,17 @@ def lstm_cell(p: Params, pre: str, x: Tensor, h_nei: Tensor, c_nei: Tensor) -> T
 
 
 def lstm_forward(p: Params, pre: str, fmess: Tensor, bgraph: Tensor, depth: int,
-                 trace: list | None = None) -> Tuple[Tensor, Tensor]:
+                 trace: list | None = None, gate_dtype: str = "f32") -> Tuple[Tensor, Tensor]:
     """LSTM.forward -- ggpm/rnn.py:96-108."""
     H = p[pre + "W_i.0.weight"].shape[0]
     h = torch.zeros(fmess.shape[0], H, dtype=fmess.dtype, device=fmess.device)
     c = torch.zeros_like(h)
     mask = _row0_mask(h.shape[0], h)
     for _ in range(depth):
-        h, c = lstm_cell(p, pre, fmess, gather_rows(h, bgraph), gather_rows(c, bgraph))
+        if gate_dtype == "f32":
+            h, c = lstm_cell(p, pre, fmess, gather_rows(h, bgraph), gather_rows(c, bgraph))
+        else:
+            h, c = lstm_cell_bf16(p, pre, fmess, h, c, bgraph, gate_dtype)
         h = h * mask
         c = c * mask
         if trace is not None:
@@ -104,12 +180,14 @@ def lstm_forward(p: Params, pre: str, fmess: Tensor, bgraph: Tensor, depth: int,
 
 
 def rnn_forward(p: Params, pre: str, rnn_type: str, fmess: Tensor, bgraph: Tensor, depth: int,
-                trace: list | None = None) -> Tensor:
+                trace: list | None = None, gate_dtype: str = "f32") -> Tensor:
     """rnn(...) followed by get_hidden_state -- ggpm/encoder.py:29-30, rnn.py:22-23,82-83."""
+    if gate_dtype not in ("f32", "bf16", "bf16w"):
+        raise ValueError("gate_dtype " + gate_dtype)
     if rnn_type == "GRU":
-        return gru_forward(p, pre, fmess, bgraph, depth, trace)
+        return gru_forward(p, pre, fmess, bgraph, depth, trace, gate_dtype)
     if rnn_type == "LSTM":
-        return lstm_forward(p, pre, fmess, bgraph, depth, trace)[0]
+        return lstm_forward(p, pre, fmess, bgraph, depth, trace, gate_dtype)[0]
     raise ValueError("unsupported rnn cell type " + rnn_type)
 
 
@@ -156,9 +234,10 @@ def _drop(x: Tensor, masks, site: str) -> Tensor:
 
 
 def mpn_forward(p: Params, pre: str, rnn_type: str, depth: int, fnode: Tensor, fmess: Tensor,
-                agraph: Tensor, bgraph: Tensor, trace: list | None = None, masks=None) -> Tuple[Tensor, Tensor]:
+                agraph: Tensor, bgraph: Tensor, trace: list | None = None, masks=None,
+                gate_dtype: str = "f32") -> Tuple[Tensor, Tensor]:
     """MPNEncoder.forward -- ggpm/encoder.py:28-38; W_o = Linear + ReLU + Dropout (:15-19)."""
-    h = rnn_forward(p, pre + "rnn.", rnn_type, fmess, bgraph, depth, trace)
+    h = rnn_forward(p, pre + "rnn.", rnn_type, fmess, bgraph, depth, trace, gate_dtype)
     nei = gather_rows(h, agraph).sum(dim=1)
     node = _drop(torch.relu(_affine(p, pre + "W_o.0", torch.cat([fnode, nei], dim=1))), masks, pre + "W_o")
     return node * _row0_mask(node.shape[0], node), h
@@ -211,22 +290,25 @@ def embed_root(p: Params, hmess: Tensor, tree_inputs, roots: Sequence[int]) -> T
 
 
 def hier_encoder_forward(p: Params, rnn_type: str, depthT: int, depthG: int, tree_tensors,
-                         graph_tensors, atom_size: int = 38, trace: Dict[str, list] | None = None, masks=None):
+                         graph_tensors, atom_size: int = 38, trace: Dict[str, list] | None = None, masks=None,
+                         gate_dtype: str = "f32"):
     """HierMPNEncoder.forward -- ggpm/encoder.py:140-157.
 
     ``tree_tensors`` / ``graph_tensors`` are the A0 tuples as int64 tensors with the
     host ``scope`` list last.  Returns (hroot, hnode, hinter, hatom).  ``masks``: training-mode dropout with injected
     masks (scaled keep masks) for the seven Dropout modules, keyed "E_i", "E_c", "W_i", "W_c" and
-    "<level>_encoder.W_o"; None = dropout inactive.
+    "<level>_encoder.W_o"; None = dropout inactive.  ``gate_dtype``: "f32", or "bf16" / "bf16w" for the bf16 gate
+    products of BASELINE configs[4] (see ``bf16_product``).
     """
     dtype = p["W_root.0.weight"].dtype
     tr = (lambda k: None) if trace is None else (lambda k: trace.setdefault(k, []))
     t = embed_graph(p, graph_tensors, atom_size, dtype)
-    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"), masks=masks)
+    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"), masks=masks, gate_dtype=gate_dtype)
     t = embed_inter(p, tree_tensors, hatom, masks)
-    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"), masks=masks)
+    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"), masks=masks, gate_dtype=gate_dtype)
     t = embed_tree(p, tree_tensors, hinter, masks)
-    hnode, hmess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, *t, trace=tr("tree"), masks=masks)
+    hnode, hmess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, *t, trace=tr("tree"), masks=masks,
+                               gate_dtype=gate_dtype)
     hroot = embed_root(p, hmess, t, [st for st, _ in tree_tensors[-1]])
     return hroot, hnode, hinter, hatom
 

@@ -688,63 +688,86 @@ def test_dropout_in_the_drivers_matches_oracle_with_the_same_masks(name):
         assert torch.equal(a, b)
 
 
-BF16_OUT_TOL, BF16_GRAD_TOL = 0.2, 0.3
+BF16_ORACLE_MODE = "bf16"      # rounding points of oracle/ref_encoder.py::bf16_product the HIP path implements
+BF16_TOL = 2e-3      # HIP bf16 path vs the oracle with the SAME operand roundings (norm-wise, every tensor)
 
 
-@pytest.mark.parametrize("case", ["cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10"])
-def test_bf16_gate_products(case):
-    """BASELINE configs[4] names bf16: ``encoder.gate_dtype = "bf16"`` rounds the OPERANDS of the H x H gate products of
-    the depth loops to bf16 (8 mantissa bits) and accumulates in fp32 on v_mfma_f32_16x16x32_bf16; state, stashes, gate
-    math, input projections and weight gradients stay fp32.  This is NOT the 1e-4 contract.  An operand error of 2^-9
-    per product goes through 20-30 recurrent depths; measured against the fp32 gate products of the same HIP path on the
-    same inputs (norm-wise, worst tensor): LSTM H=250 depth 20 outputs 4e-3 / gradients 0.17, LSTM H=600 depth 30 on
-    ~200-atom polymers 3e-2 / 4e-2, GRU H=300 depth 20 0.12 / 0.16 (the sum-aggregating GRU amplifies more, see
-    test_configs4_polymer_shard_matches_oracle).  Stated tolerance: BF16_OUT_TOL for outputs and KL, BF16_GRAD_TOL for
-    every parameter gradient -- a mixed-precision training mode to be judged by its loss curve, not a parity mode."""
+def _bf16_case(case):
+    """-> (build(), numpy tensors, H, rnn, depth, params for the oracle)"""
     from ggpm_amd import synth
-    from ggpm_amd.nnutils import make_cuda
-    if case.startswith("cfg"):
+    if case.startswith(("cfg", "tiny")):
         g = Golden(case)
-        build = lambda: _build_encoder(g)
-        tensors, H = g.numpy_tensors(), g.H
-    else:
-        rnn, depth = ("LSTM", 30) if "lstm" in case else ("GRU", 10)
-        H = 600
-        specs = synth.random_batch(606, 3, motifs=(46, 58), n_motif_vocab=60, n_attach_vocab=180)
-        tensors = synth.tensorize(specs)
+        return (lambda: _build_encoder(g)), g.numpy_tensors(), g.H, g.rnn, (g.depthT, g.depthG), g.params
+    rnn, depth = ("LSTM", 30) if "lstm" in case else ("GRU", 10)
+    H = 600
+    specs = synth.random_batch(606, 3, motifs=(46, 58), n_motif_vocab=60, n_attach_vocab=180)
+    tensors = synth.tensorize(specs)
+    from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+    sd = seeded_state_dict(encoder_param_shapes(rnn, H, 60, 180), 5)
+    sd.update(seeded_state_dict(vae_head_shapes(H, 32), 6))
 
-        def build():
-            from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
-            from ggpm_amd.property_vae import HierEncoderVAE
+    def build():
+        from ggpm_amd.property_vae import HierEncoderVAE
 
-            class A:
-                pass
-            a = A()
-            a.vocab, a.atom_vocab = _Vocab((60, 180)), _Vocab(38)
-            a.rnn_type, a.embed_size, a.hidden_size = rnn, H, H
-            a.depthT = a.depthG = depth
-            a.dropout, a.latent_size = 0.0, 32
-            sd = seeded_state_dict(encoder_param_shapes(rnn, H, 60, 180), 5)
-            sd.update(seeded_state_dict(vae_head_shapes(H, 32), 6))
-            m = HierEncoderVAE(a).to(_dev())
-            m.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
-            return m
-    res = []
+        class A:
+            pass
+        a = A()
+        a.vocab, a.atom_vocab = _Vocab((60, 180)), _Vocab(38)
+        a.rnn_type, a.embed_size, a.hidden_size = rnn, H, H
+        a.depthT = a.depthG = depth
+        a.dropout, a.latent_size = 0.0, 32
+        m = HierEncoderVAE(a).to(_dev())
+        m.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
+        return m
+
+    def params(requires_grad=False):
+        return {k: torch.from_numpy(v.copy()).requires_grad_(requires_grad) for k, v in sd.items()}
+    return build, tensors, H, rnn, (depth, depth), params
+
+
+@pytest.mark.parametrize("case", ["tiny_gru_s1", "cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10"])
+def test_bf16_gate_products_match_the_bf16_oracle(case):
+    """BASELINE configs[4] names bf16: ``encoder.gate_dtype = "bf16"`` runs the H x H gate products of the depth loops
+    on v_mfma_f32_16x16x32_bf16 -- operands rounded to bf16 (RNE), fp32 accumulate -- and (round 3) the tall
+    weight-gradient contractions on bf16 operands as well; state, gate math and input projections stay fp32.
+    Checked against oracle/ref_encoder.py with ``gate_dtype="bf16w"``: the reference's cells (ggpm/rnn.py:27-36, 88-91)
+    with the SAME operands rounded at the SAME points, so that the two differ by fp32 summation order (and the rare
+    operand whose rounding flips on a 1e-7 difference) only -- outputs, KL and EVERY parameter gradient within
+    BF16_TOL = 2e-3 norm-wise.  How far bf16 moves the result from the fp32 arithmetic is printed beside it (that
+    distance is a property of the precision, not of the kernels)."""
+    from oracle import ref_encoder as ref
+    from ggpm_amd.nnutils import make_cuda
+    from ggpm_amd.property_vae import rsample
+    build, tensors, H, rnn, (depthT, depthG), params = _bf16_case(case)
+    res = {}
     for dt in ("f32", "bf16"):
         model = build()
         model.encoder.gate_dtype = dt
         tree, graph = make_cuda(tensors)
         outs = model.encoder.forward_padded(tree, graph)
-        from ggpm_amd.property_vae import rsample
         _, kl = rsample(outs[0], model.R_mean, model.R_var, perturb=False)
         (kl + sum((o[:, :H] * o[:, :H]).sum() for o in outs)).backward()
-        res.append(([o.detach()[:, :H].cpu().numpy() for o in outs] + [np.asarray(float(kl.detach()))],
-                    {k: v.grad.cpu().numpy() for k, v in model.named_parameters() if v.grad is not None}))
-    worst_o = max(rel_err(b, a) for a, b in zip(res[0][0], res[1][0]))
-    worst_g = max(rel_err(res[1][1][k], res[0][1][k]) for k in res[0][1] if np.abs(res[0][1][k]).max() > 0)
-    print("bf16 vs fp32 gate products (%s): outputs %.2e, gradients %.2e" % (case, worst_o, worst_g))
-    assert worst_o > 1e-6          # the bf16 path really ran
-    assert worst_o < BF16_OUT_TOL and worst_g < BF16_GRAD_TOL, (worst_o, worst_g)
+        res[dt] = ([o.detach()[:, :H].cpu().numpy() for o in outs] + [np.asarray(float(kl.detach()))],
+                   {k[len("encoder."):] if k.startswith("encoder.") else k: v.grad.cpu().numpy()
+                    for k, v in model.named_parameters() if v.grad is not None})
+    p = params(requires_grad=True)
+    tt, gt = ref.to_long_tensors(tensors[0]), ref.to_long_tensors(tensors[1])
+    routs = ref.hier_encoder_forward(p, rnn, depthT, depthG, tt, gt, gate_dtype=BF16_ORACLE_MODE)
+    _, rkl = ref.rsample_kl(p, routs[0])
+    (rkl + sum((o * o).sum() for o in routs)).backward()
+    want_o = [o.detach().numpy() for o in routs] + [np.asarray(float(rkl.detach()))]
+    got_o, got_g = res["bf16"]
+    errs_o = [rel_err(a, b) for a, b in zip(got_o, want_o)]
+    errs_g = {k: rel_err(got_g[k], v.grad.numpy()) for k, v in p.items() if v.grad is not None and np.abs(v.grad.numpy()).max() > 0}
+    worst_k = max(errs_g, key=errs_g.get)
+    shift_o = max(rel_err(b, a) for a, b in zip(res["f32"][0], got_o))
+    shift_g = max(rel_err(got_g[k], res["f32"][1][k]) for k in errs_g)
+    print("bf16 (%s): HIP vs bf16 oracle: outputs %.2e, gradients %.2e (%s); distance bf16 -> fp32 arithmetic: outputs %.2e, "
+          "gradients %.2e" % (case, max(errs_o), errs_g[worst_k], worst_k, shift_o, shift_g))
+    assert shift_o > 1e-6                    # the bf16 path really ran
+    assert set(errs_g) <= set(got_g)
+    assert max(errs_o) <= BF16_TOL, errs_o
+    assert errs_g[worst_k] <= BF16_TOL, (worst_k, errs_g[worst_k])
 
 
 @pytest.mark.parametrize("name", ["cfg_gru_s0", "cfg_lstm_s2", "tiny_gru_s1", "edge_gru_s32"])

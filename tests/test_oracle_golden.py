@@ -452,3 +452,35 @@ def test_oracle_enum_attach_matches_reference(name):
     assert rel_err(node.grad.numpy(), z["d_node"]) < 2e-6
     for kk in p:
         assert rel_err(p[kk].grad.numpy(), z["grad/" + kk]) < 2e-6, kk
+
+
+@pytest.mark.parametrize("name", ["tiny_gru_s1", "tiny_lstm_s2", "cfg_gru_s0", "cfg_lstm_s2"])
+def test_bf16_cells_of_the_oracle_are_the_reference_cells_up_to_the_rounding(name, monkeypatch):
+    """oracle/ref_encoder.py ``gate_dtype="bf16"`` restates the GRU / LSTM cells with the recurrent products applied per
+    message and the hidden halves split off, so that operands can be rounded where the kernels round them.  With the
+    rounding replaced by the identity that restatement must reproduce the reference's outputs and gradients (fixtures)
+    like the plain oracle does -- which pins the bf16 oracle's algebra to the reference; and with the rounding on it must
+    move the result by a bf16-sized amount, no more."""
+    g = Golden(name)
+    tree, graph = g.tensors()
+
+    def run(mode):
+        p = g.params(requires_grad=True)
+        outs = ref.hier_encoder_forward(p, g.rnn, g.depthT, g.depthG, tree, graph, gate_dtype=mode)
+        _, kl = ref.rsample_kl(p, outs[0])
+        loss = g.beta * kl
+        for c, o in zip(g.loss_coeffs([tuple(o.shape) for o in outs]), outs):
+            loss = loss + (torch.from_numpy(c) * o).sum()
+        loss.backward()
+        return outs, p
+
+    monkeypatch.setattr(ref, "rne_bf16", lambda t: t)
+    outs, p = run("bf16w")
+    for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
+        assert rel_err(o.detach().numpy(), g.z[k]) <= 2e-5, k
+    for k, v in p.items():
+        g.check_grad(k, (v.grad if v.grad is not None else torch.zeros_like(v)).numpy(), rel=1e-4)
+    monkeypatch.undo()
+    outs_b, _ = run("bf16")
+    shift = max(rel_err(o.detach().numpy(), g.z[k]) for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs_b))
+    assert 1e-6 < shift < 0.3, shift      # (GRU at depth 20 amplifies a 2^-9 operand error to ~0.1: sum aggregation)
