@@ -28,6 +28,8 @@ SIGNATURES = {
     "ggpm_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, I, P, I, I, I, P, c_size_t, P]),
     "ggpm_gemm_grouped": (I, [I, I, I, I, I, I, P, P]),                   # problems: ggpm_gemm_problem[count]
     "ggpm_gemm_ksegments": (I, [I, I, I, I, P, P, P, P, P, P, I, I, P, I, I, I, P]),
+    "ggpm_gemm_tn_bf16": (I, [I, I, I, P, I, P, I, P, I, P, c_size_t, P]),
+    "ggpm_gemm_tn_bf16_applies": (I, [I, I, I]),
     "ggpm_colsum": (I, [P, I, I, I, P, P, P]),
     "ggpm_act_backward": (I, [P, P, I, I, I, I, I, P, P]),
     "ggpm_segment_sum": (I, [P, I, P, P, I, I, P, I, I, I, P]),
@@ -36,6 +38,7 @@ SIGNATURES = {
     "ggpm_adam_step": (I, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, I, P]),
     "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
+    "ggpm_level_gate_dtype": (I, [I]),
     "ggpm_gru_pack_floats": (c_size_t, [I]),
     "ggpm_gru_forward": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),

@@ -58,8 +58,9 @@ __device__ __forceinline__ void ggpm_lds_barrier() {
 bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count);
 // `count` (<= 4) tall contractions C_i = A_i^T B_i of one output shape (K_i may differ) in one launch + one reduce;
 // falls back to sequential ggpm_gemm calls when a member does not qualify for the tall kernel
+// bf16 != 0: operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate (gemm_tn_tall_bf16)
 int ggpm_gemm_tall_grouped(int M, int N, int count, const ggpm_gemm_problem* p, const int* K, float* ws, size_t ws_bytes,
-                           ggpm_stream_t stream);
+                           ggpm_stream_t stream, int bf16 = 0);
 #define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
 typedef ggpm_gemm_problem GgpmGemmProblem;
 

@@ -68,8 +68,9 @@ struct Dims {
 
 // the level calls of this thread take the gate-product dtype from a thread-local (tile_mma.h) for the driver's duration
 struct GateDtypeScope {
-    explicit GateDtypeScope(int dtype) { ggpm_set_gate_dtype(dtype); }
-    ~GateDtypeScope() { ggpm_set_gate_dtype(0); }
+    int prev;
+    explicit GateDtypeScope(int dtype) : prev(ggpm_gate_dtype()) { ggpm_set_gate_dtype(dtype); }
+    ~GateDtypeScope() { ggpm_set_gate_dtype(prev); }      // (nests: the side-stream bodies may run on the caller's thread)
 };
 
 // dropout sites (include/ggpm_hip.h)
@@ -611,6 +612,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
     const int blo = backward_lo(d, level, depth);
+    const int gate_dtype = d.gate_dtype;
     struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
@@ -637,8 +639,11 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             float* const dWk[4] = {dW0, dW1, dW2, dW3};
             float* const dbk[4] = {db0, db1, db2, db3};
             ggpm_wgrad_lo_depth(blo);
-            CK(ggpm_lstm_weight_grads(E1, H, depth, Hs, St, level_work, wc.level_work_bytes, dWk[0] + I, I + H, dWk[1] + I,
-                                      I + H, dWk[2] + I, I + H, dWk[3] + I, I + H, sw));
+            {       // (thread-local like the hint above: this body may run on the side worker's thread)
+                GateDtypeScope tall_dtype(gate_dtype);
+                CK(ggpm_lstm_weight_grads(E1, H, depth, Hs, St, level_work, wc.level_work_bytes, dWk[0] + I, I + H, dWk[1] + I,
+                                          I + H, dWk[2] + I, I + H, dWk[3] + I, I + H, sw));
+            }
             if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
                 GgpmGemmProblem gp[4];
                 for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
@@ -707,6 +712,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     return st.on_side([=]() -> int {
         if (!overlap) {
             ggpm_wgrad_lo_depth(blo);
+            GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)
             CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
                                      dbu, dWh + I, I + H, sw));
         }

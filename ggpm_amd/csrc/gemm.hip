@@ -694,6 +694,118 @@ __global__ void __launch_bounds__(256) gemm_tn_tall(GemmGroupArgs gg, int splits
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same contraction on bf16 operands (BASELINE configs[4]: "bf16"): C slab = rne(A)^T rne(B), fp32 accumulate, on
+// v_mfma_f32_16x16x32_bf16.  At 16x the fp32 matrix rate the launch is bound by the operand stream (K x (M + N) floats
+// from HBM / L2), not by the matrix pipe, so the structure is the plain one: 32-row k-steps, operands fetched as fp32
+// with buffer loads one step ahead (K tail and column overhang read zeros), rounded to bf16 on their way into a
+// double-buffered LDS image [k][A columns | B columns], ONE LDS-only barrier per step, several workgroups per CU to
+// cover the load latency.  Both MFMA operands want 8 consecutive k per lane while memory is k-major, so the fragments
+// are read with the transposing ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group): lane group g takes the
+// step's rows 4g..4g+3 and 16+4g..16+4g+3 -- the SAME permutation of k for both operands, so the sum is unchanged --
+// which puts the eight rows a 32-lane half reads at distinct bank octets with a row pitch of 168 dwords.
+// Same output tile and the same fragment-order slab as gemm_tn_tall, so tall_reduce serves both.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
+typedef short gs16x4 __attribute__((ext_vector_type(4)));
+constexpr int BTK = 32, BLD = 336;      // k rows per step; bf16 elements per LDS row (672 B = 168 dwords)
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, int splits) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ls[2][BTK * BLD];
+    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);        // tiles of one K chunk share an XCD's L2
+    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y;
+    const int bzz = logical / (gridDim.x * gridDim.y);
+    const GemmArgs& g = gg.p[bzz / splits];
+    const int bz = bzz % splits;
+    const int m0 = by * TM, n0 = bx * TN;
+    const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // waves 0-1 stage the A rows of a step, waves 2-3 the B rows: 32 rows x 40 float4 = 10 per thread
+    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+    const float* P = isb ? g.B : g.A;
+    const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
+    unsigned voff[10];
+    int loff[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int f = (threadIdx.x & 127) + 128 * i;
+        const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
+        loff[i] = k * BLD + isb * TM + c;
+        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
+    }
+    const unsigned vstep = (unsigned)BTK * ld * 4;
+    f32x4 r[10];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+            if (voff[i] != 0xffffff00u) voff[i] += vstep;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const gbf16x4 w = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
+            *reinterpret_cast<gbf16x4*>(&Ls[buf][loff[i]]) = w;
+        }
+    };
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment reads: lane 4q+p of 16-lane group g supplies row 4g+q (resp. 16+4g+q), columns 4p..4p+3 of
+    // the 16-column block; lane j of the group receives column j, the four rows in its four elements
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int fa0 = (4 * grp + q) * BLD + wm * 80 + 4 * pp;
+    const int fb0 = (4 * grp + q) * BLD + TM + wn * 80 + 4 * pp;
+    typedef __attribute__((address_space(3))) gs16x4* lds_v4;
+    auto frag = [&](const __bf16* base) -> gbf16x8 {
+        const gs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+        const gs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 16 * BLD));
+        gs16x4 v[2] = {lo, hi};
+        return __builtin_bit_cast(gbf16x8, v);
+    };
+
+    fetch();
+    put(0);
+    fetch();
+    ggpm_lds_barrier();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
+        gbf16x8 fa[5], fb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            fa[i] = frag(&Ls[cur][fa0 + 16 * i]);
+            fb[i] = frag(&Ls[cur][fb0 + 16 * i]);
+        }
+        put(cur ^ 1);           // rows of step s+1 (loaded a step ago); every wave finished reading that buffer before the
+        fetch();                // barrier that ended step s-1.  Then the loads of step s+2 fly under this step's MFMAs
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        ggpm_lds_barrier();
+    }
+    // split-K slab in the fragment order of gemm_tn_tall (lane l: rows 4*(l>>4) + 0..3, column l & 15 of every block)
+    f32x4* slab = reinterpret_cast<f32x4*>(g.ws) +
+                  ((((size_t)bz * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + wave) * 25) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) slab[(i * 5 + j) * 64] = acc[i][j];
+}
+
 // Sums the fragment-order slabs of gemm_tn_tall over the K chunks (fixed order: four interleaved partial sums per
 // workgroup, combined as (0+1)+(2+3)) and writes C.  One workgroup per (tile, wave, 16 x 16 block).
 __global__ void __launch_bounds__(256) tall_reduce(GemmGroupArgs gg, int splits, int tiles_n, int tiles) {
@@ -739,8 +851,10 @@ inline bool tall_shape(int M, int N, int K) {
 inline size_t tall_slab_bytes(int M, int N) {
     return (size_t)ggpm_ceil_div(M, TM) * ggpm_ceil_div(N, TN) * 4 * 25 * 64 * sizeof(f32x4);
 }
-inline int tall_splits(int M, int N, int K) {
-    static const int target = [] { const char* e = getenv("GGPM_GEMM_TALL_WGS"); return e ? atoi(e) : 256; }();
+constexpr int GGPM_TALL_BF16_WGS = 768;      // workgroups of a bf16 tall launch (three per CU: it lives on overlapped loads)
+inline int tall_splits(int M, int N, int K, int target_wgs = 0) {
+    static const int target_env = [] { const char* e = getenv("GGPM_GEMM_TALL_WGS"); return e ? atoi(e) : 256; }();
+    const int target = target_wgs > 0 ? target_wgs : target_env;
     const int tiles = ggpm_ceil_div(M, TM) * ggpm_ceil_div(N, TN);
     int s = target / tiles, maxs = K / (8 * TK);
     if (s > maxs) s = maxs;
@@ -866,7 +980,7 @@ extern "C" size_t ggpm_gemm_workspace_bytes(int M, int N, int K) {
     const int s = choose_splits(M, N, K);
     size_t bytes = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
     if (tall_shape(M, N, K)) {      // the caller's transposes are not known here: room for either kernel
-        const int ts = tall_splits(M, N, K);
+        const int ts = max(tall_splits(M, N, K), tall_splits(M, N, K, GGPM_TALL_BF16_WGS));     // (either operand dtype)
         if (ts > 1) bytes = max(bytes, ts * tall_slab_bytes(M, N));
     }
     return bytes;
@@ -975,22 +1089,24 @@ inline void fill_args(GemmArgs& g, int M, int N, int K, const GgpmGemmProblem& p
 }  // namespace
 
 int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, const int* K, float* ws, size_t ws_bytes,
-                           ggpm_stream_t stream) {
+                           ggpm_stream_t stream, int bf16) {
     GGPM_CLEAR_STALE_ERROR();
     if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || !K || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
     const size_t slab = tall_slab_bytes(M, N);
-    bool ok = use_tall && count > 1 && ws != nullptr;
+    // (bf16 operands exist in the tall kernel only: a group that does not qualify falls back to fp32 products, which is
+    // the more accurate side of the stated tolerance)
+    bool ok = use_tall && (count > 1 || bf16) && ws != nullptr;
     int splits = 1 << 30;
     for (int i = 0; i < count && ok; ++i) {
         ok = (p[i].lda & 3) == 0 && (p[i].ldb & 3) == 0 && ((uintptr_t)p[i].A & 15) == 0 && ((uintptr_t)p[i].B & 15) == 0 &&
              p[i].lda >= ggpm_round_up(M, 4) && p[i].ldb >= ggpm_round_up(N, 4) && tall_shape(M, N, K[i]) &&
              p[i].n_pad <= ggpm_round_up(N, TN) && p[i].n_pad >= N && p[i].n_pad <= p[i].ldc &&
              (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
-        splits = min(splits, tall_splits(M, N, K[i]));
+        splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : 0));
     }
     if (ok) splits = min(splits, (int)(ws_bytes / (count * slab)));      // the group shares the workspace
-    if (!ok || splits < 2) {
+    if (!ok || splits < (bf16 ? 1 : 2)) {
         for (int i = 0; i < count; ++i) {
             const int rc = ggpm_gemm(1, 0, M, N, K[i], p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].n_pad,
                                      p[i].bias, p[i].accumulate, p[i].act, p[i].zero_row0, ws, ws_bytes, stream);
@@ -1003,16 +1119,29 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     GemmGroupArgs gg;
     for (int i = 0; i < count; ++i) {
         fill_args(gg.p[i], M, N, K[i], p[i]);
-        gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), TK);
+        gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), bf16 ? BTK : TK);
         gg.p[i].ws = ws + (size_t)i * splits * (slab / sizeof(float));
     }
     for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
-    gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    if (bf16) gemm_tn_tall_bf16<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    else gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
     tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits, tiles_n, tiles_n * tiles_m);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+extern "C" int ggpm_gemm_tn_bf16_applies(int M, int N, int K) {
+    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    return use_tall && M > 0 && N > 0 && K > 0 && tall_shape(M, N, K) ? 1 : 0;
+}
+
+extern "C" int ggpm_gemm_tn_bf16(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 float* ws, size_t ws_bytes, ggpm_stream_t stream) {
+    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || ldc < N) return GGPM_ERR_ARG;
+    const GgpmGemmProblem p = {A, lda, B, ldb, C, ldc, N, nullptr, 0, GGPM_ACT_NONE, 0};
+    return ggpm_gemm_tall_grouped(M, N, 1, &p, &K, ws, ws_bytes, stream, 1);
 }
 
 bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count) {

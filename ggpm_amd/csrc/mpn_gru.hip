@@ -72,6 +72,11 @@ void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s) {
 namespace { thread_local int g_gate_dtype = 0; }
 void ggpm_set_gate_dtype(int dtype) { g_gate_dtype = dtype == 1 ? 1 : 0; }
 int ggpm_gate_dtype() { return g_gate_dtype; }
+extern "C" int ggpm_level_gate_dtype(int dtype) {
+    const int prev = g_gate_dtype;
+    if (dtype == 0 || dtype == 1) g_gate_dtype = dtype;
+    return prev;
+}
 
 namespace {
 
@@ -1066,12 +1071,12 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         gp[2].A = dq0;
         gp[2].B = Hs + (size_t)first_slot * slot;
         Ks[2] = KQ;
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
         if (rc) return rc;
         rc = ggpm_colsum(dq0, Hp, KQ, H, dbu, csws, stream);
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream);
+        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);

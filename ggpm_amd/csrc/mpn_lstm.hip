@@ -841,10 +841,10 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
         gp[3].A = DQ + (size_t)first_slot * slot;
         gp[3].B = Hs + (size_t)first_slot * slot;
         Ks[3] = (depth - first_slot) * E1;
-        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream);
+        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }

@@ -300,7 +300,8 @@ class DecodeSchedule:
         plan = {k: ((view32 if k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos") else view)(i)).view(shape)
                 for k, (i, shape) in ptab.items()}
         self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, plan=plan,
-                         **{k: view(v) for k, v in tail.items()})
+                         **{k: view(v) for k, v in tail.items()},
+                         **{k + "32": view32(tail[k]) for k in ("topo_batch", "cls_batch", "assm_batch")})
         return self
 
 
@@ -551,11 +552,11 @@ class HierMPNDecoder(ScoreHeads):
     def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev):
         """The three batched heads and their losses / accuracies (ggpm/decoder.py:261-284)."""
         H = self.hidden_size
-        topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch"], topo_vecs)
+        topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch32"], topo_vecs)
         topo_loss = bce_with_logits_sum(topo_scores, D["topo_label"])
         topo_acc = ((topo_scores.detach() >= 0).long() == D["topo_label"]).float().sum() / D["topo_label"].numel()
 
-        cls_loss, cls_pred, icls_pred = self.cls_losses(src_tree_vecs, D["cls_batch"], cls_vecs, D["cls_clab"],
+        cls_loss, cls_pred, icls_pred = self.cls_losses(src_tree_vecs, D["cls_batch32"], cls_vecs, D["cls_clab"],
                                                         D["cls_ilab"])
         cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
 
@@ -564,7 +565,7 @@ class HierMPNDecoder(ScoreHeads):
             vec = torch.cat(assm_vecs, dim=0)
             buf = torch.zeros(P * C, vec.shape[1], dtype=torch.float32, device=dev)
             buf = buf.index_copy(0, torch.cat(assm_dest), vec)       # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
-            scores = self.get_assm_score(src_graph_vecs, D["assm_batch"].view(P, C), buf.view(P, C, -1)[:, :, :H])
+            scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H])
             labels = torch.zeros(P, dtype=torch.long, device=dev)    # "the label is always the first of assm_cands"
             assm_loss, _ = cross_entropy_sum(scores.contiguous(), labels)
             s = scores.detach()

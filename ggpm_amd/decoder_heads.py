@@ -109,9 +109,20 @@ class ScoreHeads(nn.Module):
         self.matchNN = nn.Sequential(nn.Linear(hidden_size + embed_size + MAX_POS, hidden_size), nn.ReLU())
         self.W_assm = nn.Linear(hidden_size, latent_size)
 
+    def _context(self, src_vecs, batch_idx):
+        """``src_vecs.index_select(0, batch_idx)`` (ggpm/decoder.py:138,146,161) through the library's gather: its
+        backward sums the rows of one molecule in a fixed order (transposed CSR), where index_select's backward uses
+        float atomics -- every prediction of a molecule adds into the same row of d(latent vector), so with atomics
+        the whole encoder's gradient changes in its last bits from run to run."""
+        if batch_idx.dtype != torch.int32:
+            batch_idx = batch_idx.to(torch.int32)
+        idx = batch_idx if batch_idx.dim() == 1 else batch_idx.reshape(-1)    # (a resident 1-D index keeps its CSR memo)
+        L = src_vecs.shape[1]
+        src = src_vecs if src_vecs.stride(1) == 1 else src_vecs.contiguous()
+        return F_.gather_rows(src, idx, F_.csr_from_index(idx, ncols=src.shape[0]), L, (L + 3) // 4 * 4)
+
     def _parts(self, src_vecs, batch_idx, vecs):
-        cxt = src_vecs.index_select(0, batch_idx)
-        return [vecs.contiguous(), cxt], [self.hidden_size, self.latent_size]
+        return [vecs.contiguous(), self._context(src_vecs, batch_idx)], [self.hidden_size, self.latent_size]
 
     def get_topo_score(self, src_tree_vecs, batch_idx, topo_vecs):
         """reference ggpm/decoder.py:136-141"""
@@ -142,5 +153,5 @@ class ScoreHeads(nn.Module):
         shape = assm_vecs.shape
         flat = assm_vecs.reshape(-1, shape[-1]).contiguous()
         proj = F_.linear([flat], [self.hidden_size], self.W_assm.weight, self.W_assm.bias)[:, :self.latent_size]
-        cxt = src_graph_vecs.index_select(0, batch_idx.reshape(-1))
+        cxt = self._context(src_graph_vecs, batch_idx)[:, :self.latent_size]
         return (proj * cxt).sum(dim=-1).view(shape[:-1])

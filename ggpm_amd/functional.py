@@ -713,9 +713,10 @@ class _GruLevel(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H):
+    def forward(ctx, x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H, gate_dtype=0):
         _need_gpu(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h)
         lib = _lib.load()
+        ctx.gate_dtype = gate_dtype
         E1, Hp = x.shape[0], padded_hidden(H)
         f32 = dict(dtype=torch.float32, device=x.device)
         save = any(ctx.needs_input_grad)
@@ -749,10 +750,11 @@ class _GruLevel(torch.autograd.Function):
                 _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack), _p(xwork), _p(sync), _stream()), "gru_forward_persistent")
             _PERSIST["sync"] = sync
         else:
-            _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0),
-                                            _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr),
-                                            _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
-                                            _p(wpack), int(save), _stream()), "gru_forward")
+            with _gate_dtype(gate_dtype):
+                _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0),
+                                                _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr),
+                                                _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                                _p(wpack), int(save), _stream()), "gru_forward")
         if save:
             ctx.save_for_backward(x, W_z, W_r, U_r, W_h)
             ctx.stash = (X[1], Hs, Qs, Ss, Gs, Zs, Ms, Rs)
@@ -798,12 +800,13 @@ class _GruLevel(torch.autograd.Function):
                 _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4, _stream(),
                 ctypes.c_void_p(side.cuda_stream)), "gru_backward_overlapped")
         else:
-            _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
-                                             _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
-                                             _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
-                                             _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0),
-                                             _p(dU_r), H, _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work),
-                                             work.numel() * 4, 0 if use_side else 1, _stream()), "gru_backward")
+            with _gate_dtype(ctx.gate_dtype):
+                _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
+                                                 _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
+                                                 _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                                 _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0),
+                                                 _p(dU_r), H, _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work),
+                                                 work.numel() * 4, 0 if use_side else 1, _stream()), "gru_backward")
         ctx.stash = None
         ldx = _ld(x)
         dx = None
@@ -815,9 +818,10 @@ class _GruLevel(torch.autograd.Function):
 
         def weight_grads():
             if use_side and not overlapped:
-                _lib.check(lib.ggpm_gru_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(Gs), _p(work), work.numel() * 4,
-                                                     _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),
-                                                     dW_h.stride(0), _stream()), "gru_weight_grads")
+                with _gate_dtype(ctx.gate_dtype):
+                    _lib.check(lib.ggpm_gru_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(Gs), _p(work), work.numel() * 4,
+                                                         _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),
+                                                         dW_h.stride(0), _stream()), "gru_weight_grads")
             # x-halves of the gate weights and the gate biases
             gemm(1, 0, H, I, E1, dX[0], Hp, x, ldx, dWz_x, dW_z.stride(0), I, splitk=True)
             gemm(1, 0, H, I, E1, dX[1], Hp, x, ldx, dW_r, dW_r.stride(0), I, splitk=True)
@@ -837,13 +841,33 @@ class _GruLevel(torch.autograd.Function):
                                (Pb_h, db_h)):
                     _accumulate_grad(prm, g, main)
             _join_later(main, side)
-            return dx, None, None, None, None, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None, None, None, None
         db_z, db_h = weight_grads()
-        return dx, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None, None
+        return dx, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None, None, None
 
 
-def gru_level(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred: CSR, depth: int, I: int, H: int) -> torch.Tensor:
-    return _GruLevel.apply(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H)
+GATE_DTYPES = {"f32": 0, "fp32": 0, "bf16": 1, None: 0, 0: 0, 1: 1}
+
+
+class _gate_dtype:
+    """``with _gate_dtype(1):`` -- the level calls issued inside run their hidden x hidden products on bf16 operands
+    (ggpm_level_gate_dtype is per thread, so this holds for exactly the calls made here, on whichever thread autograd
+    runs the function)."""
+
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        self.prev = _lib.load().ggpm_level_gate_dtype(self.dt) if self.dt else 0
+
+    def __exit__(self, *exc):
+        if self.dt:
+            _lib.load().ggpm_level_gate_dtype(self.prev)
+        return False
+
+
+def gru_level(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred: CSR, depth: int, I: int, H: int, gate_dtype=None) -> torch.Tensor:
+    return _GruLevel.apply(x, W_z, b_z, W_r, U_r, b_u, W_h, b_h, pred, depth, I, H, GATE_DTYPES[gate_dtype])
 
 
 def _as_padded_state(h: torch.Tensor, H: int, Hp: int) -> torch.Tensor:
@@ -1079,9 +1103,10 @@ class _LstmLevel(torch.autograd.Function):
     """LSTM.forward (ggpm/rnn.py:96-108) for one level; returns (h_D, c_D) as [E1, Hp] tensors."""
 
     @staticmethod
-    def forward(ctx, x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H):
+    def forward(ctx, x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H, gate_dtype=0):
         _need_gpu(x, W_i, W_o, W_u, W_f)
         lib = _lib.load()
+        ctx.gate_dtype = gate_dtype
         E1, Hp = x.shape[0], padded_hidden(H)
         f32 = dict(dtype=torch.float32, device=x.device)
         save = any(ctx.needs_input_grad)
@@ -1103,10 +1128,11 @@ class _LstmLevel(torch.autograd.Function):
             Qs = torch.empty(2, E1, Hp, **f32)
             Ss = Is = Os = Us = Fs = None
         Wh = [w[:, I:] for w in Ws]
-        _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(X[3]), _p(Wh[0]), W_i.stride(0),
-                                         _p(Wh[1]), W_o.stride(0), _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0),
-                                         _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os),
-                                         _p(Us), _p(Fs), _p(wpack), int(save), _stream()), "lstm_forward")
+        with _gate_dtype(gate_dtype):
+            _lib.check(lib.ggpm_lstm_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(X[3]), _p(Wh[0]), W_i.stride(0),
+                                             _p(Wh[1]), W_o.stride(0), _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0),
+                                             _p(pred.rowptr), _p(pred.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss), _p(Is), _p(Os),
+                                             _p(Us), _p(Fs), _p(wpack), int(save), _stream()), "lstm_forward")
         k = depth if save else depth & 1
         if save:
             ctx.save_for_backward(x, W_i, W_o, W_u, W_f)
@@ -1135,13 +1161,14 @@ class _LstmLevel(torch.autograd.Function):
         wb = int(lib.ggpm_lstm_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         use_side = side_stream_enabled() and can_publish(*ctx.params)
-        _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0),
-                                          _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr),
-                                          _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
-                                          _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]),
-                                          _p(dX[3]), _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
-                                          _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0), _p(work),
-                                          work.numel() * 4, 0 if use_side else 1, _stream()), "lstm_backward")
+        with _gate_dtype(ctx.gate_dtype):
+            _lib.check(lib.ggpm_lstm_backward(E1, H, depth, _p(Xf), _p(Wh[0]), W_i.stride(0), _p(Wh[1]), W_o.stride(0),
+                                              _p(Wh[2]), W_u.stride(0), _p(Wh[3]), W_f.stride(0), _p(pred.rowptr),
+                                              _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Cs), _p(Qs), _p(Ss),
+                                              _p(Is), _p(Os), _p(Us), _p(Fs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]),
+                                              _p(dX[3]), _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
+                                              _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0), _p(work),
+                                              work.numel() * 4, 0 if use_side else 1, _stream()), "lstm_backward")
         ctx.stash = None
         ldx = _ld(x)
         dx = None
@@ -1153,10 +1180,11 @@ class _LstmLevel(torch.autograd.Function):
 
         def weight_grads():
             if use_side:
-                _lib.check(lib.ggpm_lstm_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(work), work.numel() * 4,
-                                                      _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
-                                                      _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0),
-                                                      _stream()), "lstm_weight_grads")
+                with _gate_dtype(ctx.gate_dtype):
+                    _lib.check(lib.ggpm_lstm_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(work), work.numel() * 4,
+                                                          _p(dWh[0]), dWs[0].stride(0), _p(dWh[1]), dWs[1].stride(0),
+                                                          _p(dWh[2]), dWs[2].stride(0), _p(dWh[3]), dWs[3].stride(0),
+                                                          _stream()), "lstm_weight_grads")
             out = []
             for k in range(4):
                 gemm(1, 0, H, I, E1, dX[k], Hp, x, ldx, dWs[k][:, :I], dWs[k].stride(0), I, splitk=True)
@@ -1175,10 +1203,10 @@ class _LstmLevel(torch.autograd.Function):
                     _accumulate_grad(ctx.params[2 * k], dWs[k], main)
                     _accumulate_grad(ctx.params[2 * k + 1], dbs[k], main)
             _join_later(main, side)
-            return (dx,) + (None,) * 12
+            return (dx,) + (None,) * 13
         dbs = weight_grads()
-        return (dx, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3], None, None, None, None)
+        return (dx, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dWs[3], dbs[3], None, None, None, None, None)
 
 
-def lstm_level(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred: CSR, depth: int, I: int, H: int):
-    return _LstmLevel.apply(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H)
+def lstm_level(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred: CSR, depth: int, I: int, H: int, gate_dtype=None):
+    return _LstmLevel.apply(x, W_i, b_i, W_o, b_o, W_u, b_u, W_f, b_f, pred, depth, I, H, GATE_DTYPES[gate_dtype])

@@ -4,6 +4,8 @@
 (row stride may be padded) and ``bgraph`` either the reference's zero-padded int64 predecessor table or an
 already converted :class:`ggpm_amd.functional.CSR`.  The depth loop runs in the fused HIP kernels
 (csrc/mpn_gru.hip, csrc/mpn_lstm.hip); the x-halves of the gate weights are hoisted into one GEMM each.
+``module.gate_dtype = "bf16"`` (attribute, default fp32) runs the hidden x hidden products of ``forward`` on bf16
+operands with fp32 accumulate (BASELINE configs[4]; not the 1e-4 parity mode).
 """
 from __future__ import annotations
 
@@ -44,7 +46,8 @@ class GRU(nn.Module):
         I, H = self.input_size, self.hidden_size
         pred = _as_csr(bgraph, fmess.shape[0])
         return F_.gru_level(fmess, self.W_z.weight, self.W_z.bias, self.W_r.weight, self.U_r.weight,
-                            self.U_r.bias, self.W_h.weight, self.W_h.bias, pred, self.depth, I, H)
+                            self.U_r.bias, self.W_h.weight, self.W_h.bias, pred, self.depth, I, H,
+                            gate_dtype=getattr(self, "gate_dtype", None))
 
     def forward(self, fmess, bgraph):
         return self.forward_padded(fmess, bgraph)[:, :self.hidden_size]
@@ -86,7 +89,7 @@ class LSTM(nn.Module):
         pred = _as_csr(bgraph, fmess.shape[0])
         i, o, u, f = self.W_i[0], self.W_o[0], self.W[0], self.W_f[0]
         return F_.lstm_level(fmess, i.weight, i.bias, o.weight, o.bias, u.weight, u.bias, f.weight, f.bias,
-                             pred, self.depth, I, H)
+                             pred, self.depth, I, H, gate_dtype=getattr(self, "gate_dtype", None))
 
     def forward(self, fmess, bgraph):
         h, c = self.forward_padded(fmess, bgraph)

@@ -103,6 +103,16 @@ int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, 
 int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda,
                         const float* const* B, const int* ldb, const int* K, float* C, int ldc, int n_pad,
                         const float* bias, int accumulate, int act, int zero_row0, ggpm_stream_t stream);
+/* C[M x N] = rne_bf16(A)^T rne_bf16(B), fp32 accumulate (v_mfma_f32_16x16x32_bf16), A [K x lda] and B [K x ldb] row-major
+ * fp32: the tall weight-gradient contraction dW = dY^T X over K = depth*E stash rows -- autograd's mm backward of the
+ * hidden x hidden gate products of GRU.GRU / LSTM.LSTM (ggpm/rnn.py:27-36, 88-91) -- with bf16 operands, as the level
+ * calls use it under gate_dtype = bf16 (BASELINE configs[4]).  `ws`: ggpm_gemm_workspace_bytes(M, N, K) bytes (split-K
+ * slabs, summed in fixed order).  Shapes the tall kernel does not take (K < 6144, a 160 x 160 tiling that would be
+ * mostly padding, operands not 16-byte aligned) are computed on fp32 operands by ggpm_gemm instead. */
+int ggpm_gemm_tn_bf16(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* ws,
+                      size_t ws_bytes, ggpm_stream_t stream);
+/* 1 when a contraction of this shape runs on bf16 operands (host-only query; 16-byte aligned operands assumed). */
+int ggpm_gemm_tn_bf16_applies(int M, int N, int K);
 /* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 256*N floats. */
 int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream);
 /* dpre = dy * act'(y) given the activation OUTPUT y; optional row-0 zeroing. In-place allowed. */
@@ -148,6 +158,12 @@ int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1,
                      int bond_types, int max_pos, float* hnode, int ld_n, float* hmess, int ld_m,
                      ggpm_stream_t stream);
 
+/* Gate-product dtype of the level calls (ggpm_gru_/ggpm_lstm_ forward, backward, weight_grads) issued by the CALLING
+ * THREAD from now on: 0 = fp32 operands (default, the 1e-4 parity mode), 1 = bf16 operands with fp32 accumulate for
+ * the hidden x hidden products of the depth loops and the tall weight-gradient contractions (BASELINE configs[4]; the
+ * reference's cells are ggpm/rnn.py:27-36, 88-91).  Returns the previous value; any other argument only queries.  The
+ * whole-encoder drivers set it from ggpm_enc_dims.gate_dtype for the duration of their call. */
+int ggpm_level_gate_dtype(int dtype);
 /* ------------------------------------------------------------------ GRU message function
  * GRU.forward (ggpm/rnn.py:41-50) with GRU.GRU (ggpm/rnn.py:25-39) restated over CSR predecessors with
  * the depth-invariant input halves hoisted:  Xz = x W_z[:, :I]^T + b_z, Xr = x W_r^T, Xh = x W_h[:, :I]^T + b_h

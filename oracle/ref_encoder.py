@@ -298,17 +298,21 @@ def hier_encoder_forward(p: Params, rnn_type: str, depthT: int, depthG: int, tre
     host ``scope`` list last.  Returns (hroot, hnode, hinter, hatom).  ``masks``: training-mode dropout with injected
     masks (scaled keep masks) for the seven Dropout modules, keyed "E_i", "E_c", "W_i", "W_c" and
     "<level>_encoder.W_o"; None = dropout inactive.  ``gate_dtype``: "f32", or "bf16" / "bf16w" for the bf16 gate
-    products of BASELINE configs[4] (see ``bf16_product``).
+    products of BASELINE configs[4] (see ``bf16_product``); a dict keyed "graph_encoder." / "inter_encoder." /
+    "tree_encoder." gives one per level.
     """
     dtype = p["W_root.0.weight"].dtype
     tr = (lambda k: None) if trace is None else (lambda k: trace.setdefault(k, []))
+    gd = (lambda pre: gate_dtype) if isinstance(gate_dtype, str) else (lambda pre: gate_dtype[pre])    # (one per level)
     t = embed_graph(p, graph_tensors, atom_size, dtype)
-    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"), masks=masks, gate_dtype=gate_dtype)
+    hatom, _ = mpn_forward(p, "graph_encoder.", rnn_type, depthG, *t, trace=tr("atom"), masks=masks,
+                           gate_dtype=gd("graph_encoder."))
     t = embed_inter(p, tree_tensors, hatom, masks)
-    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"), masks=masks, gate_dtype=gate_dtype)
+    hinter, _ = mpn_forward(p, "inter_encoder.", rnn_type, depthT, *t, trace=tr("inter"), masks=masks,
+                            gate_dtype=gd("inter_encoder."))
     t = embed_tree(p, tree_tensors, hinter, masks)
     hnode, hmess = mpn_forward(p, "tree_encoder.", rnn_type, depthT, *t, trace=tr("tree"), masks=masks,
-                               gate_dtype=gate_dtype)
+                               gate_dtype=gd("tree_encoder."))
     hroot = embed_root(p, hmess, t, [st for st, _ in tree_tensors[-1]])
     return hroot, hnode, hinter, hatom
 

@@ -93,15 +93,25 @@ def full_vae_section(rank, world):
         loss, _ = ref(*synth.train_batch(cat), beta=0.1, perturb_z=False)
         loss.backward()
         torch.cuda.synchronize()
-        worst = 0.0
+        # (the reference pads every attachment prediction to the BATCH's max_cls_size candidates and the padded rows take
+        # part in the softmax, ggpm/decoder.py:199,252-254: the comparison needs batches that agree on it)
+        from ggpm_amd.decoder import DecodeSchedule
+        sizes = {DecodeSchedule.from_specs(b, synth.tensorize(b)).max_cls_size for b in [cat] + [specs_of(r, 0) for r in range(world)]}
+        assert len(sizes) == 1, sizes
+        gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+        worst, worst_k = 0.0, ""
         for k, p in ref.named_parameters():
             want, got = p.grad, reduced[k]
-            scale = float(want.abs().max())
-            if scale < 1e-12:
-                assert float(got.abs().max()) < 1e-9, k
+            # norm-wise per tensor; a gradient that is analytically zero (W_assm.bias: the candidates of a prediction share
+            # one context vector and a softmax row's gradients sum to 0) holds rounding noise on both sides
+            if k.endswith("W_assm.bias"):
+                assert float(want.abs().max()) < 1e-4 * gmax and float(got.abs().max()) < 1e-4 * gmax, k
                 continue
-            worst = max(worst, float((want - got).abs().max()) / scale)
-        assert worst <= 1e-5, worst
+            scale = max(float(want.abs().max()), 1e-5 * gmax)
+            err = float((want - got).abs().max()) / scale
+            if err > worst:
+                worst, worst_k = err, k
+        assert worst <= 1e-5, (worst, worst_k)
         print("VAE %s 2-rank all-reduced gradient vs 1-rank gradient of the concatenated batch: worst norm-wise diff %.3e"
               % (rnn, worst), flush=True)
 
