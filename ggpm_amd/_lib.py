@@ -91,6 +91,14 @@ SIGNATURES = {
     "ggpm_persistent_timeout": (I, [P, P]),
     "ggpm_timing_enable": (I, [I]),
     "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+    # host-only decode schedule (csrc/schedule.hip): in: ggpm_sched_in*
+    "ggpm_schedule_build": (P, [P]),
+    "ggpm_schedule_get": (I, [P, c_char_p, POINTER(c_void_p), POINTER(ctypes.c_int64), POINTER(c_int), POINTER(c_int),
+                              POINTER(ctypes.c_int64)]),
+    "ggpm_schedule_pack": (I, [P, I, POINTER(c_void_p), POINTER(ctypes.c_int64)]),
+    "ggpm_schedule_names": (I, [P, c_char_p, ctypes.c_int64]),
+    "ggpm_schedule_directory": (I, [P, P, ctypes.c_int64]),
+    "ggpm_schedule_free": (None, [P]),
 }
 
 

@@ -55,6 +55,7 @@ class AtomPlan:
         """``full``: also build the level-wide per-step tables of the full-level form (``_AtomDecode``; default: only when
         GGPM_ATOM_COMPACT=0 -- the compact form does not read them and they are the larger half of the build and upload)."""
         P, steps = schedule.plan, schedule.steps
+        self._native, self._schedule, self._raw_cache = None, None, None
         self.T, self.N1, self.E1 = len(steps), n_gnodes, n_gmess
         self.full = (not compact_enabled()) if full is None else bool(full)
         full = self.full
@@ -179,7 +180,81 @@ class AtomPlan:
         st = dict(self.__dict__)
         st["_dev"] = {}
         st["_ct"] = {k: dict(v, dev={}) for k, v in self._ct.items()}
+        if self._native is not None:
+            from .decoder import _FrozenTables
+            st["_native"] = self._native if isinstance(self._native, _FrozenTables) else _FrozenTables(self._native)
+            st["ints"], st["frozen_loc"] = np.array(self.ints), np.array(self.frozen_loc)
+            st["cand_meta"] = {k: {n: np.array(v) for n, v in m.items()} for k, m in self.cand_meta.items()}
+            st["_raw_cache"] = None
         return st
+
+    # ------------------------------------------------------------------ tables built by csrc/schedule.hip
+    @classmethod
+    def from_native(cls, schedule, nt, n_gnodes: int, n_gmess: int) -> "AtomPlan":
+        """The same object over the tables of ``ggpm_schedule_build``: ``ints`` IS the int32 device pack (so the
+        addresses handed to the C drivers are offsets into one upload shared with the schedule), the compact tables for the
+        (depth, gates) the build was given are already there."""
+        self = cls.__new__(cls)
+        sc, g = nt.scalars(), nt.get
+        self._native, self._schedule = nt, schedule
+        self.T, self.N1, self.E1, self.full, self.ok = sc["T"], n_gnodes, n_gmess, False, bool(sc["ok"])
+        self.nloc, self.floc_off = g("nloc").tolist(), g("floc_off").tolist()
+        self.aoff, self.ioff = schedule.plan["atom_off"], schedule.plan["inst_off"]
+        self.ints, self.frozen_loc = nt.packs[2], g("frozen_loc")
+        self.frozen = np.ones((0, n_gmess), dtype=np.uint8)
+        d = nt.dir
+        e32 = lambda name: d[name][1] // 4                      # element offset inside the int32 pack
+        rp_off, col_off, rows_off = g("lpred_rp_off").tolist(), g("lpred_col_off").tolist(), g("rows_off").tolist()
+        self.where = {}
+        for t in range(self.T):
+            for name, off in (("lpred_rp", rp_off), ("lsucc_rp", rp_off), ("lpred_col", col_off), ("lsucc_col", col_off),
+                              ("rows", rows_off)):
+                self.where[(name, t)] = (e32(name) + off[t], off[t + 1] - off[t])
+        cb = g("cand_blocks").reshape(-1, 3).tolist()
+        self.cand_blocks = [tuple(x) for x in cb]
+        self.n_cand = sc["n_cand"]
+        self.cand_meta = {k: dict(icls=g("meta_icls/%d" % k), nth=g("meta_nth/%d" % k), dest=g("meta_dest/%d" % k))
+                          for k, _, _ in self.cand_blocks}
+        self._kbase = {k: b for k, b, _ in self.cand_blocks}
+        self._cand_pos = {k: g("cand_pos/%d" % k) for k, _, _ in self.cand_blocks}
+        psc = g("step_cands").reshape(-1, 4).tolist()
+        self._per_step_cands = [[] for _ in range(self.T)]
+        for t, k, start, n in psc:
+            self._per_step_cands[t].append((k, start, n))
+        self.step_cands = [[(self._kbase[k] + start, n) for (k, start, n) in here] for here in self._per_step_cands]
+        self._raw_cache, self._ct, self._dev = None, {}, {}
+        if sc["depth"] > 0 and sc["gates"] > 0:
+            names = ["srcF", "srcH", "agr_rp", "agr_col", "agrT_rp", "agrT_col", "pool_rp", "pool_col", "poolT_rp", "poolT_col",
+                     "cand_idx", "candT_rp", "candT_col", "xrows", "xT_rp", "xT_col"]
+            foff = g("foff").tolist()
+            where = {}
+            for name in names:
+                if name in ("srcF", "srcH"):
+                    for t in range(self.T):
+                        where[(name, t)] = (e32(name) + foff[t], foff[t + 1] - foff[t])
+                else:
+                    where[name] = (e32(name), d[name][2])
+            self._ct[(sc["depth"], sc["gates"])] = dict(ints=nt.packs[2], where=where, foff=foff, Ftot=sc["Ftot"], dev={},
+                                                        native=True)
+        return self
+
+    @property
+    def _raw(self):
+        """per step (rows, local frozen mask, incoming-message table, pool table) -- what compact_tables reads"""
+        if self._raw_cache is None:
+            nt, P = self._native, self._schedule.plan
+            rows_all, rows_off = nt.get("rows").astype(np.int64), nt.get("rows_off").tolist()
+            loc = nt.get("loc").reshape(-1, P["pool"].shape[1])
+            self._raw_cache = []
+            for t in range(self.T):
+                rows = rows_all[rows_off[t]:rows_off[t + 1]]
+                fl = np.array(self.frozen_loc[self.floc_off[t]:self.floc_off[t] + len(rows)])
+                self._raw_cache.append((rows, fl, P["g_agraph"][self.aoff[t]:self.aoff[t + 1]], loc[self.ioff[t]:self.ioff[t + 1]]))
+        return self._raw_cache
+
+    @_raw.setter
+    def _raw(self, value):
+        self._raw_cache = value
 
     def row_offsets(self, depth: int):
         """-> (offsets of the steps' [depth, n] blocks, offsets of their [depth + 1, n] blocks), each of length T + 1."""
@@ -253,8 +328,10 @@ class AtomPlan:
     def compact_device(self, depth: int, gates: int, device):
         """-> (tables dict, {key: device address}) of compact_tables on ``device`` (uploaded once)."""
         ct = self.compact_tables(depth, gates)
+        device = torch.device(device)
         if device not in ct["dev"]:
-            d = F_.upload(ct["ints"], device)
+            # (natively built tables live in the int32 pack the plan's own tables are views of: no second upload)
+            d = self.to_device(device)["ints"] if ct.get("native") else F_.upload(ct["ints"], device)
             ct["dev"][device] = (d, None, {k: d.data_ptr() + 4 * off for k, (off, _) in ct["where"].items()})
         return ct, ct["dev"][device][2]
 
@@ -270,6 +347,22 @@ class AtomPlan:
         tensors and live in the same dict, so they can never outlast them)."""
         device = torch.device(device)
         D = self._dev.get(device)
+        if D is None and self._native is not None:
+            sd = self._schedule.to_device(device)._dev
+            d64, d32 = sd["native"]
+            nd = self._native.dir
+
+            def view(name):
+                pack, off, cnt, el = nd[name]
+                return (d64 if pack == 1 else d32)[off // el:off // el + cnt]
+            floff = nd["frozen_loc"][1]
+            dl = d32.view(torch.uint8)[floff:floff + nd["frozen_loc"][2]]
+            base = d32.data_ptr()
+            ptr = {k: base + 4 * off for k, (off, n) in self.where.items()}
+            meta = {k: dict(icls=view("meta_icls/%d" % k), nth=view("meta_nth/%d" % k), dest=view("meta_dest/%d" % k))
+                    for k, _, _ in self.cand_blocks}
+            D = self._dev[device] = dict(device=device, ints=d32, frozen=None, frozen_loc=dl, ptr=ptr, meta=meta, desc={},
+                                         seen=set(), pack64=d64)
         if D is None:
             di, dl = F_.upload(self.ints, device), F_.upload(self.frozen_loc, device)
             df = F_.upload(self.frozen, device) if self.full else None
@@ -287,7 +380,7 @@ class AtomPlan:
             if cur.cuda_stream not in D["seen"]:
                 D["seen"].add(cur.cuda_stream)
                 ts = [D["ints"], D["frozen_loc"]] + ([D["frozen"]] if D["frozen"] is not None else [])
-                ts += [v for m in D["meta"].values() for v in m.values()]
+                ts += [v for m in D["meta"].values() for v in m.values()] + ([D["pack64"]] if "pack64" in D else [])
                 for t in ts:
                     t.record_stream(cur)
         return D

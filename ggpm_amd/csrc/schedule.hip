@@ -20,6 +20,9 @@
 #include <unordered_map>
 #include <utility>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "../../include/ggpm_hip.h"
 
 namespace {
@@ -40,24 +43,33 @@ struct Sched {
         return a[name];
     }
     void finalize() {
+        size_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        for (const std::string& n : order) {
+            const size_t sz = a[n].size();
+            const int k = kind[n];
+            if (k == 0) n0 += sz; else if (k == 1) n1 += sz; else if (k == 2) n2 += sz; else n3 += (sz + 3) / 4;
+        }
+        host.resize(n0); dev64.resize(n1); dev32.assign(n2 + n3, 0);
+        size_t o0 = 0, o1 = 0, o2 = 0;
         for (const std::string& n : order) {
             const V& v = a[n];
             const int k = kind[n];
-            if (k == 0) { dir[n] = {0, (int64_t)host.size(), (int64_t)v.size(), 8}; host.insert(host.end(), v.begin(), v.end()); }
-            else if (k == 1) { dir[n] = {1, (int64_t)dev64.size(), (int64_t)v.size(), 8}; dev64.insert(dev64.end(), v.begin(), v.end()); }
+            if (k == 0) { dir[n] = {0, (int64_t)o0, (int64_t)v.size(), 8}; if (!v.empty()) std::memcpy(&host[o0], v.data(), v.size() * 8); o0 += v.size(); }
+            else if (k == 1) { dir[n] = {1, (int64_t)o1, (int64_t)v.size(), 8}; if (!v.empty()) std::memcpy(&dev64[o1], v.data(), v.size() * 8); o1 += v.size(); }
             else if (k == 2) {
-                dir[n] = {2, (int64_t)dev32.size(), (int64_t)v.size(), 4};
-                for (int64_t x : v) dev32.push_back((int32_t)x);
+                dir[n] = {2, (int64_t)o2, (int64_t)v.size(), 4};
+                int32_t* d = dev32.data() + o2;
+                for (size_t i = 0; i < v.size(); ++i) d[i] = (int32_t)v[i];
+                o2 += v.size();
             }
         }
         for (const std::string& n : order) {      // byte tables behind all int32 ones (4-byte aligned starts)
             if (kind[n] != 3) continue;
             const V& v = a[n];
-            const int64_t off = (int64_t)dev32.size() * 4;
-            dev32.resize(dev32.size() + (v.size() + 3) / 4, 0);
-            uint8_t* p = reinterpret_cast<uint8_t*>(dev32.data()) + off;
+            uint8_t* p = reinterpret_cast<uint8_t*>(dev32.data() + o2);
             for (size_t i = 0; i < v.size(); ++i) p[i] = (uint8_t)v[i];
-            dir[n] = {2, off, (int64_t)v.size(), 1};
+            dir[n] = {2, (int64_t)o2 * 4, (int64_t)v.size(), 1};
+            o2 += (v.size() + 3) / 4;
         }
         a.clear();
     }
@@ -69,13 +81,13 @@ void transpose(const V& rows, const V& cols, int64_t ncols, V& rp, V& col) {
     rp.assign(ncols + 1, 0);
     for (int64_t c : cols) rp[c + 1]++;
     for (int64_t i = 0; i < ncols; ++i) rp[i + 1] += rp[i];
-    std::vector<int64_t> idx(rows.size());
-    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int64_t)i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) {
-        return cols[x] != cols[y] ? cols[x] < cols[y] : rows[x] < rows[y];
-    });
+    // counting sort by column (stable), then each column's few rows ascending
+    V cursor(rp.begin(), rp.end() - 1);
     col.resize(rows.size());
-    for (size_t i = 0; i < idx.size(); ++i) col[i] = rows[idx[i]];
+    for (size_t i = 0; i < rows.size(); ++i) col[(size_t)cursor[(size_t)cols[i]]++] = rows[i];
+    for (int64_t c = 0; c < ncols; ++c)
+        if (rp[c + 1] - rp[c] > 1 && !std::is_sorted(col.begin() + rp[c], col.begin() + rp[c + 1]))
+            std::sort(col.begin() + rp[c], col.begin() + rp[c + 1]);
 }
 
 inline void append(V& dst, const V& src) { dst.insert(dst.end(), src.begin(), src.end()); }
@@ -90,7 +102,37 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
     const int64_t Ng1 = in->Ng1, Eg1 = in->Eg1, Ag = in->Ag, Kg = in->Kg;
     const int64_t *tfnode = in->tfnode, *tfmess = in->tfmess, *tagraph = in->tagraph, *tbgraph = in->tbgraph;
     const int64_t *cgraph = in->cgraph, *gfmess = in->gfmess, *gagraph = in->gagraph, *gbgraph = in->gbgraph;
+    {       // the tables index each other: refuse anything that would read outside them
+        auto in_range = [](const int64_t* a, int64_t n, int64_t lo, int64_t hi) {
+            for (int64_t i = 0; i < n; ++i) if (a[i] < lo || a[i] >= hi) return false;
+            return true;
+        };
+        if (Nt1 < 1 || E1 < 1 || Ng1 < 1 || Eg1 < 1 || At < 1 || Kt < 1 || C < 1 || Ag < 1 || Kg < 1) return nullptr;
+        bool ok = in_range(cgraph, Nt1 * C, 0, Ng1) && in_range(gagraph, Ng1 * Ag, 0, Eg1) && in_range(gbgraph, Eg1 * Kg, 0, Eg1) &&
+                  in_range(tagraph, Nt1 * At, 0, E1) && in_range(tbgraph, E1 * Kt, 0, E1);
+        for (int64_t e = 1; e < E1 && ok; ++e) ok = tfmess[e * 4] >= 0 && tfmess[e * 4] < Nt1 && tfmess[e * 4 + 1] >= 0 && tfmess[e * 4 + 1] < Nt1;
+        for (int64_t e = 1; e < Eg1 && ok; ++e) ok = gfmess[e * 4] >= 0 && gfmess[e * 4] < Ng1 && gfmess[e * 4 + 1] >= 0 && gfmess[e * 4 + 1] < Ng1;
+        for (int64_t i = 0; i < B && ok; ++i) ok = in->tree_scope[2 * i] >= 0 && in->tree_scope[2 * i] < Nt1 && in->order_off[i + 1] >= in->order_off[i];
+        ok = ok && in->order_off[0] == 0;
+        for (int64_t q = 0; ok && q < in->order_off[B]; ++q)
+            ok = in->orders[3 * q] >= 0 && in->orders[3 * q] < Nt1 && in->orders[3 * q + 1] >= -1 && in->orders[3 * q + 1] < Nt1;
+        for (int64_t v = 0; ok && v < Nt1; ++v)
+            ok = in->icls_off[v + 1] >= in->icls_off[v] && in->cand_off[v + 1] >= in->cand_off[v] && in->cand_atom_off &&
+                 in->cand_atom_off[v + 1] - in->cand_atom_off[v] == (in->cand_off[v + 1] - in->cand_off[v]) * (in->icls_off[v + 1] - in->icls_off[v]);
+        if (ok && in->cand_atom_off[Nt1] > 0) ok = in->cands && in_range(in->cands, in->cand_atom_off[Nt1], 0, Ng1);
+        if (ok && in->icls_off[Nt1] > 0) ok = in->icls != nullptr;
+        if (!ok) return nullptr;
+    }
     Sched* S = new Sched();
+    static const bool dbg = getenv("GGPM_SCHED_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin = now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = now();
+        fprintf(stderr, "[sched] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count());
+        t_begin = t;
+    };
 
     // ---------------------------------------------------------------- DecodeSchedule.from_tensors
     std::unordered_map<int64_t, int64_t> tmess;          // (u, v) -> tree message id
@@ -100,10 +142,16 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         auto it = tmess.find(u * Nt1 + v);
         return it == tmess.end() ? -1 : it->second;
     };
-    std::vector<std::vector<std::pair<int64_t, int64_t>>> gadj((size_t)Ng1);     // src atom -> (dst atom, bond), bonds ascending
-    for (int64_t e = 1; e < Eg1; ++e) {
-        const int64_t u = gfmess[e * 4];
-        if (u >= 0 && u < Ng1) gadj[(size_t)u].push_back({gfmess[e * 4 + 1], e});
+    // src atom -> (dst atom, bond) lists, bonds ascending, as one CSR
+    V gadj_rp((size_t)Ng1 + 1, 0), gadj_dst((size_t)Eg1), gadj_e((size_t)Eg1);
+    for (int64_t e = 1; e < Eg1; ++e) { const int64_t u = gfmess[e * 4]; if (u >= 0 && u < Ng1) gadj_rp[(size_t)u + 1]++; }
+    for (int64_t i = 0; i < Ng1; ++i) gadj_rp[(size_t)i + 1] += gadj_rp[(size_t)i];
+    {
+        V cur(gadj_rp.begin(), gadj_rp.end() - 1);
+        for (int64_t e = 1; e < Eg1; ++e) {
+            const int64_t u = gfmess[e * 4];
+            if (u >= 0 && u < Ng1) { const int64_t q = cur[(size_t)u]++; gadj_dst[(size_t)q] = gfmess[e * 4 + 1]; gadj_e[(size_t)q] = e; }
+        }
     }
     auto cluster_size = [&](int64_t v) { int64_t n = 0; for (int64_t j = 0; j < C; ++j) n += cgraph[v * C + j] > 0; return n; };
     auto add_cluster = [&](int64_t v, V& out) { for (int64_t j = 0; j < C; ++j) if (cgraph[v * C + j] > 0) out.push_back(cgraph[v * C + j]); };
@@ -112,8 +160,8 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         bonds.clear();
         for (int64_t z : atoms) in_new[(size_t)z] = 1;
         for (int64_t z : atoms)
-            for (const auto& ne : gadj[(size_t)z])
-                if (in_new[(size_t)ne.first]) bonds.push_back(ne.second);
+            for (int64_t q = gadj_rp[(size_t)z]; q < gadj_rp[(size_t)z + 1]; ++q)
+                if (in_new[(size_t)gadj_dst[(size_t)q]]) bonds.push_back(gadj_e[(size_t)q]);
         for (int64_t z : atoms) in_new[(size_t)z] = 0;
     };
 
@@ -138,7 +186,7 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
     V &g_agraph = S->put("g_agraph", 0), &g_bgraph = S->put("g_bgraph", 0);
     V &atom_off = S->put("atom_off", 0), &bond_off = S->put("bond_off", 0), &inst_off = S->put("inst_off", 0);
     V &submess_all = S->put("submess_all", 0), &submess_off = S->put("submess_off", 0);
-    V &topo_batch = S->put("topo_batch", 1), &topo_label = S->put("topo_label", 1);
+    V &topo_batch = S->put("topo_batch", 0), &topo_label = S->put("topo_label", 1);
     V &cls_mess = S->put("cls_mess", 1), &cls_off = S->put("cls_off", 0);
     V cls_batch, cls_clab, cls_ilab;          // (the B roots come first in the packed forms)
     V &assm_step = S->put("assm_step", 0), &assm_yid = S->put("assm_yid", 0), &assm_nth = S->put("assm_nth", 0);
@@ -202,16 +250,21 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         cur_atoms = new_atoms;
         reveal(cur_atoms, cur_bonds);
     }
+    lap("steps");
     if (bad) { delete S; return nullptr; }
     const int64_t n_inst = (int64_t)inst_node.size();
     {       // packed prediction lists (DecodeSchedule.cls / assm_batch)
-        V &cb = S->put("cls_batch", 1), &cc = S->put("cls_clab", 1), &ci = S->put("cls_ilab", 1);
+        V &cb = S->put("cls_batch", 0), &cc = S->put("cls_clab", 1), &ci = S->put("cls_ilab", 1);
         for (int64_t i = 0; i < B; ++i) cb.push_back(i);
         append(cb, cls_batch);
         append(cc, root_clab); append(cc, cls_clab);
         append(ci, root_ilab); append(ci, cls_ilab);
-        V& ab = S->put("assm_batch", 1);
+        V& ab = S->put("assm_batch", 0);
         for (int64_t b : assm_bidx) for (int64_t j = 0; j < max_cls; ++j) ab.push_back(b);
+        // the molecule index of every prediction as int32 (row ids of the context gather, ggpm_gather_rows)
+        S->put("topo_batch32", 2) = topo_batch;
+        S->put("cls_batch32", 2) = cb;
+        S->put("assm_batch32", 2) = ab;
     }
 
     // ---------------------------------------------------------------- DecodeSchedule._level_plan
@@ -278,6 +331,7 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         for (int64_t e = 1; e < E1; ++e) { mi.push_back(mess_inst[(size_t)e]); mp.push_back(tfmess[e * 4 + 2]); }
     }
 
+    lap("level plan");
     // ---------------------------------------------------------------- AtomPlan (compact row sets)
     V &nloc = S->put("nloc", 0), &floc_off = S->put("floc_off", 0), &frozen_loc = S->put("frozen_loc", 3);
     V &lpred_rp = S->put("lpred_rp", 2), &lpred_col = S->put("lpred_col", 2), &lsucc_rp = S->put("lsucc_rp", 2);
@@ -378,6 +432,7 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         for (int64_t t = 0; t < T; ++t) for (const Here& h : per_step_cands[(size_t)t]) { psc.push_back(t); psc.push_back(h.k); psc.push_back(h.start); psc.push_back(h.n); }
     }
 
+    lap("atom plan");
     // ---------------------------------------------------------------- AtomPlan.compact_tables(depth, gates)
     int64_t Ftot = 0;
     V& foff = S->put("foff", 0);
@@ -446,10 +501,12 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         transpose(iota, xrows, gates * Eg1, S->put("xT_rp", 2), S->put("xT_col", 2));
     }
 
+    lap("compact tables");
     V& sc = S->put("scalars", 0);
     sc = {T, n_inst, E1, chain_max, all_live ? 1 : 0, max_cls, (int64_t)assm_step.size(), n_cand, Ftot, ok_atoms ? 1 : 0, B,
           (int64_t)in->depth, (int64_t)in->gates, Ng1, Eg1};
     S->finalize();
+    lap("finalize");
     return S;
 }
 
@@ -473,11 +530,25 @@ extern "C" int ggpm_schedule_get(void* h, const char* name, const void** data, i
 }
 
 extern "C" int ggpm_schedule_pack(void* h, int pack, const void** data, int64_t* bytes) {
-    if (!h || pack < 1 || pack > 2 || !data || !bytes) return GGPM_ERR_ARG;
+    if (!h || pack < 0 || pack > 2 || !data || !bytes) return GGPM_ERR_ARG;
     Sched* S = static_cast<Sched*>(h);
-    if (pack == 1) { *data = S->dev64.data(); *bytes = (int64_t)S->dev64.size() * 8; }
+    if (pack == 0) { *data = S->host.data(); *bytes = (int64_t)S->host.size() * 8; }
+    else if (pack == 1) { *data = S->dev64.data(); *bytes = (int64_t)S->dev64.size() * 8; }
     else { *data = S->dev32.data(); *bytes = (int64_t)S->dev32.size() * 4; }
     return GGPM_OK;
+}
+
+// (pack, byte offset, count, element bytes) of every table, in the order of ggpm_schedule_names
+extern "C" int ggpm_schedule_directory(void* h, int64_t* out, int64_t capacity) {
+    if (!h || !out) return -GGPM_ERR_ARG;
+    Sched* S = static_cast<Sched*>(h);
+    if ((int64_t)S->order.size() * 4 > capacity) return -GGPM_ERR_WORKSPACE;
+    int64_t* o = out;
+    for (const std::string& n : S->order) {
+        const Entry& e = S->dir[n];
+        *o++ = e.pack; *o++ = e.elem == 1 ? e.off : e.off * e.elem; *o++ = e.count; *o++ = e.elem;
+    }
+    return (int)S->order.size();
 }
 
 extern "C" int ggpm_schedule_names(void* h, char* out, int64_t cap) {

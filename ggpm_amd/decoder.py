@@ -42,7 +42,9 @@ class DecodeSchedule:
     """
 
     def __init__(self):
-        self.steps: List[dict] = []
+        self._steps: Optional[List[dict]] = []
+        self._native = None                  # schedule_native.NativeTables when the tables were built by csrc/schedule.hip
+        self._labels = None
         self.plan: Optional[dict] = None
         self._atom_plan = None
         self.root_clab: List[int] = []
@@ -52,13 +54,48 @@ class DecodeSchedule:
         self._dev = None
 
     def __getstate__(self):
+        """Host tables only.  A natively built schedule converts itself: its tables become plain numpy copies (they are
+        views into the library's buffers otherwise) and the atom plan keeps what it needs to serve the device path."""
         st = dict(self.__dict__)
         st["_dev"] = None          # (device views: rebuilt by to_device in the receiving process)
+        if self._native is not None:
+            nt = self._native
+            st["_native"] = _FrozenTables(nt)
+            st["plan"] = {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in self.plan.items()}
         return st
+
+    # ``steps``: the per-step lists of the reference's loop.  The numpy builder fills them as it goes; a natively built
+    # schedule reconstructs them on first use (only the step-by-step fallback paths, the oracle and the tests read them).
+    @property
+    def steps(self) -> List[dict]:
+        if self._steps is None:
+            self._steps = self._steps_from_native()
+        return self._steps
+
+    def _steps_from_native(self) -> List[dict]:
+        nt, B = self._native, self.batch_size
+        g = lambda k: nt.get(k)
+        ioff, aoff, boff = self.plan["inst_off"], self.plan["atom_off"], self.plan["bond_off"]
+        soff, coff = g("submess_off").tolist(), g("cls_off").tolist()
+        inter_icls, assm_cands = self._labels
+        a_step, a_yid, a_nth, a_b = (g(k).tolist() for k in ("assm_step", "assm_yid", "assm_nth", "assm_bidx"))
+        by_step: Dict[int, list] = {}
+        for t, y, nth, i in zip(a_step, a_yid, a_nth, a_b):
+            cands = np.asarray(assm_cands[int(y)], dtype=np.int64)
+            by_step.setdefault(t, []).append((cands.reshape(len(cands), -1), tuple(int(a) for a in inter_icls[int(y)]), int(nth), int(i)))
+        out = []
+        for t in range(len(ioff) - 1):
+            sl = lambda k, off: g(k)[off[t]:off[t + 1]].tolist()
+            out.append(dict(subnode=sl("inst_node", ioff), submess=sl("submess_all", soff), atoms=sl("atoms_all", aoff),
+                            bonds=sl("bonds_all", boff), topo_batch=sl("topo_batch", ioff), topo_label=sl("topo_label", ioff),
+                            cls_mess=sl("cls_mess", coff), cls_batch=g("cls_batch")[B + coff[t]:B + coff[t + 1]].tolist(),
+                            cls_clab=g("cls_clab")[B + coff[t]:B + coff[t + 1]].tolist(),
+                            cls_ilab=g("cls_ilab")[B + coff[t]:B + coff[t + 1]].tolist(), assm=by_step.get(t, [])))
+        return out
 
     # ------------------------------------------------------------------ construction (host)
     @staticmethod
-    def from_graphs(graphs, tensors, orders, vocab) -> "DecodeSchedule":
+    def from_graphs(graphs, tensors, orders, vocab, **kw) -> "DecodeSchedule":
         """From the reference's batch tuple: ``graphs = (tree_batchG, graph_batchG)`` (networkx, as produced by
         ``MolGraph.tensorize``).  Only the two labels that are not in the tensors are read from the node attributes."""
         tree_batch = graphs[0]
@@ -67,10 +104,10 @@ class DecodeSchedule:
             cls = attr["smiles"]
             inter_icls[v] = tuple(vocab[(cls, icls)][1] for _, icls in attr["inter_label"])
             assm_cands[v] = list(attr["assm_cands"])
-        return DecodeSchedule.from_tensors(tensors, orders, inter_icls, assm_cands)
+        return DecodeSchedule.from_tensors(tensors, orders, inter_icls, assm_cands, **kw)
 
     @staticmethod
-    def from_specs(specs, tensors, orders=None) -> "DecodeSchedule":
+    def from_specs(specs, tensors, orders=None, **kw) -> "DecodeSchedule":
         """From synthetic molecules (ggpm_amd.synth.MolSpec) and their ``synth.tensorize`` output."""
         tree_scope, graph_scope = tensors[0][-1], tensors[1][-1]
         inter_icls, assm_cands = {}, {}
@@ -81,11 +118,24 @@ class DecodeSchedule:
             for i in range(m.n_motifs):
                 inter_icls[toff + i] = tuple(a for _, a in m.inter_label[i])
                 assm_cands[toff + i] = [x + aoff for x in m.assm_cands[i]]
-        return DecodeSchedule.from_tensors(tensors, orders, inter_icls, assm_cands)
+        return DecodeSchedule.from_tensors(tensors, orders, inter_icls, assm_cands, **kw)
 
     @staticmethod
-    def from_tensors(tensors, orders, inter_icls: Dict[int, Tuple[int, ...]], assm_cands: Dict[int, list]
+    def from_tensors(tensors, orders, inter_icls: Dict[int, Tuple[int, ...]], assm_cands: Dict[int, list],
+                     depth: Optional[int] = None, gates: Optional[int] = None, native: Optional[bool] = None
                      ) -> "DecodeSchedule":
+        """``depth`` / ``gates`` (the decoder's diterG and 3 for GRU / 4 for LSTM), when known, let the native builder
+        prepare the tables that depend on them as well; ``native=False`` forces the numpy builder (the checker)."""
+        from . import schedule_native as SN
+        if native is None:
+            native = SN.enabled() and all(os.environ.get(k, "1") != "0" for k in
+                                          ("GGPM_DECODER_BATCHED", "GGPM_ATOM_DECODE", "GGPM_ATOM_COMPACT"))
+        if native:
+            nt = SN.build_tables(tensors, orders, inter_icls, assm_cands, depth or 0, gates or 0)
+            if nt is not None:
+                sc = nt.scalars()
+                if sc["ok"] and sc["all_live"] and sc["E1"] > 1:      # (anything else takes the step-by-step forms)
+                    return DecodeSchedule._from_native(nt, tensors, inter_icls, assm_cands)
         tree_tensors, graph_tensors = tensors
         host = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
         tfnode, tfmess, cgraph = host(tree_tensors[0]), host(tree_tensors[1]), host(tree_tensors[4])
@@ -173,6 +223,29 @@ class DecodeSchedule:
                       bond_off=np.cumsum([0] + [len(st["bonds"]) for st in S.steps]).tolist())
         return S
 
+    @staticmethod
+    def _from_native(nt, tensors, inter_icls, assm_cands) -> "DecodeSchedule":
+        """The schedule object over tables built by csrc/schedule.hip (numpy views into the library's buffers)."""
+        from .atom_decode import AtomPlan
+        tree_tensors, graph_tensors = tensors
+        sc, g = nt.scalars(), nt.get
+        S = DecodeSchedule()
+        S._native, S._steps, S._labels = nt, None, (inter_icls, assm_cands)
+        S.batch_size, S.max_cls_size = sc["B"], sc["max_cls_size"]
+        S.root_clab, S.root_ilab = g("root_clab").tolist(), g("root_ilab").tolist()
+        Kt, At, C = tree_tensors[3].shape[1], tree_tensors[2].shape[1], tree_tensors[4].shape[1]
+        Ag, Kg = graph_tensors[2].shape[1], graph_tensors[3].shape[1]
+        S.plan = dict(chain=sc["chain"], n_inst=sc["n_inst"], E1=sc["E1"], all_live=bool(sc["all_live"]),
+                      inst_motif=g("inst_motif"), inst_attach=g("inst_attach"), mess_inst=g("mess_inst"), mess_pos=g("mess_pos"),
+                      dag_tree=g("dag_tree").reshape(-1, Kt), dag_inter=g("dag_inter").reshape(-1, Kt),
+                      in_tree=g("in_tree").reshape(-1, At), in_inter=g("in_inter").reshape(-1, At),
+                      pool=g("pool").reshape(-1, C), cls_mess=g("cls_mess"), inst_off=g("inst_off").tolist(),
+                      g_agraph=g("g_agraph").reshape(-1, Ag), g_bgraph=g("g_bgraph").reshape(-1, Kg),
+                      atoms_all=g("atoms_all"), bonds_all=g("bonds_all"), atom_off=g("atom_off").tolist(),
+                      bond_off=g("bond_off").tolist())
+        S._atom_plan = AtomPlan.from_native(S, nt, sc["Ng1"], sc["Eg1"])
+        return S
+
     def _level_plan(self, tfnode, tfmess, tagraph, tbgraph, tree_scope, mess_time, mess_inst, inst_node, inst_step,
                     pool_rows) -> None:
         """Index tables of the BATCHED form of the two tree-side levels (HierMPNDecoder.forward_batched).
@@ -246,11 +319,31 @@ class DecodeSchedule:
     def assm_batch(self):
         return [i for st in self.steps for (_, _, _, i) in st["assm"]]
 
+    def _native_to_device(self, device) -> "DecodeSchedule":
+        """Two uploads (the int64 and the int32 pack of csrc/schedule.hip); every device table is a view into them."""
+        nt = self._native
+        d64, d32 = F_.upload(nt.packs[1], device), F_.upload(nt.packs[2], device)
+
+        def view(name, shape=None):
+            pack, off, cnt, el = nt.dir[name]
+            v = (d64 if pack == 1 else d32)[off // el:off // el + cnt]
+            return v.view(shape) if shape is not None else v
+
+        P = self.plan
+        plan = {k: view(k, P[k].shape) for k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos", "dag_tree",
+                                                  "dag_inter", "in_tree", "in_inter", "cls_mess", "atoms_all")}
+        self._dev = dict(device=device, steps=None, n_assm=nt.scalars()["n_assm"], host=None, plan=plan, native=(d64, d32),
+                         **{k: view(k) for k in ("topo_label", "cls_clab", "cls_ilab", "topo_batch32", "cls_batch32",
+                                                 "assm_batch32")})
+        return self
+
     # ------------------------------------------------------------------ device copy (one upload)
     def to_device(self, device) -> "DecodeSchedule":
         """All index lists packed into one pinned int64 buffer, one asynchronous copy; per-step views of it."""
         if self._dev is not None and self._dev["device"] == device:
             return self
+        if self._native is not None:
+            return self._native_to_device(device)
         chunks: List[np.ndarray] = []
         where: List[Tuple[int, int]] = []
 
@@ -305,6 +398,26 @@ class DecodeSchedule:
         return self
 
 
+class _FrozenTables:
+    """What a pickled, natively built schedule carries instead of the library handle: plain numpy copies of the tables,
+    the two device packs and the directory -- the same interface as schedule_native.NativeTables."""
+
+    def __init__(self, nt):
+        self.names, self.dir = list(nt.names), dict(nt.dir)
+        self._arr = {k: np.array(nt.get(k)) for k in nt.names}
+        self.packs = {k: np.array(v) for k, v in nt.packs.items()}
+        self._scalars = nt.scalars()
+
+    def get(self, name):
+        return self._arr[name]
+
+    def has(self, name):
+        return name in self._arr
+
+    def scalars(self):
+        return dict(self._scalars)
+
+
 def synth_orders(specs, tree_scope):
     """``orders`` as ``MolGraph.tensorize`` builds them (ggpm/mol_graph.py:225-231): per molecule the DFS order with
     the batch offset of its tree nodes."""
@@ -334,6 +447,13 @@ class HierMPNDecoder(ScoreHeads):
         self.E_assm = self.hmpn.E_i
         if latent_size != hidden_size:
             self.W_root = nn.Linear(latent_size, hidden_size)
+
+    def schedule_hints(self) -> dict:
+        """What ``DecodeSchedule.from_*`` can use of this decoder: diterG and the number of gates of its message function,
+        so that the native builder prepares the tables that depend on them in the same call."""
+        from .rnn import LSTM
+        rnn = self.hmpn.graph_encoder.rnn
+        return dict(depth=rnn.depth, gates=4 if isinstance(rnn, LSTM) else 3)
 
     # ------------------------------------------------------------------ enum_attach, batched over one step
     def enum_attach_batched(self, hgraph_node, k: int, atoms, icls, nth) -> torch.Tensor:
@@ -367,7 +487,7 @@ class HierMPNDecoder(ScoreHeads):
         B, H, L = len(orders), self.hidden_size, self.latent_size
         dev = tree_tensors[0].device
         if schedule is None:
-            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.vocab)
+            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.vocab, **self.schedule_hints())
         D = schedule.to_device(dev)._dev
         src_root_vecs, src_tree_vecs, src_graph_vecs = src_mol_vecs
         if L == H:

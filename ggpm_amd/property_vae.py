@@ -230,7 +230,7 @@ class HierPropertyVAE(nn.Module):
             # bookkeeping HERE, from the batch as it arrives (host arrays: no read-back), so that the atom level can be
             # issued beside the encoder exactly as with a prepared schedule
             from .decoder import DecodeSchedule
-            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab)
+            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab, **self.decoder.schedule_hints())
         tree_tensors, graph_tensors = tensors = make_cuda(tensors)
         self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
         root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]

@@ -1,0 +1,144 @@
+"""ctypes front end of csrc/schedule.hip: the decoder's per-batch integer bookkeeping built in C++ (host only).
+
+``build_tables`` takes what ``DecodeSchedule.from_tensors`` takes and returns a :class:`NativeTables`: named integer
+tables as numpy views into the library's buffers, the two device packs (one int64, one int32 upload per batch) and the
+directory that says where each device table sits inside its pack.  The numpy builders in ``decoder.py`` /
+``atom_decode.py`` remain the statement of what the tables mean and the checker (tests/test_schedule_native.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_P64 = ctypes.POINTER(ctypes.c_int64)
+
+
+class SchedIn(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_sched_in"""
+    _fields_ = [(k, ctypes.c_int) for k in ("B", "Nt1", "Et1", "At", "Kt", "C", "Ng1", "Eg1", "Ag", "Kg", "depth", "gates")] + \
+               [(k, ctypes.c_void_p) for k in ("tfnode", "tfmess", "tagraph", "tbgraph", "cgraph", "tree_scope", "gfmess",
+                                               "gagraph", "gbgraph", "orders", "order_off", "icls_off", "icls", "cand_off",
+                                               "cand_atom_off", "cands")]
+
+
+def enabled() -> bool:
+    return os.environ.get("GGPM_NATIVE_SCHEDULE", "1") != "0"
+
+
+def _i64(x) -> np.ndarray:
+    if hasattr(x, "detach"):                      # a torch tensor (host): no copy when it already is int64
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+class NativeTables:
+    """Owner of one ``ggpm_schedule_build`` result.  ``get(name)`` -> numpy view (valid while this object lives)."""
+
+    _ELEM = {8: np.int64, 4: np.int32, 1: np.uint8}
+
+    def __init__(self, handle, lib):
+        self._h, self._lib = handle, lib
+        cap = 1 << 13
+        buf = ctypes.create_string_buffer(cap)
+        _lib.check(lib.ggpm_schedule_names(handle, buf, cap), "schedule_names")
+        self.names = buf.value.decode().split("\n")[:-1]
+        table = np.empty(4 * len(self.names), dtype=np.int64)
+        n = lib.ggpm_schedule_directory(handle, table.ctypes.data, table.size)
+        if n != len(self.names):
+            raise RuntimeError("ggpm_schedule_directory: %d" % n)
+        rows = table.reshape(-1, 4).tolist()
+        self.dir: Dict[str, Tuple[int, int, int, int]] = {k: tuple(r) for k, r in zip(self.names, rows)}   # (pack, byte offset, count, elem)
+        self._arr: Dict[str, np.ndarray] = {}
+        self._bytes = {}
+        ptr, nb = ctypes.c_void_p(), ctypes.c_int64()
+        for which in (0, 1, 2):
+            _lib.check(lib.ggpm_schedule_pack(handle, which, ctypes.byref(ptr), ctypes.byref(nb)), "schedule_pack")
+            if nb.value and ptr.value:
+                self._bytes[which] = np.frombuffer((ctypes.c_uint8 * nb.value).from_address(ptr.value), dtype=np.uint8)
+            else:
+                self._bytes[which] = np.zeros(0, dtype=np.uint8)
+        self.packs = {1: self._bytes[1].view(np.int64), 2: self._bytes[2].view(np.int32)}
+
+    def get(self, name: str) -> np.ndarray:
+        a = self._arr.get(name)
+        if a is None:
+            pack, off, cnt, el = self.dir[name]
+            a = self._arr[name] = self._bytes[pack][off:off + cnt * el].view(self._ELEM[el])
+        return a
+
+    def has(self, name: str) -> bool:
+        return name in self.dir
+
+    def scalars(self) -> dict:
+        keys = ("T", "n_inst", "E1", "chain", "all_live", "max_cls_size", "n_assm", "n_cand", "Ftot", "ok", "B", "depth",
+                "gates", "Ng1", "Eg1")
+        return dict(zip(keys, self.get("scalars").tolist()))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.ggpm_schedule_free(h)
+            except Exception:
+                pass
+
+    def __getstate__(self):
+        raise TypeError("NativeTables holds a library handle; pickle the DecodeSchedule (it converts itself)")
+
+
+def build_tables(tensors, orders, inter_icls: Dict[int, Tuple[int, ...]], assm_cands: Dict[int, list], depth: int = 0,
+                 gates: int = 0) -> "NativeTables | None":
+    """-> NativeTables, or None when the library declines the batch (malformed orders / labels: the numpy builder then
+    raises the informative error)."""
+    lib = _lib.load()
+    tree, graph = tensors
+    tfnode, tfmess, tagraph, tbgraph, cgraph = (_i64(x) for x in tree[:5])
+    gfmess, gagraph, gbgraph = _i64(graph[1]), _i64(graph[2]), _i64(graph[3])
+    if tfnode.ndim != 2 or tfnode.shape[1] != 2 or tfmess.ndim != 2 or tfmess.shape[1] != 4 or gfmess.shape[1] != 4:
+        return None
+    scope = np.ascontiguousarray(np.asarray(tree[-1], dtype=np.int64).reshape(-1, 2))
+    B, Nt1 = len(orders), tfnode.shape[0]
+    od = np.asarray([(x, -1 if y is None else y, z) for o in orders for (x, y, z) in o], dtype=np.int64).reshape(-1, 3)
+    ooff = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum([len(o) for o in orders], out=ooff[1:])
+    # per tree node: its attachment ids (k of them) and its candidates (tuples of k atoms, or bare atoms when k = 1), flat
+    icls_n, cand_n, atom_n = [0] * (Nt1 + 1), [0] * (Nt1 + 1), [0] * (Nt1 + 1)
+    icls_flat, cand_flat = [], []
+    for v in range(Nt1):
+        ic = inter_icls.get(v)
+        if ic:
+            icls_n[v + 1] = len(ic)
+            icls_flat.extend(ic)
+        c = assm_cands.get(v)
+        if c is not None and len(c):
+            k = icls_n[v + 1]
+            if isinstance(c, np.ndarray):
+                c = c.reshape(len(c), -1).tolist()
+            if isinstance(c[0], (list, tuple)):
+                if len(c[0]) != k:
+                    return None
+                for tup in c:
+                    cand_flat.extend(tup)
+            else:
+                if k != 1:
+                    return None
+                cand_flat.extend(c)
+            cand_n[v + 1] = len(c)
+            atom_n[v + 1] = len(c) * k
+    icls_off, cand_off, cand_atom_off = (np.cumsum(np.asarray(x, dtype=np.int64)) for x in (icls_n, cand_n, atom_n))
+    icls, cands = np.asarray(icls_flat, dtype=np.int64), np.asarray(cand_flat, dtype=np.int64)
+    if cands.size != cand_atom_off[-1] or icls.size != icls_off[-1]:
+        return None
+    keep = (tfnode, tfmess, tagraph, tbgraph, cgraph, scope, gfmess, gagraph, gbgraph, od, ooff, icls_off, icls, cand_off,
+            cand_atom_off, cands)
+    p = lambda a: a.ctypes.data if a.size else 0
+    si = SchedIn(B, Nt1, tfmess.shape[0], tagraph.shape[1], tbgraph.shape[1], cgraph.shape[1], gagraph.shape[0],
+                 gfmess.shape[0], gagraph.shape[1], gbgraph.shape[1], int(depth), int(gates), *[p(a) for a in keep])
+    h = lib.ggpm_schedule_build(ctypes.byref(si))
+    del keep
+    return NativeTables(h, lib) if h else None

@@ -453,6 +453,43 @@ int ggpm_persistent_timeout(uint32_t* sync, ggpm_stream_t stream);
 int ggpm_timing_enable(int on);
 int ggpm_timing_collect(int which, int* launches, double* total_ms, double* flops);
 
+/* ------------------------------------------------------------------ decode schedule (host only, no GPU work)
+ * The integer bookkeeping of the teacher-forced decoder for one tensorized batch, which the reference interleaves
+ * with device work on every step of HierMPNDecoder.forward (ggpm/decoder.py:186-259: the per-step subtree / subgraph
+ * lists, update_graph_mask :85-100, init_decoder_state :102-122, apply_tree_mask / apply_graph_mask :72-83, the
+ * prediction tuples) and IncHierMPNEncoder.get_sub_tensor (ggpm/encoder.py:195-206), derived once per batch:
+ * the tables of ggpm_amd.decoder.DecodeSchedule (from_tensors, _level_plan) and ggpm_amd.atom_decode.AtomPlan
+ * (compact row sets, compact_tables) -- the numpy forms there are the checker (tests/test_schedule_native.py).
+ * Inputs are host arrays, int64, row-major, in the MolGraph.tensorize layout (ggpm/mol_graph.py:199-281):
+ *   tree  fnode [Nt1 x 2], fmess [Et1 x 4], agraph [Nt1 x At], bgraph [Et1 x Kt], cgraph [Nt1 x C], scope [B x 2];
+ *   graph fmess [Eg1 x 4], agraph [Ng1 x Ag], bgraph [Eg1 x Kg];
+ *   orders [n x 3] = (x, y or -1 for None, label) of all molecules back to back, order_off [B + 1];
+ *   per tree node v: the attachment ids of its inter_label, icls[icls_off[v] .. icls_off[v+1]) (k_v = their number), and
+ *   its assm_cands as cand_off[v+1] - cand_off[v] candidates of k_v atoms each, flat from cands[cand_atom_off[v]].
+ * depth / gates: also build the tables that depend on the decoder's diterG and cell (3 GRU / 4 LSTM); 0 = leave out.
+ * Returns an opaque handle (NULL: malformed input); tables are read with ggpm_schedule_get by name (pack 0 = host
+ * only; 1 / 2 = inside the int64 / int32 device pack; ggpm_schedule_pack returns a pack's base, `offset` is in bytes from it).  The
+ * call keeps no global state and may run on any thread. */
+typedef struct ggpm_sched_in {
+    int B, Nt1, Et1, At, Kt, C;
+    int Ng1, Eg1, Ag, Kg;
+    int depth, gates;
+    const int64_t *tfnode, *tfmess, *tagraph, *tbgraph, *cgraph, *tree_scope;
+    const int64_t *gfmess, *gagraph, *gbgraph;
+    const int64_t *orders, *order_off;
+    const int64_t *icls_off, *icls;
+    const int64_t *cand_off, *cand_atom_off, *cands;
+} ggpm_sched_in;
+void* ggpm_schedule_build(const ggpm_sched_in* in);
+int ggpm_schedule_get(void* handle, const char* name, const void** data, int64_t* count, int* elem_bytes, int* pack,
+                      int64_t* offset);
+int ggpm_schedule_pack(void* handle, int pack, const void** data, int64_t* bytes);
+int ggpm_schedule_names(void* handle, char* out, int64_t capacity);      /* newline-separated table names */
+/* (pack, byte offset, count, element bytes) per table in the order of ggpm_schedule_names.  Returns the number of
+ * tables, or -GGPM_ERR_* on error.  `capacity` in int64 elements (4 per table). */
+int ggpm_schedule_directory(void* handle, int64_t* out, int64_t capacity);
+void ggpm_schedule_free(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_symbol():
 
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):
-    """The two structs that cross the C ABI (ggpm_enc_dims, ggpm_decode_steps): a C program compiled against
+    """The structs that cross the C ABI (ggpm_enc_dims, ggpm_decode_steps, ggpm_sched_in): a C program compiled against
     include/ggpm_hip.h prints sizeof and every field offset; the ctypes mirrors must agree."""
     import ctypes
     import subprocess
@@ -43,7 +43,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         pytest.skip("the ABI probe starts child processes: not from a process that has initialised the GPU")
     from ggpm_amd.atom_decode import DecodeSteps
     from ggpm_amd.fused import EncDims
-    structs = {"ggpm_enc_dims": EncDims, "ggpm_decode_steps": DecodeSteps}
+    from ggpm_amd.schedule_native import SchedIn
+    structs = {"ggpm_enc_dims": EncDims, "ggpm_decode_steps": DecodeSteps, "ggpm_sched_in": SchedIn}
     lines = []
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

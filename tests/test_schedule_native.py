@@ -1,0 +1,140 @@
+"""CPU: the decode schedule built by csrc/schedule.hip (host-only C++) against the numpy builders it restates --
+``DecodeSchedule.from_tensors`` / ``_level_plan`` (ggpm_amd/decoder.py) and ``AtomPlan`` / ``compact_tables``
+(ggpm_amd/atom_decode.py).  Every table, element for element."""
+import pickle
+
+import numpy as np
+import pytest
+
+from ggpm_amd import synth
+from ggpm_amd.atom_decode import AtomPlan
+from ggpm_amd.decoder import DecodeSchedule
+
+CASES = {
+    "configs1": dict(seed=1000, B=32, motifs=(8, 12), vocab=(500, 1500)),
+    "qm9_like": dict(seed=7, B=64, motifs=(1, 3), vocab=(60, 180)),
+    "one_molecule": dict(seed=3, B=1, motifs=(4, 9), vocab=(30, 90)),
+    "small": dict(seed=5, B=4, motifs=(2, 6), vocab=(30, 90)),
+    "polymers": dict(seed=606, B=3, motifs=(46, 58), vocab=(60, 180)),
+    "mix": dict(seed=11, B=12, motifs="mix", vocab=(721, 6214)),
+}
+
+
+def _batch(c):
+    if c["motifs"] == "mix":
+        specs = synth.size_mix_batch(c["seed"], c["B"], one_of_each=True, n_motif_vocab=c["vocab"][0], n_attach_vocab=c["vocab"][1])
+    else:
+        specs = synth.random_batch(c["seed"], c["B"], motifs=c["motifs"], n_motif_vocab=c["vocab"][0], n_attach_vocab=c["vocab"][1])
+    return specs, synth.tensorize(specs)
+
+
+def _same(a, b, what):
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape and np.array_equal(a, b), what
+    else:
+        assert a == b, (what, a, b)
+
+
+def _same_steps(sa, sb):
+    assert len(sa) == len(sb)
+    for t, (x, y) in enumerate(zip(sa, sb)):
+        for k in x:
+            if k != "assm":
+                assert list(x[k]) == list(y[k]), (t, k)
+        assert len(x["assm"]) == len(y["assm"]), t
+        for (c1, i1, n1, b1), (c2, i2, n2, b2) in zip(x["assm"], y["assm"]):
+            assert np.array_equal(c1, c2) and tuple(i1) == tuple(i2) and n1 == n2 and b1 == b2, t
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("depth,gates", [(5, 3), (2, 4)])
+def test_native_schedule_equals_the_numpy_builders(case, depth, gates):
+    specs, tensors = _batch(CASES[case])
+    nat = DecodeSchedule.from_specs(specs, tensors, depth=depth, gates=gates, native=True)
+    ref = DecodeSchedule.from_specs(specs, tensors, native=False)
+    if ref.plan["E1"] <= 1 or not ref.plan["all_live"]:
+        assert nat._native is None            # degenerate batches take the numpy builder and the step-by-step forms
+        return
+    assert nat._native is not None and ref._native is None
+    assert (nat.batch_size, nat.max_cls_size, nat.root_clab, nat.root_ilab) == (ref.batch_size, ref.max_cls_size,
+                                                                                 ref.root_clab, ref.root_ilab)
+    assert set(nat.plan) == set(ref.plan)
+    for k in ref.plan:
+        _same(nat.plan[k], ref.plan[k], "plan." + k)
+    _same_steps(nat.steps, ref.steps)
+    assert nat.topo() == ref.topo() and nat.cls() == ref.cls() and nat.assm_batch() == ref.assm_batch()
+    # the int32 molecule indices the heads gather by
+    tb, _ = ref.topo()
+    cb, _, _ = ref.cls()
+    _same(nat._native.get("topo_batch32"), np.asarray(tb, dtype=np.int32), "topo_batch32")
+    _same(nat._native.get("cls_batch32"), np.asarray(cb, dtype=np.int32), "cls_batch32")
+    _same(nat._native.get("assm_batch32"), np.repeat(np.asarray(ref.assm_batch(), dtype=np.int32), ref.max_cls_size), "assm_batch32")
+
+    N1, E1 = tensors[1][0].shape[0], tensors[1][1].shape[0]
+    pa, pb = nat.atom_plan(N1, E1), AtomPlan(ref, N1, E1, full=False)
+    for k in ("T", "N1", "E1", "ok", "nloc", "floc_off", "n_cand", "full"):
+        _same(getattr(pa, k), getattr(pb, k), "AtomPlan." + k)
+    assert list(pa.aoff) == list(pb.aoff) and list(pa.ioff) == list(pb.ioff)
+    assert [tuple(x) for x in pa.cand_blocks] == [tuple(x) for x in pb.cand_blocks]
+    assert [[tuple(s) for s in st] for st in pa.step_cands] == [[tuple(s) for s in st] for st in pb.step_cands]
+    _same(pa.frozen_loc, pb.frozen_loc, "frozen_loc")
+    assert set(pa.where) == set(pb.where)
+    for key, (off, n) in pb.where.items():
+        o2, n2 = pa.where[key]
+        assert n2 == n, key
+        _same(pa.ints[o2:o2 + n2], pb.ints[off:off + n], key)
+    assert set(pa.cand_meta) == set(pb.cand_meta)
+    for k, m in pb.cand_meta.items():
+        for name, v in m.items():
+            _same(np.asarray(pa.cand_meta[k][name], dtype=np.int64), v, ("cand_meta", k, name))
+    for dg in ((depth, gates), (3, 3)):        # the pair the build was given (native tables) and another one (numpy over the native rows)
+        ca, cb_ = pa.compact_tables(*dg), pb.compact_tables(*dg)
+        assert ca["foff"] == cb_["foff"] and ca["Ftot"] == cb_["Ftot"] and set(ca["where"]) == set(cb_["where"])
+        assert bool(ca.get("native")) == (dg == (depth, gates))
+        for key, (off, n) in cb_["where"].items():
+            o2, n2 = ca["where"][key]
+            assert n2 == n, key
+            _same(ca["ints"][o2:o2 + n2], cb_["ints"][off:off + n], ("compact", dg, key))
+    assert pa.row_offsets(depth) == pb.row_offsets(depth)
+
+
+def test_native_schedule_survives_pickling():
+    """Loader workers build schedules and ship them: a natively built one converts its tables to plain arrays."""
+    specs, tensors = _batch(CASES["small"])
+    nat = DecodeSchedule.from_specs(specs, tensors, depth=5, gates=4)
+    assert nat._native is not None
+    back = pickle.loads(pickle.dumps(nat))
+    for k in nat.plan:
+        _same(back.plan[k], nat.plan[k], k)
+    _same_steps(back.steps, nat.steps)
+    N1, E1 = tensors[1][0].shape[0], tensors[1][1].shape[0]
+    pa, pb = back.atom_plan(N1, E1), nat.atom_plan(N1, E1)
+    _same(pa.ints, pb.ints, "ints")
+    assert pa.where == pb.where and pa.nloc == pb.nloc
+    ca, cb_ = pa.compact_tables(5, 4), pb.compact_tables(5, 4)
+    assert ca["where"] == cb_["where"]
+    _same(back._native.packs[1], nat._native.packs[1], "pack64")
+    _same(back._native.packs[2], nat._native.packs[2], "pack32")
+
+
+def test_native_builder_refuses_tables_that_index_outside_themselves():
+    from ggpm_amd import schedule_native as SN
+    from ggpm_amd.decoder import synth_orders
+    specs, tensors = _batch(CASES["small"])
+    tree, graph = tensors
+    orders = synth_orders(specs, tree[-1])
+    icls, cands = {}, {}
+    for b, m in enumerate(specs):                 # (the labels DecodeSchedule.from_specs reads)
+        toff, aoff = tree[-1][b][0], graph[-1][b][0]
+        for i in range(m.n_motifs):
+            icls[toff + i] = tuple(a for _, a in m.inter_label[i])
+            cands[toff + i] = [x + aoff for x in m.assm_cands[i]]
+    assert SN.build_tables(tensors, orders, icls, cands) is not None
+    bad = [list(o) for o in orders]
+    bad[0][0] = (10 ** 6, bad[0][0][1], bad[0][0][2])            # a node id beyond the tree tensors
+    assert SN.build_tables(tensors, bad, icls, cands) is None
+    g2 = list(graph)
+    g2[3] = np.array(graph[3]).copy()
+    g2[3][1, 0] = 10 ** 6                                          # a predecessor id beyond the bond table
+    assert SN.build_tables((tree, tuple(g2)), orders, icls, cands) is None
