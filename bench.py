@@ -397,27 +397,28 @@ class Workload:
 class VaeWorkload:
     """The "reported row" of SURVEY.md section 8(d): the FULL VAE training step -- HierPropertyVAE.forward (encoder,
     rsample with perturbation, teacher-forced HierMPNDecoder with diterT = 1 / diterG = 5 as every shipped config has
-    them, the four losses) + backward + Adam -- on the configs[1] workload, N = 1.  The decoder's per-batch integer
-    bookkeeping (DecodeSchedule) is resident on the device like the index tensors."""
+    them, the four losses) + backward (+ gradient all-reduce for N > 1) + Adam -- on the configs[1] workload.
+
+    Two ways of feeding it, both reported:
+      * ``ms_per_step``            the batches' index tensors AND decode schedules resident on the device, like the index
+                                   tensors of the encoder row (``schedule=`` passed in);
+      * ``schedule_in_loop``       ``model(*batch, beta=beta)`` exactly as vae_train.py:78 calls it: the batch arrives as
+                                   host arrays + the networkx graphs, ``make_cuda`` and the decode schedule
+                                   (DecodeSchedule.from_graphs -> csrc/schedule.hip, two uploads) happen INSIDE the step.
+    """
 
     DITER_T, DITER_G, TIE = 1, 5, False
 
-    def __init__(self, cfg, rnn, a, dev):
+    def __init__(self, cfg, rnn, a, dev, rank=0, world=1):
         from ggpm_amd import synth
         from ggpm_amd.decoder import DecodeSchedule
         from ggpm_amd.nnutils import make_cuda
+        from ggpm_amd.parallel import FlatGradSync, broadcast_parameters
         from ggpm_amd.property_vae import HierPropertyVAE
         from ggpm_amd.vocab import IndexPairVocab
-        self.cfg, self.rnn, self.a, self.dev = cfg, rnn, a, dev
+        self.cfg, self.rnn, self.a, self.dev, self.rank, self.world = cfg, rnn, a, dev, rank, world
         n_motif, n_attach = cfg["vocab"]
         self.vocab = IndexPairVocab(n_motif, n_attach)
-        self.items = []
-        for i in range(min(a.pool, 8)):
-            specs = synth.random_batch(1000 + i, cfg["batch"], motifs=tuple(cfg["gen"]), n_motif_vocab=n_motif,
-                                       n_attach_vocab=n_attach)
-            tensors = synth.tensorize(specs)
-            sch = DecodeSchedule.from_specs(specs, tensors)
-            self.items.append((tensors, make_cuda(tensors), sch.to_device(dev)))
         args = make_args(rnn, cfg["hidden"], cfg["depth"], cfg["latent"], n_motif, n_attach)
         args.vocab, args.diterT, args.diterG, args.tie_embedding = self.vocab, self.DITER_T, self.DITER_G, self.TIE
         torch.manual_seed(0)
@@ -427,37 +428,119 @@ class VaeWorkload:
                 torch.nn.init.constant_(p, 0)
             else:
                 torch.nn.init.xavier_normal_(p)
+        hints = self.model.decoder.schedule_hints()
+        self.items = []
+        for i in range(min(a.pool, 8)):
+            specs = synth.random_batch(1000 + rank * 313 + i, cfg["batch"], motifs=tuple(cfg["gen"]), n_motif_vocab=n_motif,
+                                       n_attach_vocab=n_attach)
+            tensors = synth.tensorize(specs)
+            batch6 = synth.train_batch(specs, tensors)            # what a DataFolder batch holds (vae_train.py:75-78)
+            sch = DecodeSchedule.from_graphs(batch6[1], tensors, batch6[3], self.vocab, **hints)
+            self.items.append((tensors, make_cuda(tensors), sch.to_device(dev), batch6))
+        broadcast_parameters(self.model)
+        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder) if world > 1 else None
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
         self.orders = [None] * cfg["batch"]
 
-    def step(self, i):
-        _, dev_tensors, sch = self.items[i % len(self.items)]
-        self.opt.zero_grad(set_to_none=True)
-        loss, metrics = self.model(None, None, dev_tensors, self.orders, None, None, beta=0.1, perturb_z=True, schedule=sch)
+    def _finish(self, loss, metrics):
         loss.backward()
+        if self.sync is not None:
+            self.sync.all_reduce()
         self.opt.step()
         metrics["Loss"]      # the training loop reads the metrics here (vae_train.py:86): one host read-back per step
         return metrics
 
-    def measure(self):
-        steps, warm = min(self.a.steps, 30), 2 * len(self.items)      # two passes over the pool: every batch shape seen, clocks up
-        for i in range(warm):
-            m = self.step(i)
+    def _zero(self):
+        if self.sync is not None:
+            self.sync.zero_grad()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+
+    def step(self, i):
+        _, dev_tensors, sch, _ = self.items[i % len(self.items)]
+        self._zero()
+        loss, metrics = self.model(None, None, dev_tensors, self.orders, None, None, beta=0.1, perturb_z=True, schedule=sch)
+        return self._finish(loss, metrics)
+
+    def step_in_loop(self, i):
+        batch6 = self.items[i % len(self.items)][3]
+        self._zero()
+        loss, metrics = self.model(*batch6, beta=0.1)             # vae_train.py:78, unchanged
+        return self._finish(loss, metrics)
+
+    def _fence(self):
         torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def _timed(self, fn, steps, first):
+        """EXACTLY `steps` calls between two fences, max over ranks -> (ms per step, per-step host marks)"""
         _settle_gc()
+        self._fence()
         t0 = time.perf_counter()
         marks = [t0]
         for i in range(steps):
-            m = self.step(warm + i)              # (ends with the metrics' .item(): the host is in step with the GPU)
+            fn(first + i)                     # (ends with the metrics' host read: the host is in step with the GPU)
             marks.append(time.perf_counter())
-        torch.cuda.synchronize()
+        self._fence()
         dt = time.perf_counter() - t0
-        B = self.cfg["batch"]
-        raw = [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return 1e3 * dt / steps, [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
+
+    def work(self):
+        """Executed / algorithmic flops per step (fwd + bwd = 3 x fwd), from the batches' schedules.
+
+        Per (row, depth step) of a message function: G gate products of 2 H^2 flops.  Encoder: the three levels as in
+        `algorithmic_work` (executed = with the tree fixed point).  Decoder atom level: every decode step runs its compact
+        row set (its bonds + the frozen older bonds they read) through diterG depth steps -- `executed` counts all rows of
+        the set, `algorithmic` the rows that are really recomputed.  Decoder tree-side levels: all messages, `chain`
+        synchronous steps each (DecodeSchedule._level_plan).  Heads: topoNN / clsNN / iclsNN / matchNN / W_assm and the
+        read-outs as dense products over their rows."""
+        from ggpm_amd import synth
+        cfg = self.cfg
+        H, L, depth = cfg["hidden"], cfg["latent"], cfg["depth"]
+        G = 3 if self.rnn == "GRU" else 4
+        n_motif, n_attach = cfg["vocab"]
+        chains = [int(getattr(it[1][0][3], "ggpm_chain", 0)) for it in self.items]
+        enc_full, enc_exec, _ = algorithmic_work([it[0] for it in self.items], H, depth, G, chains)
+        ex = al = 0.0
+        for tensors, _, sch, _ in self.items:
+            P = sch.plan
+            plan = sch.atom_plan(tensors[1][0].shape[0], tensors[1][1].shape[0])
+            gate = 2.0 * G * H * H
+            rows_exec = float(sum(plan.nloc))
+            rows_live = float(P["bond_off"][-1])
+            E1g, E1t = tensors[1][1].shape[0] - 1, P["E1"] - 1
+            x_atom = 2.0 * G * E1g * 62 * H                          # hoisted gate inputs of all bonds
+            ex += self.DITER_G * rows_exec * gate + x_atom
+            al += self.DITER_G * rows_live * gate + x_atom
+            tree = 2 * (max(P["chain"], 1) * E1t * gate + 2.0 * G * E1t * (H + 20) * H)
+            n_inst, ns_tot = P["n_inst"], P["atom_off"][-1]
+            readouts = ns_tot * 2.0 * (38 + H) * H + n_inst * (2 * 2.0 * 2 * H * H + 2 * 2.0 * 2 * H * H)
+            n_topo, n_cls = len(sch.topo()[0]), len(sch.cls()[0])
+            heads = (n_topo * 2.0 * (H + L) * H + n_cls * (2 * 2.0 * (H + L) * H + 2.0 * H * (n_motif + n_attach))
+                     + plan.n_cand * 2.0 * (H + H + 20) * H + len(sch.assm_batch()) * sch.max_cls_size * 2.0 * H * L)
+            ex += tree + readouts + heads
+            al += tree + readouts + heads
+        n = len(self.items)
+        return enc_exec + 3.0 * ex / n, enc_full + 3.0 * al / n
+
+    def measure(self):
+        B, steps = self.cfg["batch"], min(self.a.steps, 30)
+        warm = 2 * len(self.items)        # two passes over the pool: every batch shape seen, clocks up
+        for i in range(warm):
+            m = self.step(i)
+        ms, raw = self._timed(self.step, steps, warm)
         per = sorted(raw)
         log("full VAE step (%s): %.2f ms/step (per step: min %.2f, median %.2f, max %.2f at step %d; reserved %.1f GB), loss %.3f"
-            % (self.rnn, 1e3 * dt / steps, per[0], per[len(per) // 2], per[-1], raw.index(per[-1]),
-               torch.cuda.memory_reserved() / 1e9, m["Loss"]))
+            % (self.rnn, ms, per[0], per[len(per) // 2], per[-1], raw.index(per[-1]), torch.cuda.memory_reserved() / 1e9,
+               m["Loss"]))
         # the same steps with the index structures derived from the resident decode tables (CSRs, transposes, frozen masks)
         # rebuilt on the device every step, as a stream of never-seen batches would have it
         from ggpm_amd import functional as F_
@@ -466,24 +549,55 @@ class VaeWorkload:
             F_._MEMO_ON = False
             for i in range(len(self.items)):
                 self.step(i)
-            torch.cuda.synchronize()
-            n2 = min(steps, 20)
-            t1 = time.perf_counter()
-            for i in range(n2):
-                self.step(i)
-            torch.cuda.synchronize()
-            fresh = round(1e3 * (time.perf_counter() - t1) / n2, 3)
+            fresh, _ = self._timed(self.step, min(steps, 20), 0)
         finally:
             F_._MEMO_ON = True
         log("  ... %.2f ms/step with the index structures rebuilt every step" % fresh)
-        return {"ms_per_step": round(1e3 * dt / steps, 3), "value": round(steps * B / dt, 2), "unit": "molecules/s",
-                "ms_per_step_index_structures_rebuilt": fresh,
-                "steps": steps, "warmup": warm, "rnn_type": self.rnn,
-                "workload": "HierPropertyVAE fwd (perturb_z) + bwd + Adam on the configs[1] batches: latent=%d, diterT=%d, "
-                            "diterG=%d, tie_embedding=%s, metrics read back on the host every step (after optimizer.step(), where vae_train.py uses them); the batches' "
-                            "index tensors AND decode schedules are resident on the device, and the index structures derived "
-                            "from them are kept across steps (ms_per_step_index_structures_rebuilt: rebuilt every step)"
-                            % (self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}
+        # vae_train.py:78 unchanged: host batch in, make_cuda + decode schedule (C++ builder, two uploads) inside the step
+        for i in range(len(self.items)):
+            self.step_in_loop(i)
+        loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0)
+        t0 = time.perf_counter()
+        from ggpm_amd.decoder import DecodeSchedule
+        hints = self.model.decoder.schedule_hints()
+        for k in range(16):
+            b6 = self.items[k % len(self.items)][3]
+            DecodeSchedule.from_graphs(b6[1], b6[2], b6[3], self.vocab, **hints)
+        build_ms = 1e3 * (time.perf_counter() - t0) / 16
+        log("  ... %.2f ms/step as vae_train.py calls it (host batch + networkx graphs in; schedule build %.2f ms of host time)"
+            % (loop_ms, build_ms))
+        fl_exec, fl_alg = self.work()
+        tf = fl_exec * self.world / (ms * 1e-3) / 1e12
+        out = {"ms_per_step": round(ms, 3), "value": round(B * self.world / (ms * 1e-3), 2), "unit": "molecules/s",
+               "ms_per_step_index_structures_rebuilt": round(fresh, 3),
+               "schedule_in_loop": {"ms_per_step": round(loop_ms, 3), "value": round(B * self.world / (loop_ms * 1e-3), 2),
+                                    "ratio_to_resident": round(loop_ms / ms, 3),
+                                    "host_schedule_build_ms": round(build_ms, 3),
+                                    "what": "model(*batch, beta=beta) as vae_train.py:78: numpy tensors + networkx graphs in, "
+                                            "make_cuda and DecodeSchedule.from_graphs (csrc/schedule.hip) inside the step"},
+               "steps": steps, "warmup": warm, "rnn_type": self.rnn, "n_gpus": self.world,
+               "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                            "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
+                            "algorithmic_gflop_per_step_per_gpu": round(fl_alg / 1e9, 2),
+                            "note": "whole-step figure: executed flops (every row the kernels process; fwd + bwd = 3 x fwd) over "
+                                    "the step time; the step is a chain of small dependent launches (profiles/r03_vae_*), "
+                                    "not one kernel"},
+               "workload": "HierPropertyVAE fwd (perturb_z) + bwd%s + Adam on the configs[1] batches: latent=%d, diterT=%d, "
+                           "diterG=%d, tie_embedding=%s, metrics read back on the host every step (after optimizer.step(), where "
+                           "vae_train.py uses them); ms_per_step: index tensors AND decode schedules resident on the device, "
+                           "derived index structures kept across steps (ms_per_step_index_structures_rebuilt: rebuilt every "
+                           "step); schedule_in_loop: nothing resident"
+                           % (" + all-reduce" if self.world > 1 else "", self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}
+        try:        # launches per step and per-kernel-class time from the committed rocprofv3 trace of `bench.py --only-vae`
+            with open(os.path.join(ROOT, "profiles", "r03_vae_launches.json")) as f:
+                lj = json.load(f)
+            out["launches_per_step"] = lj.get(self.rnn, {}).get("launches_per_step")
+            out["kernel_classes"] = lj.get(self.rnn, {}).get("classes")
+            out["launches_source"] = lj.get("source")
+        except Exception:
+            pass
+        return out
 
     def cpu_baseline(self, budget_s=14.0):
         """The oracle's full VAE step (oracle/ref_decoder.py, reference op order) on the same batches."""
@@ -494,7 +608,7 @@ class VaeWorkload:
              if not k.startswith(("decoder.rnn_cell.", "decoder.E_assm."))}
         cfg, times, t_begin = self.cfg, [], time.time()
         for i in range(2 + 6):
-            tensors, _, sch = self.items[i % len(self.items)]
+            tensors, _, sch, _ = self.items[i % len(self.items)]
             tt, gt = ref.to_long_tensors(tensors[0]), ref.to_long_tensors(tensors[1])
             t0 = time.time()
             loss, kl, _, _ = refd.vae_forward(p, self.rnn, cfg["depth"], cfg["depth"], self.DITER_T, self.DITER_G, tt, gt,
@@ -611,8 +725,13 @@ def main():
     lib = _lib.load(build_if_missing=False)
 
     if a.only_vae:
-        vae = VaeWorkload(cfg, rnn, a, dev)
-        _emit({"vae_step": vae.measure()})
+        vae = VaeWorkload(cfg, rnn, a, dev, rank, world)
+        res = vae.measure()
+        if rank == 0:
+            _emit({"vae_step": res})
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
         return
     main_wl = Workload(cfg, rnn, a, rank, world, dev, gate_dtype=a.dtype)
     m = main_wl.measure(lib, rank)
@@ -669,16 +788,25 @@ def main():
 
     # the reported row: full VAE training step (never allowed to cost the line)
     vae = None
-    if a.config == 1 and world == 1 and not a.no_vae and not a.host_input:
+    if a.config == 1 and not a.no_vae and not a.host_input:
         try:
             main_wl = other = None               # (their models, device batches and cached blocks are not the VAE row's business)
             import gc
             gc.unfreeze()
             gc.collect()
             torch.cuda.empty_cache()
-            vae = VaeWorkload(cfg, rnn, a, dev)
+            vae = VaeWorkload(cfg, rnn, a, dev, rank, world)
             result["vae_step"] = vae.measure()
+            if a.rnn is None and not a.no_second_cell:          # the LSTM leg of the same row
+                vl = VaeWorkload(cfg, "LSTM", a, dev, rank, world)
+                ml = vl.measure()
+                result["vae_step"]["lstm"] = {k: ml[k] for k in ("ms_per_step", "value", "unit", "schedule_in_loop",
+                                                                 "ms_per_step_index_structures_rebuilt", "roofline",
+                                                                 "launches_per_step") if k in ml}
+                del vl
         except Exception as exc:
+            if world > 1:
+                raise                            # (ranks must not diverge around collectives)
             result["vae_step"] = {"error": repr(exc)}
             vae = None
 
