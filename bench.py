@@ -541,6 +541,13 @@ class VaeWorkload:
         log("full VAE step (%s): %.2f ms/step (per step: min %.2f, median %.2f, max %.2f at step %d; reserved %.1f GB), loss %.3f"
             % (self.rnn, ms, per[0], per[len(per) // 2], per[-1], raw.index(per[-1]), torch.cuda.memory_reserved() / 1e9,
                m["Loss"]))
+        if getattr(self.a, "vae_profile", None) == "resident":      # (rocprofv3 runs: the trace ends with the resident steps)
+            return {"ms_per_step": round(ms, 3), "steps": steps, "rnn_type": self.rnn}
+        if getattr(self.a, "vae_profile", None) == "in_loop":
+            for i in range(len(self.items)):
+                self.step_in_loop(i)
+            loop_ms, _ = self._timed(self.step_in_loop, steps, 0)
+            return {"ms_per_step": round(ms, 3), "schedule_in_loop_ms": round(loop_ms, 3), "steps": steps, "rnn_type": self.rnn}
         # the same steps with the index structures derived from the resident decode tables (CSRs, transposes, frozen masks)
         # rebuilt on the device every step, as a stream of never-seen batches would have it
         from ggpm_amd import functional as F_
@@ -687,6 +694,9 @@ def main():
                     help="skip the run of the other message function (configs[1] reports GRU and, under \"lstm\", LSTM)")
     ap.add_argument("--no-vae", action="store_true", help="skip the full-VAE-step row (\"vae_step\", configs[1], N = 1)")
     ap.add_argument("--only-vae", action="store_true", help="profiling: run ONLY the full-VAE-step row and print it")
+    ap.add_argument("--vae-profile", default=None, choices=["resident", "in_loop"],
+                    help="with --only-vae under rocprofv3: stop after the resident steps / after the vae_train.py-shaped steps, so "
+                         "that the trace ends with the steps to be cut out (tools/prof_summary.py --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()

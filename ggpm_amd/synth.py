@@ -143,8 +143,10 @@ def label_tree(spec: MolSpec) -> None:
 
 def random_molecule(rng: random.Random, motifs: Tuple[int, int] = (7, 11),
                     n_motif_vocab: int = 500, attach_per_motif: int = 3,
-                    n_attach_vocab: Optional[int] = None) -> MolSpec:
-    """One random-motif molecule (SURVEY.md section 8d generator)."""
+                    n_attach_vocab: Optional[int] = None, chain: float = 0.0) -> MolSpec:
+    """One random-motif molecule (SURVEY.md section 8d generator).  ``chain`` (default 0: the generator as specified):
+    probability that a new motif attaches to the most recently added one instead of a random earlier motif --
+    ``chain=1`` gives linear, polymer-like backbones."""
     M = rng.randint(motifs[0], motifs[1])
     atom_label: List[int] = []
     bonds: Dict[Tuple[int, int], int] = {}
@@ -184,7 +186,10 @@ def random_molecule(rng: random.Random, motifs: Tuple[int, int] = (7, 11),
             break
         # random parent first (random tree), then a free atom of it
         parents = sorted({c for c, _ in cand})
-        p = parents[rng.randrange(len(parents))]
+        if chain > 0 and parents[-1] == len(clusters) - 1 and rng.random() < chain:
+            p = parents[-1]
+        else:
+            p = parents[rng.randrange(len(parents))]
         free = [a for c, a in cand if c == p]
         a = free[rng.randrange(len(free))]
         clusters.append(build(a))

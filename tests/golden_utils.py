@@ -333,3 +333,53 @@ class VaeGolden(Golden):
         assert err <= rel, "%s grad probe %s: rel err %.3e" % (self.name, pname, err)
         l2 = np.sqrt((g ** 2).sum())
         assert abs(l2 - stat[1]) <= rel * max(stat[1], 1e-12) * 4, "%s grad l2 %s: %g vs %g" % (self.name, pname, l2, stat[1])
+
+
+# ---------------------------------------------------------------------------------------------- fp32 evaluation orders
+def reversed_slots(table):
+    """A zero-padded neighbour table with the real entries of every row in REVERSED order (still left-packed, trailing
+    zero column kept): the same sets, summed by the reference's ops in another order."""
+    t = np.asarray(table)
+    f = t[:, ::-1]
+    order = np.argsort(f == 0, axis=1, kind="stable")
+    return np.ascontiguousarray(np.take_along_axis(f, order, axis=1))
+
+
+def oracle_encoder_result(rnn, depth, sd, tree, graph, dtype=torch.float32, hoisted=False, threads=None):
+    """One oracle evaluation of the test loss  kl + sum_o |o|^2  -> {name: array} (outputs, kl, 'grad <param>')."""
+    from oracle import ref_encoder as ref
+    old_threads, old_rne = torch.get_num_threads(), ref.rne_bf16
+    try:
+        if threads:
+            torch.set_num_threads(threads)
+        if hoisted:
+            ref.rne_bf16 = lambda t: t            # the per-message / split-halves restatement, nothing rounded
+        p = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd.items()}
+        tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
+        routs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt, gate_dtype="bf16w" if hoisted else "f32")
+        _, rkl = ref.rsample_kl(p, routs[0])
+        (rkl + sum((o * o).sum() for o in routs)).backward()
+        r = {n: o.detach().numpy() for n, o in zip(("hroot", "hnode", "hinter", "hatom"), routs)}
+        for k, v in p.items():
+            r["grad " + k] = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))
+        r["kl"] = np.asarray(float(rkl.detach()))
+        return r
+    finally:
+        torch.set_num_threads(old_threads)
+        ref.rne_bf16 = old_rne
+
+
+def oracle_fp32_orders(rnn, depth, sd, tree, graph):
+    """The oracle's fp32 arithmetic in FOUR equivalent evaluation orders -- what "the reference's fp32 result" is known
+    up to: 'padded' (the reference's op order), 'hoisted' (recurrent products applied once per message, gate weights
+    split into input / hidden halves: exact algebra, other summation order), 'slots_reversed' (the predecessor /
+    incoming / cluster lists of every row reversed), 'threads_2' (two BLAS threads instead of all: other blocking)."""
+    rev = lambda t: tuple(reversed_slots(x) if i in idx else x for i, x in enumerate(t[:-1])) + (t[-1],)
+    idx = (2, 3, 4)
+    tree_r = rev(tree)
+    idx = (2, 3)
+    graph_r = rev(graph)
+    return {"padded": oracle_encoder_result(rnn, depth, sd, tree, graph),
+            "hoisted": oracle_encoder_result(rnn, depth, sd, tree, graph, hoisted=True),
+            "slots_reversed": oracle_encoder_result(rnn, depth, sd, tree_r, graph_r),
+            "threads_2": oracle_encoder_result(rnn, depth, sd, tree, graph, threads=2)}

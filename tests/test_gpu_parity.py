@@ -325,7 +325,7 @@ def test_motif_encoder_matches_reference_golden(name):
         g.check_grad(k, v.grad.cpu().numpy(), rel=TOL)
 
 
-def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None):
+def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None, calibrate=False):
     """Full encoder on a synthetic batch: HIP path vs the oracle on the same weights -- the four outputs, the KL and the
     gradient of EVERY parameter.  Norm-wise 1e-4 against the oracle's fp32 run (the BASELINE bar); per element
     (golden_utils.assert_close) against the oracle's fp64 run, relative to the fp32 oracle's own rounding noise
@@ -370,6 +370,28 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True,
             v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
     assert abs(float(kl.detach()) - o32["kl"]) <= tol * max(1.0, abs(o32["kl"]))
     assert set(got) == set(o32) - {"kl"}
+    if calibrate:
+        # Ill-conditioned recurrence: "the reference's fp32 result" is itself only known up to the spread between
+        # equivalent fp32 evaluation orders.  Measure that spread (four orders of the oracle against its fp64 run) and ask
+        # of the HIP result, per tensor, what any of them achieves: at most 2x the worst order's distance to fp64.
+        from golden_utils import ELEM_FLOOR, ELEM_TOL, elem_rel_err, oracle_fp32_orders
+        orders = oracle_fp32_orders(rnn, depth, sd, tree, graph)
+        rows = []
+        for k in got:
+            if np.abs(o64[k]).max() == 0:
+                continue
+            e_hip, e_ord = rel_err(got[k], o64[k]), {n: rel_err(r[k], o64[k]) for n, r in orders.items()}
+            pe_hip = elem_rel_err(got[k], o64[k], ELEM_FLOOR)
+            pe_ord = max(elem_rel_err(r[k], o64[k], ELEM_FLOOR) for r in orders.values())
+            rows.append((k, e_hip, e_ord, pe_hip, pe_ord))
+        worst = max(rows, key=lambda r: r[1] / max(max(r[2].values()), 1e-12))
+        print("calibrated parity (%s H=%d depth=%d): worst tensor %s: HIP %.2e from fp64; fp32 orders %s" % (
+            rnn, H, depth, worst[0], worst[1], ", ".join("%s %.2e" % kv for kv in worst[2].items())))
+        for k, e_hip, e_ord, pe_hip, pe_ord in rows:
+            assert e_hip <= max(2.0 * max(e_ord.values()), 0.5 * tol), \
+                "%s: norm-wise err vs fp64 %.3e; the oracle's fp32 orders: %s" % (k, e_hip, e_ord)
+            assert pe_hip <= max(2.0 * pe_ord, ELEM_TOL), "%s: per-element err vs fp64 %.3e; fp32 orders %.3e" % (k, pe_hip, pe_ord)
+        return
     for k in got:
         assert_close(got[k], o32[k], k, tol=tol, elem_tol=None, b64=None if o64 is None else o64[k], slack=slack)
 
@@ -413,14 +435,27 @@ def test_configs3_h600_shard_matches_oracle():
 def test_configs4_polymer_shard_matches_oracle(rnn):
     """BASELINE configs[4] in fp32: ~200-atom polymers (46..58 motifs), H = 600, depth 30, 4 molecules (the oracle's fp32
     and fp64 runs need ~1 minute on this; bench.py --config 4 runs the 32-molecule batch).  The LSTM case meets the
-    1e-4 bar.  The GRU recurrence with seeded random weights is chaotic at this depth on ~50-motif trees (its state is a
-    SUM over predecessors, h' = (1-z) sum_p h_p + z m, and grows along branching paths until the reset gates saturate):
-    the REFERENCE's own fp32 run is 2e-3 (hroot) to 8e-3 (gradients) away from its fp64 run
-    (profiles/r02_parity_report_configs4_gru.txt), and two fp32 evaluation orders differ by that amplification times a
-    random factor.  There the check is that the HIP result stays within 32x the reference's own distance to fp64."""
+    1e-4 bar.  The GRU recurrence with seeded random weights is ill-conditioned at this depth on ~50-motif RANDOM trees
+    (its state is a SUM over predecessors, h' = (1-z) sum_p h_p + z m, and grows along branching paths until the reset
+    gates saturate): the reference's own fp32 arithmetic is 2e-3 (hroot) to 8e-3 (gradients) away from its fp64 run, and by
+    how much depends on the evaluation order.  So the bound is CALIBRATED, not chosen: the oracle is evaluated in fp32 in
+    four equivalent orders (golden_utils.oracle_fp32_orders: the reference's padded op order, per-message recurrent
+    products, reversed neighbour slots, another BLAS blocking), each order's distance to the fp64 run is measured per
+    tensor, and the HIP result may be at most 2x as far from fp64 as the worst of them (tools/parity_report.py --orders
+    prints the table: profiles/r03_parity_report_configs4_gru.txt)."""
     from ggpm_amd import synth
     specs = synth.random_batch(505, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
-    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, slack=32.0 if rnn == "GRU" else None)
+    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, calibrate=rnn == "GRU")
+
+
+def test_configs4_shape_on_chain_polymers_meets_the_plain_bar():
+    """The same shape class where the recurrence is well conditioned: linear backbones (every motif attaches to the
+    previous one, as in real polymers; ``synth.random_molecule(chain=1)``), ~200 atoms, H = 600, depth 30, GRU, batch 4.
+    There the sum over predecessors has one term along the backbone and the plain norm-wise 1e-4 bar (plus the per-element
+    form against fp64) holds without any calibration."""
+    from ggpm_amd import synth
+    specs = synth.random_batch(506, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500, chain=1.0)
+    _oracle_vs_hip("GRU", 600, 30, specs, 500, 1500, latent=32)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])

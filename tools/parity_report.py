@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--rnn", default=None)
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--orders", action="store_true",
+                    help="also evaluate the oracle's fp32 arithmetic in four equivalent orders (tests/golden_utils."
+                         "oracle_fp32_orders) and print every order's distance to the fp64 run beside the HIP path's")
     a = ap.parse_args()
     cfg = bench.CONFIGS[a.config]
     rnn = a.rnn or cfg["rnn"]
@@ -76,6 +79,24 @@ def main():
         worst = [max(w, v) for w, v in zip(worst, vals)]
         print("%-44s | %10.2e %10.2e | %10.2e %10.2e | %10.2e %10.2e" % ((k,) + tuple(vals)))
     print("%-44s | %10.2e %10.2e | %10.2e %10.2e | %10.2e %10.2e" % (("WORST",) + tuple(worst)))
+    if a.orders:
+        from golden_utils import oracle_fp32_orders
+        orders = oracle_fp32_orders(rnn, depth, sd, tree, graph)
+        names = list(orders)
+        print()
+        print("norm-wise distance to the oracle's fp64 run: the HIP path and the oracle's fp32 arithmetic in %d equivalent "
+              "evaluation orders" % len(names))
+        print("%-44s | %10s | %s | %8s" % ("tensor", "HIP", " ".join("%14s" % n for n in names), "HIP/worst"))
+        top = 0.0
+        for k in hip:
+            if np.abs(np.atleast_1d(o64[k])).max() == 0:
+                continue
+            e = [rel_err(np.atleast_1d(orders[n][k]), np.atleast_1d(o64[k])) for n in names]
+            eh = rel_err(np.atleast_1d(hip[k]), np.atleast_1d(o64[k]))
+            ratio = eh / max(max(e), 1e-30)
+            top = max(top, ratio if max(e) > 5e-5 else 0.0)
+            print("%-44s | %10.2e | %s | %8.2f" % (k, eh, " ".join("%14.2e" % x for x in e), ratio))
+        print("largest HIP / worst-order ratio among the tensors whose fp32 orders are themselves > 5e-5 from fp64: %.2f" % top)
 
 
 if __name__ == "__main__":
