@@ -61,6 +61,9 @@ SIGNATURES = {
     "ggpm_lstm_weight_grads_stacked": (I, [I, I, I, P, P, P, P, P, P, P, I, P, I, P, I, P, I, P, c_size_t, P]),
     "ggpm_decode_steps_forward": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P, P, P]),
     "ggpm_decode_steps_backward": (I, [P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, c_size_t, P, P, P, c_size_t, P, P]),
+    "ggpm_decode_steps_forward_async": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P, P, P]),
+    "ggpm_decode_steps_backward_async": (I, [P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, c_size_t, P, P, P, c_size_t, P, P]),
+    "ggpm_decode_join": (I, []),
     "ggpm_lstm_pack_floats": (c_size_t, [I]),
     "ggpm_lstm_forward": (I, [I, I, I, P, P, P, P, P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_lstm_backward_workspace_bytes": (c_size_t, [I, I, I]),

@@ -420,6 +420,19 @@ def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
 
 
 _DRIVER = os.environ.get("GGPM_DECODE_DRIVER", "1") != "0"    # (0: the step loops are issued from Python; dev A/B, tests)
+# The two step loops are ~280 launches = 1.5-1.8 ms of host time each, inside one C call.  GGPM_ATOM_ASYNC=1 (default)
+# hands them to a worker thread of the library (ggpm_decode_steps_*_async): the forward loop is then issued beside the
+# encoder's forward, the backward loop beside the encoder's backward -- the autograd engine reaches the two nodes at about
+# the same time and would otherwise issue one chain only after the other, although they do not depend on each other.
+# What follows a loop on its stream (read-out / parameter gradients) is enqueued after ggpm_decode_join.
+_ASYNC = os.environ.get("GGPM_ATOM_ASYNC", "1") != "0"
+_INFLIGHT: list = []         # buffers named by loops the worker may still be issuing (released by the next join)
+_PENDING: dict = {}          # id(plan) -> the forward's `finish` closure, taken by atom_decode()
+
+
+def _join_worker(what: str) -> None:
+    _lib.check(_lib.load().ggpm_decode_join(), what)
+    del _INFLIGHT[:]
 _PACK_ONCE = os.environ.get("GGPM_PACK_ONCE", "1") != "0"      # (0: every decode step packs its weights again; dev A/B)
 
 
@@ -628,12 +641,17 @@ class _AtomDecodeCompact(torch.autograd.Function):
             hw = ((Wz, I), (Ur, 0), (Wh, I))
         W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
         ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
+        deferred = False
         if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
             tmp = torch.empty(2 * max(plan.nloc), Hp, **f32)
-            _lib.check(lib.ggpm_decode_steps_forward(
+            fn = lib.ggpm_decode_steps_forward_async if _ASYNC else lib.ggpm_decode_steps_forward
+            _lib.check(fn(
                 ctypes.byref(desc), W_arr, ld_arr, None if lstm else P(bu), P(X_all), P(Hs_all), P(Cs_all) if lstm else None,
                 P(Qs_all), P(St_all), St_all.stride(0), P(wpack), P(tmp), s), "decode_steps_forward")
+            if _ASYNC:
+                deferred = True
+                _INFLIGHT.append((desc, _keep, X_all, Hs_all, Cs_all, Qs_all, St_all, wpack, tmp, params))
         for t in (() if _DRIVER else range(T)):
             n = plan.nloc[t]
             src = _vp(cp[("srcH", t)])
@@ -665,19 +683,33 @@ class _AtomDecodeCompact(torch.autograd.Function):
         pooled = torch.empty(n_inst, Hp, **f32)
         cand = torch.empty(max(plan.n_cand, 1), Hp, **f32)
         ldF, ldwo = F_._ld(fn_all), Wout.stride(0)
-        _lib.check(lib.ggpm_segment_sum(P(Hs_all), Hp, _vp(cp["agr_rp"]), _vp(cp["agr_col"]), ns_tot, H, P(NEI), Hp, 0, Hp, s),
-                   "segment_sum")
-        F_.gemm_ksegments(1, ns_tot, H, [fn_all, NEI], [ldF, Hp], [Wout, Wout[:, Fdim:]], [ldwo, ldwo], [Fdim, H], NODE, Hp,
-                          Hp, bias=bout, act=F_.ACT_RELU)
-        if drop is not None:
-            _lib.check(lib.ggpm_dropout(P(NODE), ns_tot, H, Hp, drop[0], drop[1], drop[2], 0, s), "dropout")
-        _lib.check(lib.ggpm_segment_sum(P(NODE), Hp, _vp(cp["pool_rp"]), _vp(cp["pool_col"]), n_inst, H, P(pooled), Hp, 0, Hp,
-                                        s), "segment_sum")
-        _lib.check(lib.ggpm_gather_rows(P(NODE), Hp, _vp(cp["cand_idx"]), max(plan.n_cand, 1), H, P(cand), Hp, 0, Hp, s),
-                   "gather_rows")
+        stream_obj = torch.cuda.current_stream(dev)
+
+        def readout():
+            s_ = F_._stream()
+            _lib.check(lib.ggpm_segment_sum(P(Hs_all), Hp, _vp(cp["agr_rp"]), _vp(cp["agr_col"]), ns_tot, H, P(NEI), Hp, 0, Hp, s_),
+                       "segment_sum")
+            F_.gemm_ksegments(1, ns_tot, H, [fn_all, NEI], [ldF, Hp], [Wout, Wout[:, Fdim:]], [ldwo, ldwo], [Fdim, H], NODE, Hp,
+                              Hp, bias=bout, act=F_.ACT_RELU)
+            if drop is not None:
+                _lib.check(lib.ggpm_dropout(P(NODE), ns_tot, H, Hp, drop[0], drop[1], drop[2], 0, s_), "dropout")
+            _lib.check(lib.ggpm_segment_sum(P(NODE), Hp, _vp(cp["pool_rp"]), _vp(cp["pool_col"]), n_inst, H, P(pooled), Hp, 0, Hp,
+                                            s_), "segment_sum")
+            _lib.check(lib.ggpm_gather_rows(P(NODE), Hp, _vp(cp["cand_idx"]), max(plan.n_cand, 1), H, P(cand), Hp, 0, Hp, s_),
+                       "gather_rows")
+
+        if deferred:        # the loop is still being issued by the worker: the read-out follows it after the join
+            def finish():
+                _join_worker("decode_join (forward)")
+                with torch.cuda.stream(stream_obj):
+                    readout()
+            _PENDING[id(plan)] = finish
+        else:
+            readout()
         ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
         ctx.save_for_backward(fn_all, hmess, NODE, NEI, X_all, Hs_all, Qs_all, St_all, *([Cs_all] if lstm else []), *params)
         ctx.keep = (D, ct, cp)
+        ctx.params_ref = params            # the Parameter objects themselves (the async backward assigns their .grad)
         return pooled, cand
 
     @staticmethod
@@ -736,6 +768,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
         wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         frz_loc = D["frozen_loc"].data_ptr()
+        params_ref = ctx.params_ref
+        go_async = (_DRIVER and _ASYNC and F_.can_publish(*params_ref) and all(ctx.needs_input_grad[9:]))
         if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             if lstm:
                 hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
@@ -746,10 +780,13 @@ class _AtomDecodeCompact(torch.autograd.Function):
             desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
             tmp = torch.empty(2 * nmax, Hp, **f32)
             dW_arr = (ctypes.c_void_p * 4)(*([a.data_ptr() for a in acc] + ([] if len(acc) == 4 else [0])))
-            _lib.check(lib.ggpm_decode_steps_backward(
+            fn = lib.ggpm_decode_steps_backward_async if go_async else lib.ggpm_decode_steps_backward
+            _lib.check(fn(
                 ctypes.byref(desc), W_arr, ld_arr, P(X_all), P(Hs_all), P(Cs_all) if lstm else None, P(Qs_all), P(St_all),
                 St_all.stride(0), P(dF), P(dCF) if lstm else None, P(dX_all), P(DG_all), DG_all.stride(0), P(DQ_all), dW_arr,
                 P(work), work.numel() * 4, P(tmp), s), "decode_steps_backward")
+            if go_async:
+                _INFLIGHT.append((desc, _keep, sv, dF, dCF, dX_all, DG_all, DQ_all, acc, work, tmp))
         for t in (() if _DRIVER else range(T - 1, -1, -1)):
             n = plan.nloc[t]
             dhd, dhin = dF[foff[t]:foff[t + 1]], torch.empty(n, Hp, **f32)
@@ -782,21 +819,42 @@ class _AtomDecodeCompact(torch.autograd.Function):
             # the frozen rows' gradient goes to the step that produced their state (rows recomputed here: none)
             _lib.check(lib.ggpm_scatter_rows(P(dhin), Hp, srcF, n, Hp, P(dF), Hp, 1, s), "scatter_rows")
         # ---- parameter gradients, once
-        dX_tot = torch.empty(G, E1, Hp, **f32)
-        _lib.check(lib.ggpm_segment_sum(P(dX_all), Hp, _vp(cp["xT_rp"]), _vp(cp["xT_col"]), G * E1, Hp, P(dX_tot), Hp, 0, 0, s),
-                   "segment_sum")
-        R, RQ = roff[-1], qoff[-1]
-        wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
-        ws = torch.empty((wsb + 3) // 4, **f32)
-        if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h; St_all[0] = S
-            _lib.check(lib.ggpm_lstm_weight_grads_stacked(
-                R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
-                H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s), "lstm_weight_grads_stacked")
-        else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
-            _lib.check(lib.ggpm_gru_weight_grads_stacked(
-                R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
-                H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s), "gru_weight_grads_stacked")
-        return (None,) * 9 + _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot)
+        def tail():
+            s_ = F_._stream()
+            dX_tot = torch.empty(G, E1, Hp, **f32)
+            _lib.check(lib.ggpm_segment_sum(P(dX_all), Hp, _vp(cp["xT_rp"]), _vp(cp["xT_col"]), G * E1, Hp, P(dX_tot), Hp, 0, 0, s_),
+                       "segment_sum")
+            R, RQ = roff[-1], qoff[-1]
+            wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
+            ws = torch.empty((wsb + 3) // 4, **f32)
+            if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h; St_all[0] = S
+                _lib.check(lib.ggpm_lstm_weight_grads_stacked(
+                    R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
+                    H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s_), "lstm_weight_grads_stacked")
+            else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
+                _lib.check(lib.ggpm_gru_weight_grads_stacked(
+                    R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
+                    H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s_), "gru_weight_grads_stacked")
+            return _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot)
+
+        if go_async:
+            # The loop is being issued by the worker; this node returns now so that the engine can issue the encoder's
+            # backward beside it.  At the end of the pass: join the worker, enqueue the tail behind the loop on the atom
+            # level's stream, hand the gradients to .grad on the stream the rest of the step consumes them on.
+            atom_stream = torch.cuda.current_stream(dev)
+
+            def finish():
+                _join_worker("decode_join (backward)")
+                main = torch.cuda.current_stream(dev)
+                with torch.cuda.stream(atom_stream):
+                    grads = tail()
+                main.wait_stream(atom_stream)
+                for prm, g in zip(params_ref, grads):
+                    g.record_stream(main)
+                    F_._add_to_grad(prm, g)
+            torch.autograd.Variable._execution_engine.queue_callback(finish)
+            return (None,) * (9 + len(params))
+        return (None,) * 9 + tail()
 
 
 def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot):
@@ -830,8 +888,12 @@ def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, 
     return tuple(grads)
 
 
-def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: torch.Tensor, fn_all: torch.Tensor):
-    """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``."""
+def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: torch.Tensor, fn_all: torch.Tensor,
+                defer_finish: bool = False):
+    """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``.
+    ``defer_finish``: -> (pooled, cand, finish); the caller calls ``finish()`` before it reads the two tensors or lets any
+    other stream wait on the current one (with GGPM_ATOM_ASYNC the step loop is still being issued by a worker thread
+    when this returns, and the read-out behind it is enqueued by ``finish``)."""
     from .rnn import LSTM
     rnn, wo = graph_encoder.rnn, graph_encoder.W_o
     lstm = isinstance(rnn, LSTM)
@@ -848,5 +910,11 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
     if fn is _AtomDecode and not plan.full:
         raise RuntimeError("this AtomPlan was built without the level-wide tables (GGPM_ATOM_COMPACT changed after the plan "
                            "was built?); build it with full=True")
-    return fn.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
-                    rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)
+    pooled, cand = fn.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
+                            rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)
+    finish = _PENDING.pop(id(plan), None)        # set when the step loop was handed to the library's worker thread
+    if defer_finish:
+        return pooled, cand, (finish or (lambda: None))
+    if finish is not None:
+        finish()
+    return pooled, cand

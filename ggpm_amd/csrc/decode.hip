@@ -9,6 +9,11 @@
 // order, from C++: ~25 launches per step and direction that Python + ctypes otherwise issue one by one (the full VAE step
 // is as long on the host as on the GPU).
 #include "common.h"
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace {
 
@@ -123,3 +128,102 @@ extern "C" int ggpm_decode_steps_backward(const ggpm_decode_steps* d, const floa
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
+
+
+// ---- issuing the step loops from a worker thread ------------------------------------------------------------------------
+// A step loop is ~280 launches = 1.5-1.8 ms of host time inside ONE call.  While the calling thread sits in it, nothing else
+// of the training step can be issued: in the backward pass the autograd engine reaches the atom level's node and the
+// encoder's node at about the same time, and whichever it takes second starts that much later on the GPU although the two
+// chains do not depend on each other ("the two chains have to be ISSUED side by side").  The _async
+// forms hand the loop to a thread of the library and return at once; ggpm_decode_join waits until that thread has issued
+// everything (it does not wait for the GPU).  The caller keeps every buffer and the descriptor alive until then and
+// enqueues what follows the loop on the same stream only after the join.  One worker, jobs in order.
+namespace {
+
+class DecodeWorker {
+public:
+    static DecodeWorker& get() { static DecodeWorker w; return w; }
+    void post(int dev, std::function<int()> job) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back({dev, std::move(job)}); }
+        cv_.notify_one();
+    }
+    int join() {
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_.wait(lk, [&] { return q_.empty() && !busy_; });
+        const int e = err_;
+        err_ = GGPM_OK;
+        return e;
+    }
+
+private:
+    DecodeWorker() : th_([this] { run(); }) {}
+    ~DecodeWorker() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_one();
+        if (th_.joinable()) th_.join();
+    }
+    void run() {
+        int dev = -1;
+        for (;;) {
+            std::pair<int, std::function<int()>> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+                busy_ = true;
+            }
+            if (job.first != dev && job.first >= 0) { (void)hipSetDevice(job.first); dev = job.first; }
+            int rc = job.second();
+            if (!rc && hipGetLastError() != hipSuccess) rc = GGPM_ERR_LAUNCH;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (rc && !err_) err_ = rc;
+                busy_ = false;
+                if (q_.empty()) idle_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, idle_;
+    std::deque<std::pair<int, std::function<int()>>> q_;
+    bool busy_ = false, stop_ = false;
+    int err_ = GGPM_OK;
+    std::thread th_;
+};
+
+inline int current_device() { int d = -1; (void)hipGetDevice(&d); return d; }
+
+}  // namespace
+
+extern "C" int ggpm_decode_steps_forward_async(const ggpm_decode_steps* d, const float* const* W, const int* ldw, const float* bu,
+                                               const float* X_all, float* Hs_all, float* Cs_all, float* Qs_all, float* St_all,
+                                               size_t st_stride, float* wpack, float* tmp, ggpm_stream_t stream) {
+    if (!d || !W || !ldw) return GGPM_ERR_ARG;
+    const float* Wc[4] = {W[0], W[1], W[2], W[3]};
+    const int lc[4] = {ldw[0], ldw[1], ldw[2], ldw[3]};
+    DecodeWorker::get().post(current_device(), [=]() -> int {
+        return ggpm_decode_steps_forward(d, Wc, lc, bu, X_all, Hs_all, Cs_all, Qs_all, St_all, st_stride, wpack, tmp, stream);
+    });
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_decode_steps_backward_async(const ggpm_decode_steps* d, const float* const* W, const int* ldw,
+                                                const float* X_all, const float* Hs_all, const float* Cs_all,
+                                                const float* Qs_all, const float* St_all, size_t st_stride, float* dF,
+                                                float* dCF, float* dX_all, float* DG_all, size_t dg_stride, float* DQ_all,
+                                                float* const* dW_unused, float* work, size_t work_bytes, float* tmp,
+                                                ggpm_stream_t stream) {
+    if (!d || !W || !ldw || !dW_unused) return GGPM_ERR_ARG;
+    const float* Wc[4] = {W[0], W[1], W[2], W[3]};
+    const int lc[4] = {ldw[0], ldw[1], ldw[2], ldw[3]};
+    float* dWc[4] = {dW_unused[0], dW_unused[1], dW_unused[2], dW_unused[3]};
+    DecodeWorker::get().post(current_device(), [=]() -> int {
+        return ggpm_decode_steps_backward(d, Wc, lc, X_all, Hs_all, Cs_all, Qs_all, St_all, st_stride, dF, dCF, dX_all, DG_all,
+                                          dg_stride, DQ_all, dWc, work, work_bytes, tmp, stream);
+    });
+    return GGPM_OK;
+}
+
+extern "C" int ggpm_decode_join(void) { return DecodeWorker::get().join(); }

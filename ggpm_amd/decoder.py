@@ -581,19 +581,19 @@ class HierMPNDecoder(ScoreHeads):
             side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
-        self._atom_ahead = (schedule, pooled_all, cand, side)
+            pooled_all, cand, _, finish = self._atom_level(schedule, D, graph_tensors, defer_finish=True)
+        self._atom_ahead = (schedule, pooled_all, cand, side, finish)
         return True
 
-    def _atom_level(self, schedule, D, graph_tensors):
-        """(pooled cluster vectors of all visits, attachment-candidate atom vectors, plan) through atom_decode."""
+    def _atom_level(self, schedule, D, graph_tensors, defer_finish: bool = False):
+        """(pooled cluster vectors of all visits, attachment-candidate atom vectors, plan[, finish]) through atom_decode."""
         from .atom_decode import atom_decode
         hmpn, T = self.hmpn, D["plan"]
         graph_emb = hmpn.embed_graph(graph_tensors)
         fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
         ap = schedule.atom_plan(graph_tensors[0].size(0), graph_tensors[1].size(0))
-        pooled_all, cand = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all)
-        return pooled_all, cand, ap
+        out = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all, defer_finish=defer_finish)
+        return (out[0], out[1], ap) + tuple(out[2:])
 
     def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
         """Same vectors as ``_states_stepwise`` with the two tree-side levels de-sequentialised: only the atom level
@@ -612,11 +612,14 @@ class HierMPNDecoder(ScoreHeads):
         ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if os.environ.get("GGPM_ATOM_DECODE", "1") != "0" else None
         if ap is not None and ap.ok:                        # ---- atom level as ONE autograd node (atom_decode.py)
             if ahead is not None and ahead[0] is schedule:  # issued before the encoder on its own stream: join it here
-                _, pooled_all, cand, side = ahead
+                _, pooled_all, cand, side, finish = ahead
+                finish()                                    # (worker-issued step loop: join it, enqueue the read-out behind it)
                 main = torch.cuda.current_stream(dev)
                 main.wait_stream(side)
                 pooled_all.record_stream(main); cand.record_stream(main)
             else:
+                if ahead is not None:
+                    ahead[4]()                              # (a stale ahead run of another schedule: let its loop drain)
                 pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
             meta = ap.to_device(dev)["meta"]
             for k, base, n in ap.cand_blocks:

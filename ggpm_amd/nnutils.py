@@ -77,6 +77,24 @@ def make_cuda(tensors):
     tensor (``ggpm_chain``), which lets the encoder stop the tree-side levels at their fixed point."""
     tree_tensors, graph_tensors = tensors
     chain = tree_chain_length(tree_tensors[3]) if len(tree_tensors) > 4 else 0
+    host = lambda x: isinstance(x, np.ndarray) or (isinstance(x, torch.Tensor) and not x.is_cuda)
+    if is_cuda and len(tree_tensors) == 6 and len(graph_tensors) == 5 and all(host(x) for x in list(tree_tensors[:5]) + list(graph_tensors[:4])):
+        # a batch as the loader delivers it (host arrays, vae_train.py:78): the nine index arrays packed into ONE int64
+        # buffer, one asynchronous copy through the pinned staging ring, device views -- instead of nine blocking
+        # pageable copies and as many int32 -> int64 conversion launches
+        from . import functional as F_
+        from .dataloader import batch_layout, pack_into, unpack_views
+        arrays, layout, total = batch_layout(tensors)
+        B = len(tree_tensors[-1])
+        flat = np.zeros(total + (B + 1) // 2, dtype=np.int64)
+        pack_into(flat, arrays, layout)
+        flat.view(np.int32)[2 * total:2 * total + B] = [st for st, _ in tree_tensors[-1]]      # root node ids, int32
+        dev = F_.upload(flat, current_device())
+        tree_tensors, graph_tensors = unpack_views(dev, layout, tree_tensors[-1], graph_tensors[-1])
+        if chain:
+            attach_hint(tree_tensors[3], "ggpm_chain", chain)
+        attach_hint(tree_tensors[0], "ggpm_roots", dev.view(torch.int32)[2 * total:2 * total + B])
+        return tree_tensors, graph_tensors
     tree_tensors = [make_tensor(x).long() for x in tree_tensors[:-1]] + [tree_tensors[-1]]
     graph_tensors = [make_tensor(x).long() for x in graph_tensors[:-1]] + [graph_tensors[-1]]
     if chain and isinstance(tree_tensors[3], torch.Tensor):

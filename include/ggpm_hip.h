@@ -347,6 +347,20 @@ int ggpm_decode_steps_backward(const ggpm_decode_steps* steps, const float* cons
                                size_t st_stride, float* dF, float* dCF, float* dX_all, float* DG_all, size_t dg_stride,
                                float* DQ_all, float* const* dW_unused, float* work, size_t work_bytes, float* tmp,
                                ggpm_stream_t stream);
+/* The same two loops ISSUED by a worker thread of the library: the call returns at once, ggpm_decode_join() waits until
+ * the worker has issued everything posted so far (not for the GPU) and returns its first error.  Until then the caller
+ * keeps the descriptor, the arrays it points to and every buffer alive, and enqueues what follows the loop on `stream`
+ * only after the join.  Lets the ~1.5 ms of host time a loop takes run beside the calling thread's other launches (the
+ * encoder's backward, which autograd reaches at the same moment). */
+int ggpm_decode_steps_forward_async(const ggpm_decode_steps* steps, const float* const* W, const int* ldw, const float* bu,
+                                    const float* X_all, float* Hs_all, float* Cs_all, float* Qs_all, float* St_all,
+                                    size_t st_stride, float* wpack, float* tmp, ggpm_stream_t stream);
+int ggpm_decode_steps_backward_async(const ggpm_decode_steps* steps, const float* const* W, const int* ldw, const float* X_all,
+                                     const float* Hs_all, const float* Cs_all, const float* Qs_all, const float* St_all,
+                                     size_t st_stride, float* dF, float* dCF, float* dX_all, float* DG_all, size_t dg_stride,
+                                     float* DQ_all, float* const* dW_unused, float* work, size_t work_bytes, float* tmp,
+                                     ggpm_stream_t stream);
+int ggpm_decode_join(void);
 
 /* ------------------------------------------------------------------ decoder score-head losses
  * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in
