@@ -603,7 +603,11 @@ class _AtomDecodeCompact(torch.autograd.Function):
     once over the stacked stashes."""
 
     @staticmethod
-    def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, *params):
+    def launch(plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, params) -> dict:
+        """Everything the forward computes, issued now (no autograd node): -> state for ``forward(..., state, *params)``.
+        ``HierMPNDecoder.start_atom_level`` calls this BEFORE the encoder runs and creates the node later, behind the
+        encoder's: the engine then reaches this node first in the backward pass and -- its loop being issued by the worker
+        thread -- goes straight on to the encoder's backward, so that the longer chain starts first."""
         lib = _lib.load()
         dev = hmess.device
         D = plan.to_device(dev)
@@ -698,19 +702,28 @@ class _AtomDecodeCompact(torch.autograd.Function):
             _lib.check(lib.ggpm_gather_rows(P(NODE), Hp, _vp(cp["cand_idx"]), max(plan.n_cand, 1), H, P(cand), Hp, 0, Hp, s_),
                        "gather_rows")
 
+        finish = None
         if deferred:        # the loop is still being issued by the worker: the read-out follows it after the join
             def finish():
                 _join_worker("decode_join (forward)")
                 with torch.cuda.stream(stream_obj):
                     readout()
-            _PENDING[id(plan)] = finish
         else:
             readout()
+        return dict(pooled=pooled, cand=cand, finish=finish, keep=(D, ct, cp), lstm=lstm,
+                    saved=(fn_all, hmess, NODE, NEI, X_all, Hs_all, Qs_all, St_all) + ((Cs_all,) if lstm else ()))
+
+    @staticmethod
+    def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, state, *params):
+        if state is None:
+            state = _AtomDecodeCompact.launch(plan, cell, depth, H, Fdim, I, fn_all, hmess, drop, params)
+            if state["finish"] is not None:
+                _PENDING[id(plan)] = state["finish"]
         ctx.plan, ctx.meta, ctx.drop = plan, (cell, depth, H, Fdim, I), drop
-        ctx.save_for_backward(fn_all, hmess, NODE, NEI, X_all, Hs_all, Qs_all, St_all, *([Cs_all] if lstm else []), *params)
-        ctx.keep = (D, ct, cp)
+        ctx.save_for_backward(*state["saved"], *params)
+        ctx.keep = state["keep"]
         ctx.params_ref = params            # the Parameter objects themselves (the async backward assigns their .grad)
-        return pooled, cand
+        return state["pooled"], state["cand"]
 
     @staticmethod
     def backward(ctx, d_pooled, d_cand):
@@ -769,7 +782,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
         work = torch.empty((wb + 3) // 4, **f32)
         frz_loc = D["frozen_loc"].data_ptr()
         params_ref = ctx.params_ref
-        go_async = (_DRIVER and _ASYNC and F_.can_publish(*params_ref) and all(ctx.needs_input_grad[9:]))
+        go_async = (_DRIVER and _ASYNC and F_.can_publish(*params_ref) and all(ctx.needs_input_grad[10:]))
         if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             if lstm:
                 hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
@@ -853,8 +866,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
                     g.record_stream(main)
                     F_._add_to_grad(prm, g)
             torch.autograd.Variable._execution_engine.queue_callback(finish)
-            return (None,) * (9 + len(params))
-        return (None,) * 9 + tail()
+            return (None,) * (10 + len(params))
+        return (None,) * 10 + tail()
 
 
 def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot):
@@ -888,8 +901,18 @@ def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, 
     return tuple(grads)
 
 
+def atom_decode_node(pre: dict):
+    """The autograd node of a prelaunched atom level (``atom_decode(..., prelaunch=True)``), created where the decoder
+    joins it: -> (pooled, cand).  Joins the worker and enqueues the read-out first."""
+    fin = pre["state"]["finish"]
+    if fin is not None:
+        fin()
+        pre["state"]["finish"] = None
+    return _AtomDecodeCompact.apply(*pre["args"], pre["state"], *pre["params"])
+
+
 def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: torch.Tensor, fn_all: torch.Tensor,
-                defer_finish: bool = False):
+                defer_finish: bool = False, prelaunch: bool = False):
     """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``.
     ``defer_finish``: -> (pooled, cand, finish); the caller calls ``finish()`` before it reads the two tensors or lets any
     other stream wait on the current one (with GGPM_ATOM_ASYNC the step loop is still being issued by a worker thread
@@ -910,8 +933,14 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
     if fn is _AtomDecode and not plan.full:
         raise RuntimeError("this AtomPlan was built without the level-wide tables (GGPM_ATOM_COMPACT changed after the plan "
                            "was built?); build it with full=True")
-    pooled, cand = fn.apply(plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim,
-                            rnn.input_size, fn_all, hmess_a, drop, *params, wo[0].weight, wo[0].bias)
+    args = (plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim, rnn.input_size, fn_all,
+            hmess_a, drop)
+    params = params + (wo[0].weight, wo[0].bias)
+    if prelaunch:           # issue now, create the autograd node later (atom_decode_node)
+        assert fn is _AtomDecodeCompact
+        with torch.no_grad():
+            return dict(args=args, params=params, state=fn.launch(*args, params))
+    pooled, cand = fn.apply(*args, *params) if fn is _AtomDecode else fn.apply(*args, None, *params)
     finish = _PENDING.pop(id(plan), None)        # set when the step loop was handed to the library's worker thread
     if defer_finish:
         return pooled, cand, (finish or (lambda: None))

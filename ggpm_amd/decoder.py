@@ -580,19 +580,28 @@ class HierMPNDecoder(ScoreHeads):
         if side is None:
             side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)
+        from .atom_decode import compact_enabled
         with torch.cuda.stream(side):
-            pooled_all, cand, _, finish = self._atom_level(schedule, D, graph_tensors, defer_finish=True)
-        self._atom_ahead = (schedule, pooled_all, cand, side, finish)
+            if compact_enabled():       # issued now; its autograd node is created at the join, behind the encoder's
+                pre = self._atom_level(schedule, D, graph_tensors, prelaunch=True)
+                self._atom_ahead = (schedule, None, None, side, None, pre)
+            else:
+                pooled_all, cand, _, finish = self._atom_level(schedule, D, graph_tensors, defer_finish=True)
+                self._atom_ahead = (schedule, pooled_all, cand, side, finish, None)
         return True
 
-    def _atom_level(self, schedule, D, graph_tensors, defer_finish: bool = False):
-        """(pooled cluster vectors of all visits, attachment-candidate atom vectors, plan[, finish]) through atom_decode."""
+    def _atom_level(self, schedule, D, graph_tensors, defer_finish: bool = False, prelaunch: bool = False):
+        """(pooled cluster vectors of all visits, attachment-candidate atom vectors, plan[, finish]) through atom_decode;
+        ``prelaunch``: -> the state ``atom_decode_node`` turns into the autograd node later."""
         from .atom_decode import atom_decode
         hmpn, T = self.hmpn, D["plan"]
         graph_emb = hmpn.embed_graph(graph_tensors)
         fnode_all = graph_emb[0].index_select(0, T["atoms_all"])
         ap = schedule.atom_plan(graph_tensors[0].size(0), graph_tensors[1].size(0))
-        out = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all, defer_finish=defer_finish)
+        out = atom_decode(ap, hmpn.graph_encoder, graph_emb[0], graph_emb[1], fnode_all, defer_finish=defer_finish,
+                          prelaunch=prelaunch)
+        if prelaunch:
+            return out
         return (out[0], out[1], ap) + tuple(out[2:])
 
     def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
@@ -612,14 +621,21 @@ class HierMPNDecoder(ScoreHeads):
         ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if os.environ.get("GGPM_ATOM_DECODE", "1") != "0" else None
         if ap is not None and ap.ok:                        # ---- atom level as ONE autograd node (atom_decode.py)
             if ahead is not None and ahead[0] is schedule:  # issued before the encoder on its own stream: join it here
-                _, pooled_all, cand, side, finish = ahead
-                finish()                                    # (worker-issued step loop: join it, enqueue the read-out behind it)
+                _, pooled_all, cand, side, finish, pre = ahead
+                if pre is not None:                         # prelaunched: join the worker, read-out, autograd node NOW (on
+                    from .atom_decode import atom_decode_node          # the level's stream: its backward runs there)
+                    with torch.cuda.stream(side):
+                        pooled_all, cand = atom_decode_node(pre)
+                else:
+                    finish()                                # (worker-issued step loop: join it, enqueue the read-out behind it)
                 main = torch.cuda.current_stream(dev)
                 main.wait_stream(side)
                 pooled_all.record_stream(main); cand.record_stream(main)
             else:
-                if ahead is not None:
-                    ahead[4]()                              # (a stale ahead run of another schedule: let its loop drain)
+                if ahead is not None:                       # (a stale ahead run of another schedule: let its loop drain)
+                    stale = ahead[4] if ahead[5] is None else ahead[5]["state"]["finish"]
+                    if stale is not None:
+                        stale()
                 pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
             meta = ap.to_device(dev)["meta"]
             for k, base, n in ap.cand_blocks:

@@ -39,7 +39,7 @@ torch.cuda.synchronize()
 bench._settle_gc()
 rows = []
 for i in range(16):
-    _, dev_tensors, sch = wl.items[i % len(wl.items)]
+    _, dev_tensors, sch, _ = wl.items[i % len(wl.items)]
     wl.opt.zero_grad(set_to_none=True)
     f0 = torch.cuda.Event(enable_timing=True); f0.record()
     loss, metrics = wl.model(None, None, dev_tensors, wl.orders, None, None, beta=0.1, perturb_z=True, schedule=sch)
