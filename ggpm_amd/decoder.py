@@ -578,7 +578,10 @@ class HierMPNDecoder(ScoreHeads):
         main = torch.cuda.current_stream(dev)
         side = self._ATOM_STREAMS.get(dev.index)
         if side is None:
-            side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+            # high priority: this chain of small dependent launches is the step's critical path, the encoder beside it
+            # has slack -- where both have a kernel waiting for CUs, this one goes first (GGPM_ATOM_PRIORITY=0: default)
+            prio = -1 if os.environ.get("GGPM_ATOM_PRIORITY", "1") != "0" else 0
+            side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=prio)
         side.wait_stream(main)
         from .atom_decode import compact_enabled
         with torch.cuda.stream(side):
