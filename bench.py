@@ -438,8 +438,15 @@ class VaeWorkload:
             sch = DecodeSchedule.from_graphs(batch6[1], tensors, batch6[3], self.vocab, **hints)
             self.items.append((tensors, make_cuda(tensors), sch.to_device(dev), batch6))
         broadcast_parameters(self.model)
-        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder) if world > 1 else None
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        # Adam (vae_train.py:60) on one flat view of the parameters, gradients in the flat buffer the all-reduce uses anyway
+        # and the encoder's backward writes into directly (GGPM_FLAT_ADAM=0: torch.optim.Adam over the parameter list)
+        if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
+            from ggpm_amd.optim import FlatAdam
+            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
+            self.opt = FlatAdam(self.sync, lr=1e-3)
+        else:
+            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder) if world > 1 else None
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
         self.orders = [None] * cfg["batch"]
 
     def _finish(self, loss, metrics):

@@ -84,8 +84,13 @@ namespace {
 #define GGPM_GATHER_U 2            // predecessor rows gathered per trip of the forward gather (null slots read row 0;
                                    // 4 per trip measured equal on the atom level, 1.3 us slower on the tree levels)
 #endif
-constexpr int RT = 1;              // row tiles (of 16 messages) per workgroup
+constexpr int RT = 1;              // row tiles (of 16 messages) per workgroup (default; the kernels take it as RTT)
 constexpr int ROWS = RT * 16;
+// RTT = 2 (32 message rows per workgroup): every weight fragment a wave streams from L2 then feeds TWO row tiles, which
+// halves the weight stream of a level -- at H = 600 with ~950 row tiles (configs[4]) every workgroup reads all 3 Hp^2 packed
+// weights per launch, 4.2 GB in total, and that stream, not the matrix pipe, bounds the launch.  Two tiles of 32 rows
+// fill the LDS, so there is no room for the fused q' / dS,dG phase: those levels use the B launches.
+constexpr int GGPM_RT2_MIN_ROW_TILES = 512;
 
 struct GruFwdArgs {
     int E1, Hp, tg;                // tg: output tiles per column group of kernel A
@@ -117,8 +122,9 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time (full Hp width: two 256-column sweeps
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
-template <bool STASH, bool BF16>
+template <bool STASH, bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;
@@ -209,67 +215,85 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
-    const int lr = lane & 15, row = r0 + lr;
+    const int lr = lane & 15;
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        const float4 xz = ggpm_ld4(a.Xz + o);      // in flight under the GEMM
-        const float4 xh = ggpm_ld4(a.Xh + o);
-        f32x4 acc[2][RT];
-        ggpm_zero_acc<2, RT>(acc);
+        float4 xz[RTT], xh[RTT];
+        auto load_inputs = [&]() {
+#pragma unroll
+            for (int r = 0; r < RTT; ++r) {
+                const int row = r0 + 16 * r + lr;
+                const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+                xz[r] = ggpm_ld4(a.Xz + o);
+                xh[r] = ggpm_ld4(a.Xh + o);
+            }
+        };
+        if constexpr (RTT == 1) load_inputs();      // in flight under the GEMM (two row tiles: the registers go to the GEMM)
+        f32x4 acc[2][RTT];
+        ggpm_zero_acc<2, RTT>(acc);
         if (p2_gemm) {
             const float* const tiles[2] = {Ts, Tg};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
+        if constexpr (RTT != 1) load_inputs();
         if (dbg_on) a.dbg[3] = wall_clock64();
-        float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
-        if (row >= a.E1) {
-            if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, h);
-            continue;
-        }
-        if (a.frozen && a.frozen[row]) {
-            h = ggpm_ld4(a.Hprev + o);             // z = m = 0 in the stash => the backward passes dh through
-        } else if (row != 0 || a.frozen) {
-            const float4 s = ggpm_ld4(Ts + lr * LD + c);
-            const float4 pz = ggpm_f4(acc[0][0]) + xz, pm = ggpm_f4(acc[1][0]) + xh;
-            z = ggpm_sigmoid4(pz);
-            m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
-            h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
-                            (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
-        }
-        ggpm_st4(a.Hnew + o, h);
-        if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, h);
-        if (STASH) {
-            ggpm_st4(a.Z + o, z);
-            ggpm_st4(a.M + o, m);
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            const int lrow = 16 * r + lr, row = r0 + lrow;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
+            if (row >= a.E1) {
+                if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, h);
+                continue;
+            }
+            if (a.frozen && a.frozen[row]) {
+                h = ggpm_ld4(a.Hprev + o);             // z = m = 0 in the stash => the backward passes dh through
+            } else if (row != 0 || a.frozen) {
+                const float4 s = ggpm_ld4(Ts + lrow * LD + c);
+                const float4 pz = ggpm_f4(acc[0][r]) + xz[r], pm = ggpm_f4(acc[1][r]) + xh[r];
+                z = ggpm_sigmoid4(pz);
+                m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
+                h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
+                                (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
+            }
+            ggpm_st4(a.Hnew + o, h);
+            if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, h);
+            if (STASH) {
+                ggpm_st4(a.Z + o, z);
+                ggpm_st4(a.M + o, m);
+            }
         }
     }
     if (dbg_on) a.dbg[4] = wall_clock64();
     if (!a.fuse_b) return;
 
-    // ---- P3 (single column group only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
-    const float* const wps3[1] = {a.Ur};
-    GgpmRing<1> ring3;
-    if constexpr (!BF16)
-        if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
-    ggpm_lds_barrier();
-    const float* Th = lds + 2 * ROWS * LD;
-    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
-        const int c = 16 * tt + 4 * (lane >> 4);
-        const float4 b = ggpm_ld4(a.bu + c);
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
-        const float* const tiles[1] = {Th};
-        if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
-        else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
-        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+    // ---- P3 (single column group, RTT = 1 only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
+    if constexpr (RTT == 1) {
+        const int row = r0 + lr;
+        const float* const wps3[1] = {a.Ur};
+        GgpmRing<1> ring3;
+        if constexpr (!BF16)
+            if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+        ggpm_lds_barrier();
+        const float* Th = lds + 2 * ROWS * LD;
+        for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+            const int c = 16 * tt + 4 * (lane >> 4);
+            const float4 b = ggpm_ld4(a.bu + c);
+            f32x4 acc[1][1];
+            ggpm_zero_acc<1, 1>(acc);
+            const float* const tiles[1] = {Th};
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+        }
     }
 }
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
@@ -284,18 +308,21 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
     ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
-    const int row = r0 + (lane & 15);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         const float4 b = ggpm_ld4(a.bu + c);
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
+        f32x4 acc[1][RTT];
+        ggpm_zero_acc<1, RTT>(acc);
         if (!(a.ablate & 2)) {
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
-        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            const int row = r0 + 16 * r + (lane & 15);
+            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][r]) + b);
+        }
     }
 }
 
@@ -328,8 +355,9 @@ struct GruBwdArgs {
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
 // gate derivatives for this workgroup's column group.
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T0 = lds;                  // dh partial
@@ -412,108 +440,126 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     if (dbg_on) a.dbg[2] = wall_clock64();
 
     // ---- P2: dh = partial + dq . U_r ; gate derivatives, for this wave's tiles
-    const int lr = lane & 15, row = r0 + lr;
-    float4 dsd_keep[2] = {ggpm_zero4(), ggpm_zero4()};      // fused P3: ds_dir of this wave's (at most two) tiles
+    const int lr = lane & 15;
+    float4 dsd_keep[2] = {ggpm_zero4(), ggpm_zero4()};      // fused P3 (RTT = 1): ds_dir of this wave's (at most two) tiles
     int it = 0;
     for (int tt = t; tt < t_end; tt += GGPM_NWA, ++it) {
         const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        float4 s = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4(), oxz = ggpm_zero4(), oxh = ggpm_zero4();
-        if (!a.final_pass) {
-            s = ggpm_ld4(a.S + o); z = ggpm_ld4(a.Z + o); m = ggpm_ld4(a.M + o);
-            if (!a.first) { oxz = ggpm_ld4(a.dXz + o); oxh = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
-        }
-        const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
+        float4 s[RTT], z[RTT], m[RTT], oxz[RTT], oxh[RTT], dhd[RTT];
+        auto load_inputs = [&]() {
+#pragma unroll
+            for (int r = 0; r < RTT; ++r) {
+                const int row = r0 + 16 * r + lr;
+                const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+                s[r] = z[r] = m[r] = oxz[r] = oxh[r] = ggpm_zero4();
+                if (!a.final_pass) {
+                    s[r] = ggpm_ld4(a.S + o); z[r] = ggpm_ld4(a.Z + o); m[r] = ggpm_ld4(a.M + o);
+                    if (!a.first) { oxz[r] = ggpm_ld4(a.dXz + o); oxh[r] = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
+                }
+                dhd[r] = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+            }
+        };
+        if constexpr (RTT == 1) load_inputs();      // in flight under the GEMM (two row tiles: the registers go to the GEMM)
+        f32x4 acc[1][RTT];
+        ggpm_zero_acc<1, RTT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
+        if constexpr (RTT != 1) load_inputs();
         if (dbg_on) a.dbg[3] = wall_clock64();
-        if (row >= a.E1) {
-            if (a.fuse_b) {
-                ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, ggpm_zero4());
-                ggpm_st4(lds + 3 * ROWS * LD + lr * LD + c, ggpm_zero4());
-            }
-            continue;
-        }
-        const bool frz = a.frozen && a.frozen[row];
-        if (a.final_pass) {        // gradient of the incoming state: frozen rows only (active rows started from 0)
-            float4 dh0 = ggpm_zero4();
-            if (frz) dh0 = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c) + ggpm_ld4(a.carry + o);
-            ggpm_st4(a.dHin + o, dh0);
-            continue;
-        }
-        float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
-        if (row != 0 || a.frozen) {
-            float4 dh = a.first ? dhd : (ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c));
-            if (frz) {             // h_t = h_{t-1} for frozen rows: carry the whole dh to the previous depth
-                if (!a.first) dh = dh + ggpm_ld4(a.carry + o);      // (the first backward depth starts the carry: no memset)
-                ggpm_st4(a.carry + o, dh);
-                dh = ggpm_zero4();   // nothing flows through gates (their stash is 0 anyway)
-            }
-            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s.x, s.y, s.z, s.w};
-            const float zv[4] = {z.x, z.y, z.z, z.w}, mv[4] = {m.x, m.y, m.z, m.w};
-            float o_ds[4], o_dz[4], o_dm[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o_ds[k] = dhv[k] * (1.f - zv[k]);
-                o_dz[k] = dhv[k] * (mv[k] - sv[k]) * zv[k] * (1.f - zv[k]);
-                o_dm[k] = dhv[k] * zv[k] * (1.f - mv[k] * mv[k]);
+        for (int r = 0; r < RTT; ++r) {
+            const int lrow = 16 * r + lr, row = r0 + lrow;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            if (row >= a.E1) {
+                if (a.fuse_b) {
+                    ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, ggpm_zero4());
+                    ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, ggpm_zero4());
+                }
+                continue;
             }
-            dsdir = make_float4(o_ds[0], o_ds[1], o_ds[2], o_ds[3]);
-            dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
-            dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
-        }
-        ggpm_st4(a.DZP + o, dzp);
-        ggpm_st4(a.DMP + o, dmp);
-        ggpm_st4(a.dXz + o, oxz + dzp);
-        ggpm_st4(a.dXh + o, oxh + dmp);
-        if (a.fuse_b) {
-            ggpm_st4(lds + 2 * ROWS * LD + lr * LD + c, dzp);
-            ggpm_st4(lds + 3 * ROWS * LD + lr * LD + c, dmp);
-            if (it == 0) dsd_keep[0] = dsdir; else dsd_keep[1] = dsdir;
-        } else {
-            ggpm_st4(a.DSD + o, dsdir);
+            const bool frz = a.frozen && a.frozen[row];
+            if (a.final_pass) {        // gradient of the incoming state: frozen rows only (active rows started from 0)
+                float4 dh0 = ggpm_zero4();
+                if (frz) dh0 = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c) + ggpm_ld4(a.carry + o);
+                ggpm_st4(a.dHin + o, dh0);
+                continue;
+            }
+            float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
+            if (row != 0 || a.frozen) {
+                float4 dh = a.first ? dhd[r] : (ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c));
+                if (frz) {             // h_t = h_{t-1} for frozen rows: carry the whole dh to the previous depth
+                    if (!a.first) dh = dh + ggpm_ld4(a.carry + o);      // (the first backward depth starts the carry: no memset)
+                    ggpm_st4(a.carry + o, dh);
+                    dh = ggpm_zero4();   // nothing flows through gates (their stash is 0 anyway)
+                }
+                const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, sv[4] = {s[r].x, s[r].y, s[r].z, s[r].w};
+                const float zv[4] = {z[r].x, z[r].y, z[r].z, z[r].w}, mv[4] = {m[r].x, m[r].y, m[r].z, m[r].w};
+                float o_ds[4], o_dz[4], o_dm[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o_ds[k] = dhv[k] * (1.f - zv[k]);
+                    o_dz[k] = dhv[k] * (mv[k] - sv[k]) * zv[k] * (1.f - zv[k]);
+                    o_dm[k] = dhv[k] * zv[k] * (1.f - mv[k] * mv[k]);
+                }
+                dsdir = make_float4(o_ds[0], o_ds[1], o_ds[2], o_ds[3]);
+                dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
+                dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
+            }
+            ggpm_st4(a.DZP + o, dzp);
+            ggpm_st4(a.DMP + o, dmp);
+            ggpm_st4(a.dXz + o, oxz[r] + dzp);
+            ggpm_st4(a.dXh + o, oxh[r] + dmp);
+            if (a.fuse_b) {
+                ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, dzp);
+                ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, dmp);
+                if (it == 0) dsd_keep[0] = dsdir; else dsd_keep[1] = dsdir;
+            } else {
+                ggpm_st4(a.DSD + o, dsdir);
+            }
         }
     }
     if (dbg_on) a.dbg[4] = wall_clock64();
     if (!a.fuse_b) return;
 
-    // ---- P3 (single column group only): the workgroup holds the complete dz_pre / dm_pre rows ->
+    // ---- P3 (single column group, RTT = 1 only): the workgroup holds the complete dz_pre / dm_pre rows ->
     // dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h ; dXr += dG * R   (the body of kernel B)
-    const float* const wps3[2] = {a.WhT, a.WzT};
-    GgpmRing<2> ring3;
-    if constexpr (!BF16)
-        if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
-    ggpm_lds_barrier();
-    it = 0;
-    for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
-        const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        const float4 dsd = it == 0 ? dsd_keep[0] : dsd_keep[1];
-        const float4 rco = ggpm_ld4(a.R + o), oxr = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
-        f32x4 acc[2][RT];
-        ggpm_zero_acc<2, RT>(acc);
-        {
-            const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+    if constexpr (RTT == 1) {
+        const int row = r0 + lr;
+        const float* const wps3[2] = {a.WhT, a.WzT};
+        GgpmRing<2> ring3;
+        if constexpr (!BF16)
+            if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
+        ggpm_lds_barrier();
+        it = 0;
+        for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
+            const int c = 16 * tt + 4 * (lane >> 4);
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            const float4 dsd = it == 0 ? dsd_keep[0] : dsd_keep[1];
+            const float4 rco = ggpm_ld4(a.R + o), oxr = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
+            f32x4 acc[2][1];
+            ggpm_zero_acc<2, 1>(acc);
+            {
+                const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
+                if constexpr (BF16) ggpm_wave_gemm_bf16<2, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+                else ggpm_wave_gemm_ring<2, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            }
+            if (row >= a.E1) continue;
+            const float4 dg = ggpm_f4(acc[0][0]);
+            ggpm_st4(a.dGout + o, dg);
+            ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
+            ggpm_st4(a.dXr + o, oxr + dg * rco);
         }
-        if (row >= a.E1) continue;
-        const float4 dg = ggpm_f4(acc[0][0]);
-        ggpm_st4(a.dGout + o, dg);
-        ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
-        ggpm_st4(a.dXr + o, oxr + dg * rco);
     }
 }
 
 // Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T1 = lds;                  // dz_pre rows
@@ -530,24 +576,37 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
     ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
     __syncthreads();
-    const int e = r0 + (lane & 15);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
-        const float4 dsd = ggpm_ld4(a.DSD + o), rco = ggpm_ld4(a.R + o);
-        const float4 oxr = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
-        f32x4 acc[2][RT];
-        ggpm_zero_acc<2, RT>(acc);
+        float4 dsd[RTT], rco[RTT], oxr[RTT];
+        auto load_inputs = [&]() {
+#pragma unroll
+            for (int r = 0; r < RTT; ++r) {
+                const int e = r0 + 16 * r + (lane & 15);
+                const size_t o = (size_t)(e < a.E1 ? e : 0) * Hp + c;
+                dsd[r] = ggpm_ld4(a.DSD + o); rco[r] = ggpm_ld4(a.R + o);
+                oxr[r] = a.first ? ggpm_zero4() : ggpm_ld4(a.dXr + o);
+            }
+        };
+        if constexpr (RTT == 1) load_inputs();
+        f32x4 acc[2][RTT];
+        ggpm_zero_acc<2, RTT>(acc);
         {
             const float* const tiles[2] = {T2, T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<2, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
-        if (e >= a.E1) continue;
-        const float4 dg = ggpm_f4(acc[0][0]);
-        ggpm_st4(a.dGout + o, dg);
-        ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
-        ggpm_st4(a.dXr + o, oxr + dg * rco);
+        if constexpr (RTT != 1) load_inputs();
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            const int e = r0 + 16 * r + (lane & 15);
+            if (e >= a.E1) continue;
+            const size_t o = (size_t)e * Hp + c;
+            const float4 dg = ggpm_f4(acc[0][r]);
+            ggpm_st4(a.dGout + o, dg);
+            ggpm_st4(a.dSout + o, ggpm_f4(acc[1][r]) + dsd[r]);
+            ggpm_st4(a.dXr + o, oxr[r] + dg * rco[r]);
+        }
     }
 }
 
@@ -580,11 +639,21 @@ inline int pick_tg(int E1, int NT) {
     return ggpm_tiles_per_group(E1, NT);
 }
 
+// two row tiles per workgroup where the level is large enough to be bound by the weight stream (see GGPM_RT2_MIN_ROW_TILES)
+inline bool use_rt2(int E1, int Hp, bool sparse) {
+    static const int mode = [] { const char* e = getenv("GGPM_RT2"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
+    if (mode == 0 || sparse) return false;
+    if ((size_t)2 * 32 * (Hp + 4) * sizeof(float) > 160 * 1024) return false;
+    return mode == 2 || ggpm_ceil_div(E1, 16) >= GGPM_RT2_MIN_ROW_TILES;
+}
+
 void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
-    dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
-    a.fuse_b = (with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
+    const bool rt2 = use_rt2(a.E1, Hp, a.frozen != nullptr);
+    const int rows = rt2 ? 32 : 16;
+    dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
+    const size_t lds_b = (size_t)rows * (Hp + 4) * sizeof(float);
+    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
@@ -599,8 +668,13 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
         set_lds(kernel, lds_a);
         kernel<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     };
-    if (a.bf16) { if (stash) go(gru_fwd_a<true, true>); else go(gru_fwd_a<false, true>); }
-    else { if (stash) go(gru_fwd_a<true, false>); else go(gru_fwd_a<false, false>); }
+    if (rt2) {
+        if (a.bf16) { if (stash) go(gru_fwd_a<true, true, 2>); else go(gru_fwd_a<false, true, 2>); }
+        else { if (stash) go(gru_fwd_a<true, false, 2>); else go(gru_fwd_a<false, false, 2>); }
+    } else {
+        if (a.bf16) { if (stash) go(gru_fwd_a<true, true, 1>); else go(gru_fwd_a<false, true, 1>); }
+        else { if (stash) go(gru_fwd_a<true, false, 1>); else go(gru_fwd_a<false, false, 1>); }
+    }
     ggpm_timing_end(0, s);
     if (a.dbg && (++dbg_count % 97) == 0) {
         unsigned long long h[7];
@@ -611,22 +685,27 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
                 (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, ((double)h[5] - (double)h[0]) * 0.01, (h[6] - h[5]) * 0.01);
     }
     if (with_b) {
+        auto gob = [&](auto kernel) {
+            set_lds(kernel, lds_b);
+            kernel<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a);
+        };
         ggpm_timing_begin(4, s, 1 * flops1);
-        if (a.bf16) { set_lds(gru_fwd_b<true>, lds_b); gru_fwd_b<true><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a); }
-        else { set_lds(gru_fwd_b<false>, lds_b); gru_fwd_b<false><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a); }
+        if (rt2) { if (a.bf16) gob(gru_fwd_b<true, 2>); else gob(gru_fwd_b<false, 2>); }
+        else { if (a.bf16) gob(gru_fwd_b<true, 1>); else gob(gru_fwd_b<false, 1>); }
         ggpm_timing_end(4, s);
     }
 }
 
 void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
-    dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    const size_t lds = (size_t)2 * ROWS * (Hp + 4) * sizeof(float);
-    a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && 2 * lds <= 160 * 1024 &&
+    const bool rt2 = use_rt2(a.E1, Hp, a.frozen != nullptr);
+    const int rows = rt2 ? 32 : 16;
+    dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
+    const size_t lds = (size_t)2 * rows * (Hp + 4) * sizeof(float);
+    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && 2 * lds <= 160 * 1024 &&
                 !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t lds_a = a.fuse_b ? 2 * lds : lds;
-    if (a.bf16) set_lds(gru_bwd_a<true>, lds_a); else set_lds(gru_bwd_a<false>, lds_a);
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
@@ -634,9 +713,13 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
         if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
         a.dbg = dbg_buf;
     }
+    auto go = [&](auto kernel, size_t bytes) {
+        set_lds(kernel, bytes);
+        kernel<<<grid_a, GGPM_NWA * 64, bytes, s>>>(a);
+    };
     ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
-    if (a.bf16) gru_bwd_a<true><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
-    else gru_bwd_a<false><<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
+    if (rt2) { if (a.bf16) go(gru_bwd_a<true, 2>, lds_a); else go(gru_bwd_a<false, 2>, lds_a); }
+    else { if (a.bf16) go(gru_bwd_a<true, 1>, lds_a); else go(gru_bwd_a<false, 1>, lds_a); }
     ggpm_timing_end(1, s);
     if (a.dbg && !a.first && (++dbg_count % 89) == 0) {
         unsigned long long h[5];
@@ -648,8 +731,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     }
     if (with_b) {
         ggpm_timing_begin(5, s, 2 * flops1);
-        if (a.bf16) { set_lds(gru_bwd_b<true>, lds); gru_bwd_b<true><<<grid_a, GGPM_NWA * 64, lds, s>>>(a); }
-        else { set_lds(gru_bwd_b<false>, lds); gru_bwd_b<false><<<grid_a, GGPM_NWA * 64, lds, s>>>(a); }
+        if (rt2) { if (a.bf16) go(gru_bwd_b<true, 2>, lds); else go(gru_bwd_b<false, 2>, lds); }
+        else { if (a.bf16) go(gru_bwd_b<true, 1>, lds); else go(gru_bwd_b<false, 1>, lds); }
         ggpm_timing_end(5, s);
     }
 }
@@ -732,8 +815,8 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu; a0.bf16 = bf16;
         const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
-        if (bf16) { set_lds(gru_fwd_b<true>, lds_b); gru_fwd_b<true><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
-        else { set_lds(gru_fwd_b<false>, lds_b); gru_fwd_b<false><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        if (bf16) { set_lds(gru_fwd_b<true, 1>, lds_b); gru_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        else { set_lds(gru_fwd_b<false, 1>, lds_b); gru_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
     }
     // dense levels start from h^0 = 0: the first depth launch knows that (h0_zero), so H^0 / Q^0 are never materialised
 
