@@ -675,10 +675,27 @@ class HierMPNDecoder(ScoreHeads):
             node = F_.linear([hnode, nei], [H, H], enc.W_o[0].weight, enc.W_o[0].bias, act=F_.ACT_RELU)
             return enc.W_o[2](node)
 
+        fm = tree_tensors[1]
+        from . import tree_decode as TD
+        ie, te = hmpn.inter_encoder, hmpn.tree_encoder
+        mods = (hmpn.E_i[1], hmpn.E_c[1], hmpn.W_i[2], hmpn.W_c[2], ie.W_o[2], te.W_o[2])
+        prms = [q for m in (hmpn.E_i, hmpn.E_c, hmpn.W_i, hmpn.W_c, ie.W_o, te.W_o, ie.rnn, te.rnn) for q in m.parameters()]
+        if TD.usable(mods, prms):
+            # ---- both levels as ONE autograd node each (tree_decode.py): same arithmetic, a seventh of the host work
+            specs = D.get("level_specs")
+            if specs is None:
+                B_ = init_vecs.shape[0]
+                specs = D["level_specs"] = (
+                    TD.LevelSpec(T["inst_attach"], T["mess_inst"], T["mess_pos"], T["dag_inter"], T["in_inter"], E1, 0, depth),
+                    TD.LevelSpec(T["inst_motif"], T["mess_inst"], T["mess_pos"], T["dag_tree"], T["in_tree"], E1, B_, depth))
+            hinter_node, _ = TD.tree_level(specs[0], ie.rnn, hmpn.E_i, hmpn.W_i, ie.W_o, pooled, None)
+            htree_node, hid_t = TD.tree_level(specs[1], te.rnn, hmpn.E_c, hmpn.W_c, te.W_o, hinter_node,
+                                              init_vecs.contiguous())
+            cls_vecs = torch.cat([init_vecs, hid_t[:, :H].index_select(0, T["cls_mess"])], dim=0)
+            return htree_node[:, :H], cls_vecs, assm_vecs, assm_dest
         # ---- attachment level (embed_sub_tree(is_inter_layer=True) + inter_encoder, ggpm/encoder.py:208-245)
         finput = IE._embedding_rows(hmpn.E_i, T["inst_attach"])
         hnode_i = hmpn.W_i[2](F_.linear([finput, pooled], [He, H], hmpn.W_i[0].weight, hmpn.W_i[0].bias, act=F_.ACT_RELU))
-        fm = tree_tensors[1]
         h_i = self._level_states(hmpn.inter_encoder.rnn, rnn_cell.get_init_state(fm), messages(hnode_i), T["dag_inter"], depth)
         hinter_node = readout(hmpn.inter_encoder, hnode_i, h_i, T["in_inter"])
         # ---- motif level: the root vectors ride as B extra, frozen message rows (init_decoder_state, :102-122)
