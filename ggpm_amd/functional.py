@@ -511,7 +511,7 @@ def side_stream_enabled() -> bool:
 def _side_stream(device) -> torch.cuda.Stream:
     key = (device.index if device.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        _SIDE[key] = torch.cuda.Stream(device=device)      # (ROCm offers priorities 0 and -1 only: nothing below normal)
     return _SIDE[key]
 
 
