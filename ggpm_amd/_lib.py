@@ -39,6 +39,10 @@ SIGNATURES = {
     "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
     "ggpm_level_gate_dtype": (I, [I]),
+    "ggpm_backward_skip_x_sums": (None, [I]),
+    "ggpm_gru_backward_stashes": (I, [P, I, I, I, POINTER(c_void_p), POINTER(c_void_p)]),
+    "ggpm_lstm_backward_stashes": (I, [P, I, I, I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "ggpm_sum_slots": (I, [P, I, c_size_t, P, P]),
     "ggpm_gru_pack_floats": (c_size_t, [I]),
     "ggpm_gru_forward": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),

@@ -81,6 +81,8 @@ int ggpm_take_wgrad_lo();
 // ggpm_backward_defer_stash (include/ggpm_hip.h): caller-owned gate-gradient stashes for the next sparse backward of this
 // thread.  -> true (and the pointers) once.
 bool ggpm_take_defer_stash(float* (&out)[4]);
+// ggpm_backward_skip_x_sums (include/ggpm_hip.h): consumed by the next dense level backward of this thread.
+bool ggpm_take_skip_x_sums();
 // ggpm_weights_packed (include/ggpm_hip.h): the next level / sparse call of this thread finds its packed weights in place.
 bool ggpm_take_weights_packed();
 

@@ -614,11 +614,17 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     const int blo = backward_lo(d, level, depth);
     const int gate_dtype = d.gate_dtype;
     struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
+    // no input gradient wanted (the atom level: one-hot inputs): the summed gate-input gradients are not needed on this
+    // stream at all -- the depth launches skip their read-modify-write and the second stream sums the stashed gate
+    // gradients before it contracts them (GGPM_SKIP_XSUM=0: per-depth accumulation everywhere)
+    static const bool xsum_env = !(getenv("GGPM_SKIP_XSUM") && atoi(getenv("GGPM_SKIP_XSUM")) == 0);
+    const bool skip_xsum = xsum_env && overlap_wgrads == 0 && dx == nullptr && depth > 1;
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         float* dW[4] = {G[lq(level, Q_WI)], G[lq(level, Q_WOG)], G[lq(level, Q_WU)], G[lq(level, Q_WF)]};
         float* db[4] = {G[lq(level, Q_BI)], G[lq(level, Q_BOG)], G[lq(level, Q_BU)], G[lq(level, Q_BF)]};
         ggpm_backward_lo_depth(blo);
+        if (skip_xsum) ggpm_backward_skip_x_sums(1);
         CK(ggpm_lstm_backward(E1, H, depth, L.X + 3 * slot, W[0] + I, I + H, W[1] + I, I + H, W[2] + I, I + H, W[3] + I, I + H,
                               pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Cs, L.Qs, L.St, L.St + ds,
                               L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot, dX + 3 * slot,
@@ -638,6 +644,14 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         return st.on_side([=]() -> int {
             float* const dWk[4] = {dW0, dW1, dW2, dW3};
             float* const dbk[4] = {db0, db1, db2, db3};
+            if (skip_xsum) {
+                float *DI = nullptr, *DO = nullptr, *DU = nullptr;
+                CK(ggpm_lstm_backward_stashes(level_work, E1, H, depth, &DI, &DO, &DU));
+                const int lo_ = blo < 1 ? 1 : blo;      // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
+                float* const src[3] = {DI, DO, DU};
+                for (int k = 0; k < 3; ++k)
+                    CK(ggpm_sum_slots(src[k] + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + (size_t)k * slot, sw));
+            }
             ggpm_wgrad_lo_depth(blo);
             {       // (thread-local like the hint above: this body may run on the side worker's thread)
                 GateDtypeScope tall_dtype(gate_dtype);
@@ -691,6 +705,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         }
     } else {
         ggpm_backward_lo_depth(blo);
+        if (skip_xsum) ggpm_backward_skip_x_sums(1);
         CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
                                  pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
                                  L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
@@ -710,6 +725,13 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     const float* Hs = L.Hs; const float* St = L.St;
     float* const dbu = G[lp(level, L_BU)]; float* const dbz = G[lp(level, L_BZ)]; float* const dbh = G[lp(level, L_BH)];
     return st.on_side([=]() -> int {
+        if (skip_xsum) {
+            float *DMP = nullptr, *DZP = nullptr;
+            CK(ggpm_gru_backward_stashes(level_work, E1, H, depth, &DMP, &DZP));
+            const int lo_ = blo < 1 ? 1 : blo;          // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
+            CK(ggpm_sum_slots(DZP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX, sw));
+            CK(ggpm_sum_slots(DMP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + 2 * slot, sw));
+        }
         if (!overlap) {
             ggpm_wgrad_lo_depth(blo);
             GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)

@@ -351,6 +351,7 @@ struct GruBwdArgs {
     const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
     unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
     int bf16;                      // gate products on bf16 operands
+    int skip_xsum;                 // dXz / dXh are NOT accumulated here: the caller sums the DZP / DMP stash slots afterwards
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 s[r] = z[r] = m[r] = oxz[r] = oxh[r] = ggpm_zero4();
                 if (!a.final_pass) {
                     s[r] = ggpm_ld4(a.S + o); z[r] = ggpm_ld4(a.Z + o); m[r] = ggpm_ld4(a.M + o);
-                    if (!a.first) { oxz[r] = ggpm_ld4(a.dXz + o); oxh[r] = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
+                    if (!a.first && !a.skip_xsum) { oxz[r] = ggpm_ld4(a.dXz + o); oxh[r] = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
                 }
                 dhd[r] = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
             }
@@ -510,8 +511,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             }
             ggpm_st4(a.DZP + o, dzp);
             ggpm_st4(a.DMP + o, dmp);
-            ggpm_st4(a.dXz + o, oxz[r] + dzp);
-            ggpm_st4(a.dXh + o, oxh[r] + dmp);
+            if (!a.skip_xsum) {
+                ggpm_st4(a.dXz + o, oxz[r] + dzp);
+                ggpm_st4(a.dXh + o, oxh[r] + dmp);
+            }
             if (a.fuse_b) {
                 ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, dzp);
                 ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, dmp);
@@ -771,6 +774,9 @@ extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float
     g_defer[0] = s0; g_defer[1] = s1; g_defer[2] = s2; g_defer[3] = s3;
     g_defer_set = s0 != nullptr;
 }
+namespace { thread_local bool g_skip_xsum = false; }
+extern "C" void ggpm_backward_skip_x_sums(int yes) { g_skip_xsum = yes != 0; }
+bool ggpm_take_skip_x_sums() { const bool v = g_skip_xsum; g_skip_xsum = false; return v; }
 namespace { thread_local bool g_packed = false; }
 extern "C" void ggpm_weights_packed(int yes) { g_packed = yes != 0; }
 bool ggpm_take_weights_packed() { const bool v = g_packed; g_packed = false; return v; }
@@ -923,6 +929,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  ggpm_stream_t side_stream = nullptr, const int32_t* succ_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
+    const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen && !side_stream;
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
         !dWz_h || !dUr || !dbu || !dWh_h || !work)
@@ -991,6 +998,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
+        a.skip_xsum = skip_xsum ? 1 : 0;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);     // (the dS/dG launch of step lo > 1 still forms dXr)
         if (side_stream && !frozen) {
             // Overlapped weight gradients: the stash slots of the depths finished so far are final, so their share of
@@ -1165,6 +1173,35 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
     }
     GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+namespace {
+__global__ void __launch_bounds__(256) sum_slots_k(const float* __restrict__ src, int slots, size_t slot4, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= slot4) return;
+    const float4* p = reinterpret_cast<const float4*>(src) + i;
+    float4 acc = p[0];
+    for (int t = 1; t < slots; ++t) acc = acc + p[(size_t)t * slot4];          // fixed order
+    reinterpret_cast<float4*>(out)[i] = acc;
+}
+}  // namespace
+
+extern "C" int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, float* out, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!src || !out || slots <= 0 || slot_floats == 0 || (slot_floats & 3)) return GGPM_ERR_ARG;
+    const size_t slot4 = slot_floats / 4;
+    sum_slots_k<<<(unsigned)((slot4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, slots, slot4, out);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+// where ggpm_gru_backward left its dm_pre / dz_pre stashes inside `work` (slot t-1 of each = backward step t)
+extern "C" int ggpm_gru_backward_stashes(float* work, int E1, int H, int depth, float** DMP, float** DZP) {
+    if (!work || !DMP || !DZP || E1 <= 0 || H <= 0 || depth <= 0) return GGPM_ERR_ARG;
+    const size_t Hp = (size_t)ggpm_padded_hidden(H), slot = (size_t)E1 * Hp;
+    *DMP = work + 3 * Hp * Hp;
+    *DZP = *DMP + (size_t)depth * slot;
     return GGPM_OK;
 }
 

@@ -234,6 +234,7 @@ struct LstmBwdArgs {
     float *dHin, *dCin;
     int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
     int bf16;                        // gate products on bf16 operands
+    int skip_xsum;                   // dXi / dXo / dXu are NOT accumulated here (the caller sums the DI / DO / DU stash slots)
 };
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             gi = ggpm_ld4(a.I + o); go = ggpm_ld4(a.O + o); gu = ggpm_ld4(a.U + o); cc = ggpm_ld4(a.Ccur + o);
             fco = ggpm_ld4(a.F + o);
             if (!a.first) {        // depth D starts the dX sums
-                oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o);
+                if (!a.skip_xsum) { oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o); }
                 oxf = ggpm_ld4(a.dXf + o);
             }
         }
@@ -402,9 +403,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         ggpm_st4(a.DO + o, dop);
         ggpm_st4(a.DU + o, dup);
         ggpm_st4(a.dFCout + o, dfc);
-        ggpm_st4(a.dXi + o, oxi + dip);
-        ggpm_st4(a.dXo + o, oxo + dop);
-        ggpm_st4(a.dXu + o, oxu + dup);
+        if (!a.skip_xsum) {
+            ggpm_st4(a.dXi + o, oxi + dip);
+            ggpm_st4(a.dXo + o, oxo + dop);
+            ggpm_st4(a.dXu + o, oxu + dup);
+        }
         ggpm_st4(a.dXf + o, oxf + dfc * fco);      // dXf_e += dFC_e * sum_p c_p f(1-f)
         if (a.fuse_b) {
             ggpm_st4(Ta + lr * LD + c, dip);
@@ -698,6 +701,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 
+    const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen;
     // (the packed transposes come first: their place does not depend on E1 -- ggpm_weights_packed)
     float* w = work;
     const int bf16 = ggpm_gate_dtype();
@@ -737,7 +741,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     int lo = ggpm_take_backward_lo();
     if (lo < 1 || lo > depth || frozen) lo = 1;
     for (int t = depth; t >= lo; --t) {
-        LstmBwdArgs a;
+        LstmBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
         a.Xf = Xf;
         a.Ccur = Cs + (size_t)t * slot;
@@ -754,6 +758,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         a.dXi = dXi; a.dXo = dXo; a.dXu = dXu; a.dXf = dXf;
         a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col;
+        a.skip_xsum = skip_xsum ? 1 : 0;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
@@ -771,6 +776,16 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     if (!weight_grads) return GGPM_OK;
     return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu,
                                   dWf_h, ld_dwf, frozen != nullptr, lo, stream);
+}
+
+// where ggpm_lstm_backward left its di_pre / do_pre / du_pre stashes inside `work` (slot t-1 of each = backward step t)
+extern "C" int ggpm_lstm_backward_stashes(float* work, int E1, int H, int depth, float** DI, float** DO, float** DU) {
+    if (!work || !DI || !DO || !DU || E1 <= 0 || H <= 0 || depth <= 0) return GGPM_ERR_ARG;
+    const size_t Hp = (size_t)ggpm_padded_hidden(H), slot = (size_t)E1 * Hp;
+    *DI = work + 4 * Hp * Hp;
+    *DO = *DI + (size_t)depth * slot;
+    *DU = *DO + (size_t)depth * slot;
+    return GGPM_OK;
 }
 
 extern "C" int ggpm_lstm_backward(int E1, int H, int depth, const float* Xf, const float* Wi_h, int ld_wi,

@@ -158,6 +158,17 @@ int ggpm_embed_graph(const int64_t* fnode, int N1, const int64_t* fmess, int E1,
                      int bond_types, int max_pos, float* hnode, int ld_n, float* hmess, int ld_m,
                      ggpm_stream_t stream);
 
+/* One-shot hint for the NEXT dense ggpm_gru_backward / ggpm_lstm_backward of the calling thread: do not accumulate dXz / dXh per depth (their
+ * outputs are then undefined).  The per-depth gate gradients are stashed anyway (for the weight-gradient contractions), so
+ * a caller that does not need the sums on the critical path -- the atom level has no input gradient: its inputs are one-hot
+ * constants, ggpm/encoder.py:119-126 -- forms dXz = sum_t DZP_t, dXh = sum_t DMP_t afterwards with ggpm_sum_slots over
+ * the slots ggpm_gru_backward_stashes names, e.g. on a second stream: 13 MB less HBM traffic and four memory operations
+ * fewer per element in every depth launch.  ggpm_sum_slots: out[i] = sum_t src[t * slot_floats + i], fixed order. */
+void ggpm_backward_skip_x_sums(int yes);
+int ggpm_gru_backward_stashes(float* work, int E1, int H, int depth, float** DMP, float** DZP);
+/* ... and for ggpm_lstm_backward: dXi, dXo, dXu = sums of the DI / DO / DU stash slots (dXf still accumulates per depth) */
+int ggpm_lstm_backward_stashes(float* work, int E1, int H, int depth, float** DI, float** DO, float** DU);
+int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, float* out, ggpm_stream_t stream);
 /* Gate-product dtype of the level calls (ggpm_gru_/ggpm_lstm_ forward, backward, weight_grads) issued by the CALLING
  * THREAD from now on: 0 = fp32 operands (default, the 1e-4 parity mode), 1 = bf16 operands with fp32 accumulate for
  * the hidden x hidden products of the depth loops and the tall weight-gradient contractions (BASELINE configs[4]; the
