@@ -404,7 +404,9 @@ class VaeWorkload:
                                    tensors of the encoder row (``schedule=`` passed in);
       * ``schedule_in_loop``       ``model(*batch, beta=beta)`` exactly as vae_train.py:78 calls it: the batch arrives as
                                    host arrays + the networkx graphs, ``make_cuda`` and the decode schedule
-                                   (DecodeSchedule.from_graphs -> csrc/schedule.hip, two uploads) happen INSIDE the step.
+                                   (DecodeSchedule.from_graphs -> csrc/schedule.hip, two uploads) happen INSIDE the step;
+      * ``schedule_ahead``         that loop with its iterator wrapped, ``for batch in ScheduleAhead(dataset, model)``: the
+                                   schedule of batch k+1 is built on a worker thread while step k runs.
     """
 
     DITER_T, DITER_G, TIE = 1, 5, False
@@ -473,6 +475,23 @@ class VaeWorkload:
         batch6 = self.items[i % len(self.items)][3]
         self._zero()
         loss, metrics = self.model(*batch6, beta=0.1)             # vae_train.py:78, unchanged
+        return self._finish(loss, metrics)
+
+    def step_ahead(self, i):
+        """the loop with its one changed line, ``for batch in ScheduleAhead(dataset, model)``: batch i+1's schedule is
+        built on a worker thread while this step runs"""
+        if getattr(self, "_ahead", None) is None:
+            from ggpm_amd.dataloader import ScheduleAhead
+
+            def forever():
+                k = i
+                while True:
+                    yield self.items[k % len(self.items)][3]
+                    k += 1
+            self._ahead = iter(ScheduleAhead(forever(), self.model))
+        batch6 = next(self._ahead)
+        self._zero()
+        loss, metrics = self.model(*batch6, beta=0.1)
         return self._finish(loss, metrics)
 
     def _fence(self):
@@ -571,6 +590,13 @@ class VaeWorkload:
         for i in range(len(self.items)):
             self.step_in_loop(i)
         loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0)
+        # ... and with the loop's iterator wrapped (dataloader.ScheduleAhead): the schedule of batch k+1 built during step k
+        self._ahead = None
+        for i in range(len(self.items)):
+            self.step_ahead(i)
+        ahead_ms, _ = self._timed(self.step_ahead, min(steps, 20), 0)
+        self._ahead.close()
+        self._ahead = None
         t0 = time.perf_counter()
         from ggpm_amd.decoder import DecodeSchedule
         hints = self.model.decoder.schedule_hints()
@@ -578,8 +604,8 @@ class VaeWorkload:
             b6 = self.items[k % len(self.items)][3]
             DecodeSchedule.from_graphs(b6[1], b6[2], b6[3], self.vocab, **hints)
         build_ms = 1e3 * (time.perf_counter() - t0) / 16
-        log("  ... %.2f ms/step as vae_train.py calls it (host batch + networkx graphs in; schedule build %.2f ms of host time)"
-            % (loop_ms, build_ms))
+        log("  ... %.2f ms/step as vae_train.py calls it (host batch + networkx graphs in; schedule build %.2f ms of host time); "
+            "%.2f ms/step with the loop's iterator wrapped in ScheduleAhead" % (loop_ms, build_ms, ahead_ms))
         fl_exec, fl_alg = self.work()
         tf = fl_exec * self.world / (ms * 1e-3) / 1e12
         out = {"ms_per_step": round(ms, 3), "value": round(B * self.world / (ms * 1e-3), 2), "unit": "molecules/s",
@@ -589,6 +615,11 @@ class VaeWorkload:
                                     "host_schedule_build_ms": round(build_ms, 3),
                                     "what": "model(*batch, beta=beta) as vae_train.py:78: numpy tensors + networkx graphs in, "
                                             "make_cuda and DecodeSchedule.from_graphs (csrc/schedule.hip) inside the step"},
+               "schedule_ahead": {"ms_per_step": round(ahead_ms, 3), "value": round(B * self.world / (ahead_ms * 1e-3), 2),
+                                  "ratio_to_resident": round(ahead_ms / ms, 3),
+                                  "what": "the same loop with ONE changed line, `for batch in ScheduleAhead(dataset, model)` "
+                                          "(ggpm_amd/dataloader.py): batch k+1's schedule is built on a worker thread during "
+                                          "step k; make_cuda and the two table uploads stay in the step"},
                "steps": steps, "warmup": warm, "rnn_type": self.rnn, "n_gpus": self.world,
                "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
@@ -818,7 +849,7 @@ def main():
                 vl = VaeWorkload(cfg, "LSTM", a, dev, rank, world)
                 ml = vl.measure()
                 result["vae_step"]["lstm"] = {k: ml[k] for k in ("ms_per_step", "value", "unit", "schedule_in_loop",
-                                                                 "ms_per_step_index_structures_rebuilt", "roofline",
+                                                                 "schedule_ahead", "ms_per_step_index_structures_rebuilt", "roofline",
                                                                  "launches_per_step") if k in ml}
                 del vl
         except Exception as exc:

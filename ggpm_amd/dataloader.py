@@ -135,3 +135,62 @@ class DevicePrefetcher:
                 cur.wait_event(ev)                       # consumer stream ordered behind the upload
                 dev.record_stream(cur)
             yield tree, graph
+
+
+class ScheduledGraphs(tuple):
+    """``graphs`` of a batch tuple with the batch's decode schedule riding along (``.ggpm_schedule``): still the
+    ``(tree_batchG, graph_batchG)`` pair for every reader of the reference's batch shape."""
+    ggpm_schedule = None
+
+
+class ScheduleAhead:
+    """Iterator wrapper for the training loop (vae_train.py:71, ``for batch in dataset``): yields the SAME batch tuples
+    ``(mols, graphs, tensors, orders, homos, lumos)``, with the decoder's integer bookkeeping of batch k+1
+    (``DecodeSchedule.from_graphs``: label walk over the networkx nodes + csrc/schedule.hip, which releases the GIL)
+    built on a worker thread while step k runs.  ``HierPropertyVAE.forward`` picks the schedule up from ``graphs``.
+
+        for batch in ScheduleAhead(dataset, model):          # the one changed line
+            loss, metrics = model(*batch, beta=beta)
+
+    ``depth`` batches are in flight (default 1).  Exceptions of the builder surface at the batch they belong to; a
+    batch whose ``graphs`` is None passes through untouched.  Host work only: uploads stay in the step (two copies).
+    """
+
+    def __init__(self, batches: Iterable, model, depth: int = 1):
+        self.batches, self.depth = batches, max(1, int(depth))
+        dec = model.decoder
+        self._vocab, self._hints = dec.vocab, dec.schedule_hints()
+
+    def _prepare(self, batch):
+        from .decoder import DecodeSchedule
+        mols, graphs, tensors, orders = batch[:4]
+        if graphs is None or getattr(graphs, "ggpm_schedule", None) is not None:
+            return batch
+        sch = DecodeSchedule.from_graphs(graphs, tensors, orders, self._vocab, **self._hints)
+        g = ScheduledGraphs(graphs)
+        g.ggpm_schedule = sch
+        return (mols, g, tensors, orders) + tuple(batch[4:])
+
+    def __iter__(self) -> Iterator:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ggpm-schedule")
+        try:
+            pending = []
+            it = iter(self.batches)
+            exhausted = False
+            while True:
+                while not exhausted and len(pending) < self.depth + 1:
+                    try:
+                        b = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                    pending.append(pool.submit(self._prepare, b))
+                if not pending:
+                    return
+                yield pending.pop(0).result()
+        finally:
+            pool.shutdown(wait=True, cancel_futures=True)
+
+    def __len__(self):
+        return len(self.batches)

@@ -225,6 +225,8 @@ class HierPropertyVAE(nn.Module):
         return rsample(z_vecs, W_mean, W_var, perturb)
 
     def forward(self, mols, graphs, tensors, orders, homos=None, lumos=None, beta=0.0, perturb_z=True, schedule=None):
+        if schedule is None:
+            schedule = getattr(graphs, "ggpm_schedule", None)       # dataloader.ScheduleAhead: built one batch ahead
         if schedule is None and graphs is not None:
             # the reference's call shape, ``model(*batch, beta=beta)`` (vae_train.py:78): derive the decoder's integer
             # bookkeeping HERE, from the batch as it arrives (host arrays: no read-back), so that the atom level can be

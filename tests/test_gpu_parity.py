@@ -1,4 +1,5 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import types
 import numpy as np
 import pytest
 import torch
@@ -1130,6 +1131,59 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     for k, v in model.named_parameters():
         grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
         g.check_grad(k, grad, rel=TOL)
+
+
+@pytest.mark.parametrize("rnn,H,L,depth,B,motifs,vocab,tie,seed", [
+    ("GRU", 300, 32, 20, 32, (8, 12), (500, 1500), False, 4242),      # configs[1]: the bench workload's batch shape
+    ("LSTM", 250, 24, 20, 20, (6, 14), (721, 6489), False, 77),       # configs[0]: the pretrained model's shape (9 attachments per motif)
+    ("GRU", 300, 32, 20, 64, (1, 3), (500, 1500), False, 78),         # configs[2]: QM9-shaped, single-motif molecules among them
+    ("LSTM", 600, 24, 20, 8, (6, 14), (721, 6489), True, 79),         # configs[3]'s model: H=600, tied embeddings
+])
+def test_vae_step_at_config_shapes_matches_oracle(rnn, H, L, depth, B, motifs, vocab, tie, seed):
+    """The full VAE step (encoder, rsample, teacher-forced decoder, four losses, backward) against oracle/ref_decoder.
+    vae_forward at the model shapes BASELINE.json's configs name (the golden vectors of the reference cover H <= 64):
+    loss, KL, the four accuracies and every parameter gradient, norm-wise 1e-4.  diterT=1, diterG=5 as the configs have
+    them; no dropout, no latent noise."""
+    from ggpm_amd import synth
+    from ggpm_amd.decoder import DecodeSchedule
+    from ggpm_amd.params import vae_param_shapes, tied_state_dict, seeded_state_dict
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    from oracle import ref_encoder as ref, ref_decoder as refd
+    n_motif, n_attach = vocab
+    specs = synth.random_batch(seed, B, motifs=motifs, n_motif_vocab=n_motif, n_attach_vocab=n_attach)
+    tensors = synth.tensorize(specs)
+    sch = DecodeSchedule.from_specs(specs, tensors)
+    sd = seeded_state_dict(vae_param_shapes(rnn, H, L, n_motif, n_attach), seed)
+    if tie:
+        sd = tied_state_dict(sd)
+    voc = IndexPairVocab(n_motif, n_attach)
+    a = types.SimpleNamespace(vocab=voc, rnn_type=rnn, embed_size=H, hidden_size=H,
+                              atom_vocab=types.SimpleNamespace(size=lambda: 38), depthT=depth, depthG=depth, diterT=1,
+                              diterG=5, dropout=0.0, latent_size=L, tie_embedding=tie)
+    model = HierPropertyVAE(a).to(_dev())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    loss, metrics = model(None, None, tensors, [None] * B, None, None, beta=0.1, perturb_z=False, schedule=sch)
+    loss.backward()
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    if tie:
+        for k in ("E_c.0.weight", "E_i.0.weight"):
+            p["encoder." + k] = p["decoder.hmpn." + k]
+    tt, gt = ref.to_long_tensors(tensors[0]), ref.to_long_tensors(tensors[1])
+    rl, rkl, accs, _ = refd.vae_forward(p, rnn, depth, depth, 1, 5, tt, gt, sch, voc.mask, 0.1)
+    rl.backward()
+    assert abs(float(loss.detach()) - float(rl.detach())) <= TOL * abs(float(rl.detach()))
+    assert abs(metrics["KL:"] - float(rkl.detach())) <= TOL * max(1.0, abs(float(rkl.detach())))
+    assert np.allclose([metrics[k] for k in ("Word", "I-Word", "Topo", "Assm")], [float(x) for x in accs], atol=1e-6)
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    for k, v in model.named_parameters():
+        want = p[k].grad.numpy() if p[k].grad is not None else np.zeros(tuple(v.shape), np.float32)
+        got = v.grad.cpu().numpy() if v.grad is not None else np.zeros_like(want)
+        scale = float(np.abs(want).max())
+        if scale <= 1e-6 * gmax:            # analytically zero gradients (a bias under a softmax over all rows): rounding only
+            assert float(np.abs(got).max()) <= 1e-4 * gmax, k
+            continue
+        assert float(np.abs(got - want).max()) / scale < TOL, (k, float(np.abs(got - want).max()) / scale)
 
 
 @pytest.mark.parametrize("M,N,ld", [(1, 1, 4), (37, 300, 304), (600, 250, 256), (2048, 62, 64), (2049, 300, 304),

@@ -132,6 +132,39 @@ def test_forward_with_graphs_equals_forward_with_a_prebuilt_schedule():
         assert torch.equal(ga[k], gb[k]), k
 
 
+def test_schedule_ahead_loop_equals_the_plain_loop():
+    """``for batch in ScheduleAhead(dataset, model)`` (schedules built one batch ahead on a worker thread) against the
+    unchanged loop: same losses and the same parameters after four Adam steps, bit for bit."""
+    from ggpm_amd import synth
+    from ggpm_amd.dataloader import ScheduleAhead
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(40, 120)
+    configs = _Configs(vocab, rnn_type="GRU", hidden_size=64, embed_size=64, latent_size=16, depthT=6, depthG=6, dropout=0.0)
+    dataset = [synth.train_batch(synth.random_batch(70 + i, 6, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120))
+               for i in range(4)]
+
+    def loop(wrap):
+        torch.manual_seed(11)
+        model = HierPropertyVAE(configs).to(_dev())
+        _init_like_vae_train(model)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for batch in (ScheduleAhead(dataset, model) if wrap else dataset):
+            model.zero_grad()
+            loss, m = model(*batch, beta=0.3, perturb_z=False)
+            loss.backward()
+            opt.step()
+            losses.append(m["Loss"])
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    la, pa = loop(False)
+    lb, pb = loop(True)
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 def test_refilling_a_resident_index_tensor_rebuilds_its_csr():
     """VERDICT r2 weak #9: the CSR memo hangs on the index tensor object; an in-place refill must invalidate it."""
     from ggpm_amd import functional as F_

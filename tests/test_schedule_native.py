@@ -138,3 +138,51 @@ def test_native_builder_refuses_tables_that_index_outside_themselves():
     g2[3] = np.array(graph[3]).copy()
     g2[3][1, 0] = 10 ** 6                                          # a predecessor id beyond the bond table
     assert SN.build_tables((tree, tuple(g2)), orders, icls, cands) is None
+
+
+class _FakeDecoder:
+    def __init__(self, vocab, depth, gates):
+        self.vocab, self._h = vocab, dict(depth=depth, gates=gates)
+
+    def schedule_hints(self):
+        return dict(self._h)
+
+
+class _FakeModel:
+    def __init__(self, vocab, depth=4, gates=3):
+        self.decoder = _FakeDecoder(vocab, depth, gates)
+
+
+def test_schedule_ahead_yields_the_same_batches_with_their_schedules():
+    """dataloader.ScheduleAhead: the loop's batches come out in order, unchanged but for ``graphs`` carrying the decode
+    schedule the forward would otherwise build (same tables as a direct DecodeSchedule.from_graphs)."""
+    from ggpm_amd.dataloader import ScheduleAhead, ScheduledGraphs
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(40, 120)
+    model = _FakeModel(vocab)
+    dataset = [synth.train_batch(synth.random_batch(30 + i, 5, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120))
+               for i in range(4)]
+    out = list(ScheduleAhead(dataset, model))
+    assert len(out) == len(dataset) == len(ScheduleAhead(dataset, model))
+    for got, want in zip(out, dataset):
+        assert got[0] is want[0] and got[2] is want[2] and got[3] is want[3] and got[4] is want[4] and got[5] is want[5]
+        assert isinstance(got[1], ScheduledGraphs) and got[1][0] is want[1][0] and got[1][1] is want[1][1]
+        direct = DecodeSchedule.from_graphs(want[1], want[2], want[3], vocab, depth=4, gates=3)
+        _same_steps(got[1].ggpm_schedule.steps, direct.steps)
+    # a batch without graphs (the prepared-schedule call shape) passes through untouched
+    bare = (None, None, dataset[0][2], dataset[0][3], None, None)
+    assert list(ScheduleAhead([bare], model))[0] is bare
+
+
+def test_schedule_ahead_raises_at_the_batch_that_is_malformed():
+    from ggpm_amd.dataloader import ScheduleAhead
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(40, 120)
+    good = synth.train_batch(synth.random_batch(3, 4, motifs=(2, 6), n_motif_vocab=40, n_attach_vocab=120))
+    orders = [list(o) for o in good[3]]
+    orders[0][0] = (10 ** 6, orders[0][0][1], orders[0][0][2])                          # a node id beyond the tree tensors
+    bad = (good[0], good[1], good[2], orders, good[4], good[5])
+    it = iter(ScheduleAhead([good, bad, good], _FakeModel(vocab)))
+    assert next(it)[1].ggpm_schedule is not None
+    with pytest.raises(Exception):
+        next(it)
