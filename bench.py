@@ -452,10 +452,14 @@ class VaeWorkload:
         self.orders = [None] * cfg["batch"]
 
     def _finish(self, loss, metrics):
+        from ggpm_amd.functional import mark          # (no-ops unless tools/vae_phase_times.py switched them on)
+        mark("bwd: starts")
         loss.backward()
+        mark("bwd: engine returns")
         if self.sync is not None:
             self.sync.all_reduce()
         self.opt.step()
+        mark("optimizer issued")
         metrics["Loss"]      # the training loop reads the metrics here (vae_train.py:86): one host read-back per step
         return metrics
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                      P, I, P, I, P, P, I, P, c_size_t, P]),
     "ggpm_backward_defer_stash": (None, [P, P, P, P]),
+    "ggpm_forward_gather_state": (None, [P, P, P]),
+    "ggpm_backward_scatter_state": (None, [P, P, P]),
     "ggpm_weights_packed": (None, [I]),
     "ggpm_weight_grads_stacked_workspace_bytes": (c_size_t, [I, I]),
     "ggpm_gru_weight_grads_stacked": (I, [I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, c_size_t, P]),

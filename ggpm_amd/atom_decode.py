@@ -729,8 +729,13 @@ class _AtomDecodeCompact(torch.autograd.Function):
     def backward(ctx, d_pooled, d_cand):
         lib = _lib.load()
         # everything upstream of the atom level (heads, the two tree-side levels) has run its backward: their queued
-        # weight-gradient contractions can start now, beside this node and the encoder's backward
-        F_.flush_deferred_early()
+        # weight-gradient contractions can start beside this node and the encoder's backward.  They are ~45 launches of
+        # host time: with the step loop handed to the worker thread they are issued AFTER the loop has been posted (below),
+        # so that the longest chain of the pass starts first; without the worker, here.
+        F_.mark("bwd: atom level's node reached")
+        flush_after_post = _DRIVER and _ASYNC and os.environ.get("GGPM_DEFER_EARLY_AT", "post") == "post"
+        if not flush_after_post:
+            F_.flush_deferred_early()
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
         lstm = cell == "LSTM"
         sv = list(ctx.saved_tensors)
@@ -800,6 +805,10 @@ class _AtomDecodeCompact(torch.autograd.Function):
                 P(work), work.numel() * 4, P(tmp), s), "decode_steps_backward")
             if go_async:
                 _INFLIGHT.append((desc, _keep, sv, dF, dCF, dX_all, DG_all, DQ_all, acc, work, tmp))
+        F_.mark("bwd: atom loop posted")
+        if flush_after_post:
+            F_.flush_deferred_early()
+        F_.mark("bwd: atom node returns")
         for t in (() if _DRIVER else range(T - 1, -1, -1)):
             n = plan.nloc[t]
             dhd, dhin = dF[foff[t]:foff[t + 1]], torch.empty(n, Hp, **f32)
@@ -857,10 +866,12 @@ class _AtomDecodeCompact(torch.autograd.Function):
             atom_stream = torch.cuda.current_stream(dev)
 
             def finish():
+                F_.mark("bwd: end-of-pass callback")
                 _join_worker("decode_join (backward)")
                 main = torch.cuda.current_stream(dev)
                 with torch.cuda.stream(atom_stream):
                     grads = tail()
+                    F_.mark("bwd: atom level's tail issued")
                 main.wait_stream(atom_stream)
                 for prm, g in zip(params_ref, grads):
                     g.record_stream(main)

@@ -85,6 +85,10 @@ bool ggpm_take_defer_stash(float* (&out)[4]);
 bool ggpm_take_skip_x_sums();
 // ggpm_weights_packed (include/ggpm_hip.h): the next level / sparse call of this thread finds its packed weights in place.
 bool ggpm_take_weights_packed();
+// ggpm_forward_gather_state / ggpm_backward_scatter_state (include/ggpm_hip.h): consumed by the next sparse forward /
+// backward of this thread.  -> true (and the pointers) once.
+bool ggpm_take_gather_state(const float** src_h, const float** src_c, const int32_t** idx);
+bool ggpm_take_scatter_state(float** dst_h, float** dst_c, const int32_t** idx);
 
 // Gate-product dtype of the level calls issued by this thread: 0 fp32 (default), 1 bf16 operands.  Set by the encoder
 // drivers from ggpm_enc_dims.gate_dtype for the duration of their call (mpn_gru.hip).

@@ -17,6 +17,10 @@
 
 namespace {
 
+// GGPM_DECODE_FOLD=0 (dev A/B, tests): the start-state gather and the incoming-gradient scatter of every decode step as
+// launches of their own instead of inside the step's first / last launch
+inline bool decode_fold() { static const bool v = [] { const char* e = getenv("GGPM_DECODE_FOLD"); return !e || atoi(e) != 0; }(); return v; }
+
 struct Offs {
     size_t f0, f1, r0, q0;      // F-id range of the step, first row of its [depth][n] and [depth + 1][n] blocks
 };
@@ -43,6 +47,7 @@ extern "C" int ggpm_decode_steps_forward(const ggpm_decode_steps* d, const float
     int nmax = 0;
     for (int t = 0; t < d->T; ++t) nmax = d->n[t] > nmax ? d->n[t] : nmax;
     (void)tmp;
+    const bool fold = decode_fold();
     for (int t = 0; t < d->T; ++t) {
         const int n = d->n[t];
         const Offs o = offs(d, t);
@@ -52,15 +57,24 @@ extern "C" int ggpm_decode_steps_forward(const ggpm_decode_steps* d, const float
         float* qs = Qs_all + o.r0 * Hp;
         float* st[5];
         for (int k = 0; k < 5; ++k) st[k] = St_all + (size_t)k * st_stride + o.r0 * Hp;
-        // the step's start state straight into slot 0 of its block: frozen rows from the blocks of the steps that produced
-        // them, zero for the rows the step recomputes (srcH = -1) -- exactly the masked state sparse_forward would build
-        int rc = ggpm_gather_rows(Hs_all, Hp, d->srcH[t], n, Hp, hs, Hp, 0, 0, stream);
-        if (rc) return rc;
+        // the step's start state goes straight into slot 0 of its block: frozen rows from the blocks of the steps that
+        // produced them, zero for the rows the step recomputes (srcH = -1) -- exactly the masked state sparse_forward would
+        // build.  The step's first launch (q^0 = U_r h^0 / qf^0 = Wf_h h^0) fetches the rows through srcH and writes slot 0
+        // on the way (ggpm_forward_gather_state); GGPM_DECODE_FOLD=0: a gather launch of its own, as before.
+        int rc = GGPM_OK;
+        if (fold) {
+            ggpm_forward_gather_state(Hs_all, d->lstm ? Cs_all : nullptr, d->srcH[t]);
+        } else {
+            rc = ggpm_gather_rows(Hs_all, Hp, d->srcH[t], n, Hp, hs, Hp, 0, 0, stream);
+            if (rc) return rc;
+        }
         if (t > 0) ggpm_weights_packed(1);      // same weights, same `wpack`: packed by the first step
         if (d->lstm) {
             float* cs = Cs_all + o.q0 * Hp;
-            rc = ggpm_gather_rows(Cs_all, Hp, d->srcH[t], n, Hp, cs, Hp, 0, 0, stream);
-            if (rc) return rc;
+            if (!fold) {
+                rc = ggpm_gather_rows(Cs_all, Hp, d->srcH[t], n, Hp, cs, Hp, 0, 0, stream);
+                if (rc) return rc;
+            }
             rc = ggpm_lstm_sparse_forward(n, H, d->depth, hs, cs, d->frozen[t], x, x + xs, x + 2 * xs, x + 3 * xs, W[0],
                                           ldw[0], W[1], ldw[1], W[2], ldw[2], W[3], ldw[3], d->pred_rowptr[t], d->pred_col[t],
                                           hs, cs, qs, st[0], st[1], st[2], st[3], st[4], wpack, 1, stream);
@@ -89,6 +103,7 @@ extern "C" int ggpm_decode_steps_backward(const ggpm_decode_steps* d, const floa
     for (int t = 0; t < d->T; ++t) nmax = d->n[t] > nmax ? d->n[t] : nmax;
     float* dhin = tmp;
     float* dcin = tmp + (size_t)nmax * Hp;
+    const bool fold = decode_fold();
     for (int t = d->T - 1; t >= 0; --t) {
         const int n = d->n[t];
         const Offs o = offs(d, t);
@@ -104,6 +119,9 @@ extern "C" int ggpm_decode_steps_backward(const ggpm_decode_steps* d, const floa
         float* dhd = dF + o.f0 * Hp;
         if (t < d->T - 1) ggpm_weights_packed(1);      // same weights, same `work`: the transposes were packed by the first call
         int rc;
+        // the frozen rows' gradient goes to the step that produced their state (rows recomputed here: none): added there by
+        // the step's last launch (ggpm_backward_scatter_state), or by scatter launches of their own
+        if (fold) ggpm_backward_scatter_state(dF, d->lstm ? dCF : nullptr, d->srcF[t]);
         if (d->lstm) {
             ggpm_backward_defer_stash(dg[0], dg[1], dg[2], DQ_all + o.q0 * Hp);
             rc = ggpm_lstm_sparse_backward(n, H, d->depth, d->frozen[t], x + 3 * xs, W[0], ldw[0], W[1], ldw[1], W[2], ldw[2],
@@ -112,7 +130,7 @@ extern "C" int ggpm_decode_steps_backward(const ggpm_decode_steps* d, const floa
                                            dCF + o.f0 * Hp, dhin, dcin, dx, dx + xs, dx + 2 * xs, dx + 3 * xs, dW_unused[0],
                                            H, dW_unused[1], H, dW_unused[2], H, dW_unused[3], H, work, work_bytes, stream);
             if (rc) return rc;
-            rc = ggpm_scatter_rows(dcin, Hp, d->srcF[t], n, Hp, dCF, Hp, 1, stream);
+            if (!fold) rc = ggpm_scatter_rows(dcin, Hp, d->srcF[t], n, Hp, dCF, Hp, 1, stream);
         } else {
             ggpm_backward_defer_stash(dg[0], dg[1], DQ_all + o.q0 * Hp, nullptr);
             rc = ggpm_gru_sparse_backward(n, H, d->depth, d->frozen[t], x + xs, W[0], ldw[0], W[1], ldw[1], W[2], ldw[2],
@@ -121,8 +139,7 @@ extern "C" int ggpm_decode_steps_backward(const ggpm_decode_steps* d, const floa
                                           dW_unused[1], H, dW_unused[3], dW_unused[2], H, work, work_bytes, stream);
         }
         if (rc) return rc;
-        // the frozen rows' gradient goes to the step that produced their state (rows recomputed here: none)
-        rc = ggpm_scatter_rows(dhin, Hp, d->srcF[t], n, Hp, dF, Hp, 1, stream);
+        if (!fold) rc = ggpm_scatter_rows(dhin, Hp, d->srcF[t], n, Hp, dF, Hp, 1, stream);
         if (rc) return rc;
     }
     GGPM_CHECK_LAUNCH();

@@ -109,6 +109,8 @@ struct GruFwdArgs {
     int bf16;                      // gate products on bf16 operands (packed weights are bf16 fragments then)
     int h0_zero;                   // first depth of a dense level: h^0 = 0, so s = g = 0 without a gather and the gate
                                    // products vanish (h^1 = sigmoid(x_z) tanh(x_h)); H^0 / Q^0 are neither built nor read
+    const float* src_h;            // kernel B of a sparse forward's q^0 launch (ggpm_forward_gather_state): row r of the
+    const int32_t* src_idx;        // start state is src_h[src_idx[r]] (zero when < 0); the launch writes it to Hnew itself
 };
 
 __global__ void pad_bias(const float* __restrict__ b, int H, int Hp, float* __restrict__ out) {
@@ -306,7 +308,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     GgpmRing<1> ring;
     if constexpr (!BF16)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
-    ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+    if (a.src_idx) ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
+    else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
@@ -347,6 +350,8 @@ struct GruBwdArgs {
     float* carry;                  // [E1,Hp] running dh of frozen rows (started by the first backward depth)
     int final_pass;                // t == 0: P1 + dq.U_r only, result to dHin
     float* dHin;                   // [E1,Hp]
+    float* scat_h;                 // ggpm_backward_scatter_state: the final pass ADDS row r's result to
+    const int32_t* scat_idx;       // scat_h[scat_idx[r]] (unique ids; < 0: dropped) instead of writing dHin
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
     const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
     unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
@@ -485,7 +490,15 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             if (a.final_pass) {        // gradient of the incoming state: frozen rows only (active rows started from 0)
                 float4 dh0 = ggpm_zero4();
                 if (frz) dh0 = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c) + ggpm_ld4(a.carry + o);
-                ggpm_st4(a.dHin + o, dh0);
+                if (a.scat_idx) {
+                    const int id = frz ? a.scat_idx[row] : -1;
+                    if (id >= 0) {
+                        float* d = a.scat_h + (size_t)id * Hp + c;
+                        ggpm_st4(d, ggpm_ld4(d) + dh0);
+                    }
+                } else {
+                    ggpm_st4(a.dHin + o, dh0);
+                }
                 continue;
             }
             float4 dsdir = ggpm_zero4(), dzp = ggpm_zero4(), dmp = ggpm_zero4();
@@ -777,6 +790,28 @@ extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float
 namespace { thread_local bool g_skip_xsum = false; }
 extern "C" void ggpm_backward_skip_x_sums(int yes) { g_skip_xsum = yes != 0; }
 bool ggpm_take_skip_x_sums() { const bool v = g_skip_xsum; g_skip_xsum = false; return v; }
+namespace {
+thread_local const float* g_gs_h = nullptr; thread_local const float* g_gs_c = nullptr; thread_local const int32_t* g_gs_idx = nullptr;
+thread_local float* g_ss_h = nullptr; thread_local float* g_ss_c = nullptr; thread_local const int32_t* g_ss_idx = nullptr;
+}
+extern "C" void ggpm_forward_gather_state(const float* src_h, const float* src_c, const int32_t* idx) {
+    g_gs_h = src_h; g_gs_c = src_c; g_gs_idx = idx;
+}
+bool ggpm_take_gather_state(const float** src_h, const float** src_c, const int32_t** idx) {
+    *src_h = g_gs_h; *src_c = g_gs_c; *idx = g_gs_idx;
+    const bool v = g_gs_idx != nullptr && g_gs_h != nullptr;
+    g_gs_h = g_gs_c = nullptr; g_gs_idx = nullptr;
+    return v;
+}
+extern "C" void ggpm_backward_scatter_state(float* dst_h, float* dst_c, const int32_t* idx) {
+    g_ss_h = dst_h; g_ss_c = dst_c; g_ss_idx = idx;
+}
+bool ggpm_take_scatter_state(float** dst_h, float** dst_c, const int32_t** idx) {
+    *dst_h = g_ss_h; *dst_c = g_ss_c; *idx = g_ss_idx;
+    const bool v = g_ss_idx != nullptr && g_ss_h != nullptr;
+    g_ss_h = g_ss_c = nullptr; g_ss_idx = nullptr;
+    return v;
+}
 namespace { thread_local bool g_packed = false; }
 extern "C" void ggpm_weights_packed(int yes) { g_packed = yes != 0; }
 bool ggpm_take_weights_packed() { const bool v = g_packed; g_packed = false; return v; }
@@ -814,11 +849,16 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     }
     dim3 ig(ggpm_ceil_div(Hp, 256), E1);
     const int tg0 = pick_tg(E1, Hp / 16);
+    const float *gs_h = nullptr, *gs_c = nullptr;
+    const int32_t* gs_idx = nullptr;
+    const bool gathered = ggpm_take_gather_state(&gs_h, &gs_c, &gs_idx) && frozen;      // (consumed on every path)
     if (frozen) {      // sparse_forward: start from the caller's state, q^0 = U_r h^0 + b_u by one B launch
-        // (h_in == Hs: the caller put the masked start state -- frozen rows' states, zero elsewhere -- into slot 0 itself)
-        if (h_in != Hs) sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
+        // (h_in == Hs: the caller put the masked start state -- frozen rows' states, zero elsewhere -- into slot 0 itself;
+        // ggpm_forward_gather_state: the q^0 launch fetches it through the index and writes slot 0 on the way)
+        if (h_in != Hs && !gathered) sparse_init_state<<<ig, 256, 0, s>>>(h_in, frozen, Hs, Hp);
         GruFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu; a0.bf16 = bf16;
+        if (gathered) { a0.src_h = gs_h; a0.src_idx = gs_idx; }
         const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
         if (bf16) { set_lds(gru_fwd_b<true, 1>, lds_b); gru_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
@@ -930,6 +970,9 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen && !side_stream;
+    float *ss_h = nullptr, *ss_c = nullptr;
+    const int32_t* ss_idx = nullptr;
+    const bool scattered = ggpm_take_scatter_state(&ss_h, &ss_c, &ss_idx) && frozen;      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xr || !Wz_h || !Ur || !Wh_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Qs || !Ss || !Gs || !Zs || !Ms || !Rs || !dHD || !dXz || !dXr || !dXh ||
         !dWz_h || !dUr || !dbu || !dWh_h || !work)
@@ -1055,6 +1098,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.dSin = dSb[1]; a.dGin = dGb[1];          // written by the B launch of depth 1
         a.DQ = DQ; a.UrT = pUrT; a.srowptr = succ_rowptr; a.scol = succ_col; a.bf16 = bf16;
         a.frozen = frozen; a.carry = carry; a.dHin = dHin;
+        if (scattered) { a.scat_h = ss_h; a.scat_idx = ss_idx; }
         launch_bwd(a, false, flops1, s);
         GGPM_CHECK_LAUNCH();
     }

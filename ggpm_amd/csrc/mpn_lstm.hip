@@ -29,6 +29,8 @@ struct LstmFwdArgs {
     int fuse_b;                      // single column group: kernel A also forms qf' = Wf_h h' (no B launch)
     int h0_zero;                     // first depth of a dense level: h^0 = c^0 = 0 -> no gather, no gate products
     int bf16;                        // gate products on bf16 operands (packed weights are bf16 fragments then)
+    const float *src_h, *src_c;      // kernel B of a sparse forward's qf^0 launch (ggpm_forward_gather_state): the start
+    const int32_t* src_idx;          // (h, c) of row r is (src_h, src_c)[src_idx[r]] (zero when < 0), written to Hnew / Cnew
 };
 
 __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f - r.x, 1.f - r.y, 1.f - r.z, 1.f - r.w); }
@@ -195,7 +197,20 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     GgpmRing<1> ring;
     if constexpr (!BF16)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
-    ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+    if (a.src_idx) {
+        ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
+        if (grp == 0) {            // the cell state of the same rows: copied through, not a GEMM operand
+            const int q = Hp >> 2;
+            for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
+                const int lr = it / q, c = (it - lr * q) * 4, r = r0 + lr;
+                if (r >= a.E1) continue;
+                const int id = a.src_idx[r];
+                ggpm_st4(a.Cnew + (size_t)r * Hp + c, id >= 0 ? ggpm_ld4(a.src_c + (size_t)id * Hp + c) : ggpm_zero4());
+            }
+        }
+    } else {
+        ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+    }
     __syncthreads();
     const int row = r0 + (lane & 15);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -232,6 +247,8 @@ struct LstmBwdArgs {
     float *carry_h, *carry_c;        // [E1,Hp] each, started by the first backward depth
     int final_pass;
     float *dHin, *dCin;
+    float *scat_h, *scat_c;          // ggpm_backward_scatter_state: the final pass ADDS row r's results to
+    const int32_t* scat_idx;         // (scat_h, scat_c)[scat_idx[r]] (unique ids; < 0: dropped) instead of writing dHin / dCin
     int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
     int bf16;                        // gate products on bf16 operands
     int skip_xsum;                   // dXi / dXo / dXu are NOT accumulated here (the caller sums the DI / DO / DU stash slots)
@@ -362,8 +379,18 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                 dh0 = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c) + ggpm_ld4(a.carry_h + o);
                 dc0 = ggpm_ld4(T2 + lr * LD + c) + ggpm_ld4(a.carry_c + o);
             }
-            ggpm_st4(a.dHin + o, dh0);
-            ggpm_st4(a.dCin + o, dc0);
+            if (a.scat_idx) {
+                const int id = frz ? a.scat_idx[row] : -1;
+                if (id >= 0) {
+                    float* dh_to = a.scat_h + (size_t)id * Hp + c;
+                    float* dc_to = a.scat_c + (size_t)id * Hp + c;
+                    ggpm_st4(dh_to, ggpm_ld4(dh_to) + dh0);
+                    ggpm_st4(dc_to, ggpm_ld4(dc_to) + dc0);
+                }
+            } else {
+                ggpm_st4(a.dHin + o, dh0);
+                ggpm_st4(a.dCin + o, dc0);
+            }
             continue;
         }
         float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
@@ -591,12 +618,17 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         if (!weights_packed) ggpm_launch_pack(pk, 4, s);
     }
     const int tg = pick_tg(E1, Hp / 16);
+    const float *gs_h = nullptr, *gs_c = nullptr;
+    const int32_t* gs_idx = nullptr;
+    const bool gathered = ggpm_take_gather_state(&gs_h, &gs_c, &gs_idx) && frozen && gs_c;      // (consumed on every path)
     if (frozen) {      // sparse_forward: start from the caller's (h, c); qf^0 = Wf_h h^0 by one B launch
         dim3 ig(ggpm_ceil_div(Hp, 256), E1);
-        // (h_in == Hs and c_in == Cs: the caller put the masked start state into slot 0 itself)
-        if (h_in != Hs || c_in != Cs) lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
+        // (h_in == Hs and c_in == Cs: the caller put the masked start state into slot 0 itself; ggpm_forward_gather_state:
+        // the qf^0 launch fetches it through the index and writes slot 0 of both on the way)
+        if ((h_in != Hs || c_in != Cs) && !gathered) lstm_sparse_init_state<<<ig, 256, 0, s>>>(h_in, c_in, frozen, Hs, Cs, Hp);
         LstmFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf; a0.bf16 = bf16;
+        if (gathered) { a0.src_h = gs_h; a0.src_c = gs_c; a0.src_idx = gs_idx; a0.Cnew = Cs; }
         const size_t lb = lds_tiles(1, Hp);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg));
         if (bf16) { set_lds(lstm_fwd_b<true>, lb); lstm_fwd_b<true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
@@ -611,7 +643,7 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
     int run_depth = ggpm_take_run_depth();
     if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
     for (int t = 1; t <= run_depth; ++t) {
-        LstmFwdArgs a;
+        LstmFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;
         a.frozen = frozen;
@@ -691,6 +723,9 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
                                   const float* dCD, float* dHin, float* dCin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
+    float *ss_h = nullptr, *ss_c = nullptr;
+    const int32_t* ss_idx = nullptr;
+    const bool scattered = ggpm_take_scatter_state(&ss_h, &ss_c, &ss_idx) && frozen && ss_c;      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xf || !Wi_h || !Wo_h || !Wu_h || !Wf_h || !pred_rowptr || !pred_col ||
         !succ_rowptr || !succ_col || !Hs || !Cs || !Qs || !Ss || !Is || !Os || !Us || !Fs || !dHD || !dXi || !dXo || !dXu ||
         !dXf || !dWi_h || !dWo_h || !dWu_h || !dWf_h || !work)
@@ -769,6 +804,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         a.dSin = dSb[1]; a.dFCin = dFb[1];          // written by the launches of depth 1
         a.DQ = DQ; a.WfT = pWfT; a.srowptr = succ_rowptr; a.scol = succ_col; a.bf16 = bf16;
         a.frozen = frozen; a.carry_h = carry_h; a.carry_c = carry_c; a.dHin = dHin; a.dCin = dCin;
+        if (scattered) { a.scat_h = ss_h; a.scat_c = ss_c; a.scat_idx = ss_idx; }
         launch_bwd(a, false, flops1, s);
         GGPM_CHECK_LAUNCH();
     }

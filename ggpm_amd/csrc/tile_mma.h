@@ -299,6 +299,27 @@ __device__ __forceinline__ void ggpm_load_rows_to_lds(const float* __restrict__ 
     }
 }
 
+// The same tile through an index: row r0 + i comes from src[idx[r0 + i]] (zeros when the id is negative); `copy`
+// (optional) receives the gathered rows at their own position -- the start state of a sparse forward, fetched and
+// materialised by the launch that first needs it.
+template <int ROWS>
+__device__ __forceinline__ void ggpm_gather_rows_to_lds(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                        int r0, int rows, int Hp, int LD, float* __restrict__ tile,
+                                                        float* __restrict__ copy) {
+    const int q = Hp >> 2;
+    for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
+        const int lr = it / q, c = (it - lr * q) * 4;
+        const int row = r0 + lr;
+        float4 v = ggpm_zero4();
+        if (row < rows) {
+            const int id = idx[row];
+            if (id >= 0) v = ggpm_ld4(src + (size_t)id * Hp + c);
+            if (copy) ggpm_st4(copy + (size_t)row * Hp + c, v);
+        }
+        ggpm_st4(tile + lr * LD + c, v);
+    }
+}
+
 // Pack up to 4 gate matrices W (or W^T) into fragment order, zero padded to Hp x Hp, in ONE launch
 // (blockIdx.z = matrix; matrix m lands at dst + m*Hp*Hp); optionally pads one bias vector to Hp.
 //   src(out, k) = transpose ? W[k*ldw + out] : W[out*ldw + k]     for out, k < H

@@ -634,6 +634,7 @@ class HierMPNDecoder(ScoreHeads):
                 main = torch.cuda.current_stream(dev)
                 main.wait_stream(side)
                 pooled_all.record_stream(main); cand.record_stream(main)
+                F_.mark("fwd: atom level joined")
             else:
                 if ahead is not None:                       # (a stale ahead run of another schedule: let its loop drain)
                     stale = ahead[4] if ahead[5] is None else ahead[5]["state"]["finish"]
@@ -692,6 +693,7 @@ class HierMPNDecoder(ScoreHeads):
             htree_node, hid_t = TD.tree_level(specs[1], te.rnn, hmpn.E_c, hmpn.W_c, te.W_o, hinter_node,
                                               init_vecs.contiguous())
             cls_vecs = torch.cat([init_vecs, hid_t[:, :H].index_select(0, T["cls_mess"])], dim=0)
+            F_.mark("fwd: tree-side levels issued")
             return htree_node[:, :H], cls_vecs, assm_vecs, assm_dest
         # ---- attachment level (embed_sub_tree(is_inter_layer=True) + inter_encoder, ggpm/encoder.py:208-245)
         finput = IE._embedding_rows(hmpn.E_i, T["inst_attach"])

@@ -528,6 +528,20 @@ def _join_later(main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
     torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
 
 
+# ----------------------------------------------------------------------------- phase marks (dev instrumentation)
+# tools/vae_phase_times.py sets MARKS = [] and reads (name, host time, event on the current stream) triples back; None
+# (default) makes mark() a no-op.
+MARKS = None
+
+
+def mark(name: str) -> None:
+    if MARKS is not None:
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        MARKS.append((name, time.perf_counter(), ev))
+
+
 # ----------------------------------------------------------------------------- deferred parameter gradients
 # The teacher-forced decoder uses the same parameters on every one of its ~20 steps, so a backward pass meets each
 # Linear ~20 times.  Forming dW = dpre^T x (+ column sum, + the accumulate kernel autograd adds) per visit is ~40 tiny

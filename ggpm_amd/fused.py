@@ -111,6 +111,7 @@ class _HierEncoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_hroot, d_hnode, d_hinter, d_hatom):
         lib = _lib.load()
+        F_.mark("bwd: encoder's node reached")
         dims = ctx.dims
         saved, roots, hroot, hnode, hinter, hatom, *params = ctx.saved_tensors
         dev = saved.device

@@ -145,9 +145,11 @@ class HierEncoderVAE(nn.Module):
 class StepMetrics(dict):
     """The metrics dictionary ``HierPropertyVAE.forward`` returns (ggpm/property_vae.py:60-62 builds it with ``.item()``:
     python floats).  Same keys, same values -- read on FIRST ACCESS: the six device scalars are stacked by one kernel when
-    the forward ends and copied to the host when a value is asked for, which in ``vae_train.py`` is after
-    ``loss.backward(); optimizer.step()`` (:81-86).  Reading them inside the forward, as the reference does, stops the host
-    in the middle of the step: the backward cannot be issued while the forward's tail still runs."""
+    the forward ends, their copy into pinned host memory is enqueued right behind it, and a value is taken from there
+    when it is asked for, which in ``vae_train.py`` is after ``loss.backward(); optimizer.step()`` (:81-86).  Reading them
+    inside the forward, as the reference does, stops the host in the middle of the step: the backward cannot be issued
+    while the forward's tail still runs.  The read waits for the copy's event, not for the stream: like the reference's
+    loop, the host goes on to the next batch while the GPU still finishes this step's backward and optimizer."""
 
     _KEYS = ('Loss', 'KL:', 'Word', 'I-Word', 'Topo', 'Assm')
 
@@ -158,10 +160,23 @@ class StepMetrics(dict):
         dev = next((v.device for v in vals if v is not None), None)
         self._dev = torch.stack([v if v is not None else torch.zeros((), device=dev) for v in vals]) if dev is not None else None
         self._ready = False
+        self._host = self._event = None
+        if self._dev is not None and self._dev.is_cuda and os.environ.get("GGPM_METRICS_ASYNC", "1") != "0":
+            # the copy to the host is ENQUEUED here, behind the forward; a reader waits for this event only -- not for
+            # whatever the stream has been given since (backward, optimizer), so the loop can go on to the next batch
+            # while the step's tail still runs, as it does around the reference's .item() calls
+            self._host = torch.empty(len(self._KEYS), dtype=torch.float32, pin_memory=True)
+            self._host.copy_(self._dev, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
 
     def _fill(self):
         if not self._ready:
-            host = self._dev.tolist() if self._dev is not None else [0.0] * len(self._KEYS)
+            if self._event is not None:
+                self._event.synchronize()
+                host = self._host.tolist()
+            else:
+                host = self._dev.tolist() if self._dev is not None else [0.0] * len(self._KEYS)
             for k, h, c in zip(self._KEYS, host, self._const):
                 dict.__setitem__(self, k, h if c is None else c)
             self._ready = True
@@ -234,12 +249,16 @@ class HierPropertyVAE(nn.Module):
             from .decoder import DecodeSchedule
             schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab, **self.decoder.schedule_hints())
         tree_tensors, graph_tensors = tensors = make_cuda(tensors)
+        F_.mark("fwd: inputs on the device")
         self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
+        F_.mark("fwd: atom level posted")
         root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
         root_vecs, kl_div = rsample(root_vecs, self.R_mean, self.R_var, perturb_z)
+        F_.mark("fwd: encoder + rsample issued")
         loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,
                                                     schedule=schedule)
         loss = loss + beta * kl_div
+        F_.mark("fwd: heads and losses issued")
         if os.environ.get("GGPM_LAZY_METRICS", "1") != "0":
             return loss, StepMetrics((loss, kl_div, wacc, iacc, tacc, sacc))
         return loss, {'Loss': loss.item(), 'KL:': kl_div.item(), 'Word': float(wacc), 'I-Word': float(iacc),

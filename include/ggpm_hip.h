@@ -319,6 +319,17 @@ int ggpm_lstm_sparse_backward(int E1, int H, int depth, const unsigned char* fro
  *   the same buffer left there -- the decode steps share one set of weights.  One call consumes the setting. */
 void ggpm_weights_packed(int yes);
 void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
+/* Start state / incoming-state gradient of a sparse call through an index (the decode steps keep every step's rows in
+ * stacked blocks; a step's frozen rows are the final states of rows of earlier blocks, ggpm/encoder.py:165-179 reads them
+ * out of the level-wide `hmess` instead):
+ *   ggpm_forward_gather_state(src_h, src_c, idx): the NEXT ggpm_gru_sparse_forward / ggpm_lstm_sparse_forward of this thread
+ *   takes the start state of row r from src_h[idx[r]] (src_c likewise, LSTM; zero where idx[r] < 0) and writes it to slot 0
+ *   of Hs (Cs) itself, inside its first launch; `h_in` / `c_in` are not read.
+ *   ggpm_backward_scatter_state(dst_h, dst_c, idx): the NEXT ggpm_*_sparse_backward of this thread ADDS the gradient of the
+ *   incoming state of row r to dst_h[idx[r]] (dst_c likewise; idx unique, rows with idx[r] < 0 dropped) inside its last
+ *   launch; dHin / dCin are not written.  Rows are [Hp] floats.  One call consumes the setting. */
+void ggpm_forward_gather_state(const float* src_h, const float* src_c, const int32_t* idx);
+void ggpm_backward_scatter_state(float* dst_h, float* dst_c, const int32_t* idx);
 size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows);
 int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const float* DMP, const float* Gs, const float* DZP,
                                   const float* Ss, const float* DQ, const float* Hs, float* dWz_h, int ld_dwz, float* dUr,
