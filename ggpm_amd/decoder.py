@@ -392,10 +392,22 @@ class DecodeSchedule:
             steps.append(d)
         plan = {k: ((view32 if k in ("inst_motif", "inst_attach", "mess_inst", "mess_pos") else view)(i)).view(shape)
                 for k, (i, shape) in ptab.items()}
-        self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, plan=plan,
+        self._dev = dict(device=device, steps=steps, n_assm=len(ab), host=hostbuf, plan=plan, packs=(devbuf, dev32),
                          **{k: view(v) for k, v in tail.items()},
                          **{k + "32": view32(tail[k]) for k in ("topo_batch", "cls_batch", "assm_batch")})
         return self
+
+
+def _note_stream(D: dict, stream) -> None:
+    """The schedule's device tables (two tensors, everything else is a view) are about to be read on ``stream``, which is
+    not the stream they were uploaded on: tell the allocator once per stream."""
+    seen = D.setdefault("streams_seen", set())
+    if stream.cuda_stream in seen:
+        return
+    seen.add(stream.cuda_stream)
+    for t in D.get("native") or D.get("packs") or ():
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(stream)
 
 
 class _FrozenTables:
@@ -430,6 +442,10 @@ def synth_orders(specs, tree_scope):
 def _accuracy(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """get_accuracy (ggpm/nnutils.py:84-87) from the arg-max the loss kernel already produced."""
     return (pred.long() == labels).float().sum() / labels.numel()
+
+
+def _head_streams_enabled() -> bool:
+    return os.environ.get("GGPM_HEAD_STREAMS", "1") != "0"
 
 
 class HierMPNDecoder(ScoreHeads):
@@ -494,12 +510,14 @@ class HierMPNDecoder(ScoreHeads):
             init_vecs = src_root_vecs
         else:
             init_vecs = F_.linear([src_root_vecs.contiguous()], [L], self.W_root.weight, self.W_root.bias)[:, :H]
+        assm_ctx = dict(src=src_graph_vecs)
         if os.environ.get("GGPM_DECODER_BATCHED", "1") != "0" and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_batched(schedule, D, tree_tensors, graph_tensors,
-                                                                            init_vecs)
+                                                                            init_vecs, assm_ctx)
         else:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_stepwise(D, tree_tensors, graph_tensors, init_vecs)
-        return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev)
+        return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev,
+                            assm_ctx)
 
     def _states_stepwise(self, D, tree_tensors, graph_tensors, init_vecs):
         """The reference's loop, step by step (ggpm/decoder.py:175-259): three incremental encoder calls per step."""
@@ -607,7 +625,7 @@ class HierMPNDecoder(ScoreHeads):
             return out
         return (out[0], out[1], ap) + tuple(out[2:])
 
-    def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
+    def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs, assm_ctx=None):
         """Same vectors as ``_states_stepwise`` with the two tree-side levels de-sequentialised: only the atom level
         (diterG interacting iterations per step) keeps the step loop; the attachment and motif levels are ONE call each
         over all their messages (a DAG in decode time, DecodeSchedule._level_plan) and ONE read-out over all visits."""
@@ -642,9 +660,30 @@ class HierMPNDecoder(ScoreHeads):
                         stale()
                 pooled_all, cand, _ = self._atom_level(schedule, D, graph_tensors)
             meta = ap.to_device(dev)["meta"]
-            for k, base, n in ap.cand_blocks:
-                assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
-                assm_dest.append(meta[k]["dest"])
+
+            def attach_rows():
+                for k, base, n in ap.cand_blocks:
+                    assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
+                    assm_dest.append(meta[k]["dest"])
+
+            if assm_ctx is not None and _head_streams_enabled() and dev.type == "cuda":
+                # The attachment head reads the atom level only (candidate atom vectors + the latent vector), not the two
+                # tree-side levels: it is issued HERE, on a stream of its own, and runs beside those levels -- forwards
+                # and, since autograd runs a node's backward on the stream of its forward, backwards too.
+                main = torch.cuda.current_stream(dev)
+                hs = F_.head_stream(dev, 0)
+                F_._MAIN_OF_PASS[0] = main
+                hs.wait_stream(main)
+                cand.record_stream(hs)
+                assm_ctx["src"].record_stream(hs)
+                _note_stream(D, hs)
+                with torch.cuda.stream(hs):
+                    ap.to_device(dev)                      # (notes the stream for the plan's own tables)
+                    attach_rows()
+                    assm_ctx["result"] = self._assm_head(schedule, D, assm_ctx["src"], assm_vecs, assm_dest, dev)
+                assm_ctx["stream"] = hs
+            else:
+                attach_rows()
             steps = []
         else:
             # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
@@ -710,7 +749,24 @@ class HierMPNDecoder(ScoreHeads):
         cls_vecs = torch.cat([init_vecs, rnn_cell.get_hidden_state(h_t).index_select(0, T["cls_mess"])], dim=0)
         return htree_node[:, :H], cls_vecs, assm_vecs, assm_dest
 
-    def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev):
+    def _assm_head(self, schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev):
+        """(attachment loss, accuracy) of the batch -- ggpm/decoder.py:252-254, 276-281"""
+        H = self.hidden_size
+        P, C = D["n_assm"], schedule.max_cls_size
+        if P <= 0:
+            return 0, 1
+        vec = torch.cat(assm_vecs, dim=0)
+        buf = torch.zeros(P * C, vec.shape[1], dtype=torch.float32, device=dev)
+        buf = buf.index_copy(0, torch.cat(assm_dest), vec)       # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
+        scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H])
+        labels = torch.zeros(P, dtype=torch.long, device=dev)    # "the label is always the first of assm_cands"
+        assm_loss, _ = cross_entropy_sum(scores.contiguous(), labels)
+        s = scores.detach()
+        assm_acc = (s[:, 0] == s.max(dim=-1)[0]).float().sum() / P      # get_accuracy_sym
+        return assm_loss, assm_acc
+
+    def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev,
+                assm_ctx=None):
         """The three batched heads and their losses / accuracies (ggpm/decoder.py:261-284)."""
         H = self.hidden_size
         topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch32"], topo_vecs)
@@ -721,17 +777,14 @@ class HierMPNDecoder(ScoreHeads):
                                                         D["cls_ilab"])
         cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
 
-        P, C = D["n_assm"], schedule.max_cls_size
-        if P > 0:
-            vec = torch.cat(assm_vecs, dim=0)
-            buf = torch.zeros(P * C, vec.shape[1], dtype=torch.float32, device=dev)
-            buf = buf.index_copy(0, torch.cat(assm_dest), vec)       # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
-            scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H])
-            labels = torch.zeros(P, dtype=torch.long, device=dev)    # "the label is always the first of assm_cands"
-            assm_loss, _ = cross_entropy_sum(scores.contiguous(), labels)
-            s = scores.detach()
-            assm_acc = (s[:, 0] == s.max(dim=-1)[0]).float().sum() / P      # get_accuracy_sym
+        if assm_ctx is not None and "result" in assm_ctx:      # issued beside the tree-side levels on its own stream
+            assm_loss, assm_acc = assm_ctx["result"]
+            main = torch.cuda.current_stream(dev)
+            main.wait_stream(assm_ctx["stream"])
+            for t_ in (assm_loss, assm_acc):
+                if isinstance(t_, torch.Tensor):
+                    t_.record_stream(main)
         else:
-            assm_loss, assm_acc = 0, 1
+            assm_loss, assm_acc = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev)
         loss = (topo_loss + cls_loss + assm_loss) / B
         return loss, cls_acc, icls_acc, topo_acc, assm_acc

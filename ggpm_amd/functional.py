@@ -508,6 +508,17 @@ def side_stream_enabled() -> bool:
     return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
 
 
+_HEAD: dict = {}
+
+
+def head_stream(device, which: int = 0) -> torch.cuda.Stream:
+    """Streams for branches of the decoder's heads that do not depend on each other (decoder._losses)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
+    if key not in _HEAD:
+        _HEAD[key] = torch.cuda.Stream(device=device)
+    return _HEAD[key]
+
+
 def _side_stream(device) -> torch.cuda.Stream:
     key = (device.index if device.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
@@ -549,7 +560,8 @@ def mark(name: str) -> None:
 # backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
 # visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
 # parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
-_DEFER = {"linear": {}, "sum": {}, "gather": {}, "task": None, "stream": None, "early": None, "pending": []}
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "task": None, "stream": None, "early": None, "pending": [],
+          "others": []}      # others: streams other than "stream" that queued entries since the last flush (head streams)
 
 
 def defer_wgrads_enabled() -> bool:
@@ -568,6 +580,11 @@ def can_publish(*params) -> bool:
     return all(p is None or (getattr(p, "is_leaf", False) and p.requires_grad and not _has_hooks(p)) for p in params)
 
 
+# The stream the step's main line runs on, told by whoever forks work onto other streams (decoder head streams): a
+# backward pass may reach a node of a forked branch first, and the deferred queue must still hang on the main stream.
+_MAIN_OF_PASS = [None]
+
+
 def _defer_register() -> None:
     """Queue the end-of-backward flush once per backward pass.  A pass is identified by the autograd engine's graph
     task id: a pass that RAISED never ran its callbacks, so whatever it left queued is dropped when the next pass
@@ -577,10 +594,14 @@ def _defer_register() -> None:
         _DEFER["linear"].clear()
         _DEFER["sum"].clear()
         _DEFER["gather"].clear()
-        _DEFER["pending"], _DEFER["early"] = [], None
+        _DEFER["pending"], _DEFER["early"], _DEFER["others"] = [], None, []
         _DEFER["task"] = task
-        _DEFER["stream"] = torch.cuda.current_stream()
+        _DEFER["stream"] = _MAIN_OF_PASS[0] or torch.cuda.current_stream()
         torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
+    if torch.cuda.is_available():
+        cur = torch.cuda.current_stream()
+        if cur != _DEFER["stream"] and cur not in _DEFER["others"]:
+            _DEFER["others"].append(cur)      # the flush orders itself behind this stream too
 
 
 def _defer_linear(weight, bias, dpre, xs, Ks) -> None:
@@ -620,6 +641,7 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
     _DEFER["sum"].clear()
     _DEFER["gather"].clear()
     main = _DEFER["stream"]
+    others, _DEFER["others"] = _DEFER["others"], []
     if side is None:
         _DEFER["task"] = None
         if main is not None and _DEFER["early"] is not None:
@@ -639,10 +661,12 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
         side.wait_stream(main)
         stream = side
         _DEFER["early"] = side
+    for o in others:                       # entries queued by nodes that ran on other streams (the decoder's head streams)
+        stream.wait_stream(o)
 
-    def use(t):                            # queued on `main`, read on `side`: keep the allocator from recycling it early
-        if side is not None and isinstance(t, torch.Tensor):
-            t.record_stream(side)
+    def use(t):                            # queued on one stream, read on another: keep the allocator from recycling it early
+        if (side is not None or others) and isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(stream)
         return t
 
     def publish(param, g):

@@ -54,15 +54,17 @@ def main():
         marks, F_.MARKS = F_.MARKS, None
         starts.append((len(marks), None))
         for (a, h0), (b, _) in zip(starts[2:], starts[3:]):          # (the first two steps fill the pipeline)
+            first = marks[a][2]            # "inputs on the device": reached by the main stream behind the previous step
             for name, h, ev in marks[a:b]:
                 if name not in acc:
-                    acc[name] = [0.0, 0]
+                    acc[name] = [0.0, 0.0, 0]
                     order.append(name)
                 acc[name][0] += (h - h0) * 1e3
-                acc[name][1] += 1
-        print("%-36s %10s" % ("mark", "host ms"))
+                acc[name][1] += first.elapsed_time(ev)
+                acc[name][2] += 1
+        print("%-36s %10s %22s" % ("mark", "host ms", "gpu ms after 1st mark"))
         for name in order:
-            print("%-36s %10.3f" % (name, acc[name][0] / acc[name][1]))
+            print("%-36s %10.3f %22.3f" % (name, acc[name][0] / acc[name][2], acc[name][1] / acc[name][2]))
     acc, order = {}, []
     total = 0.0
     for i in range(n):
