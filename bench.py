@@ -458,6 +458,7 @@ class VaeWorkload:
         mark("bwd: engine returns")
         if self.sync is not None:
             self.sync.all_reduce()
+        mark("gradients packed")
         self.opt.step()
         mark("optimizer issued")
         metrics["Loss"]      # the training loop reads the metrics here (vae_train.py:86): one host read-back per step

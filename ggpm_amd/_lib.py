@@ -59,6 +59,9 @@ SIGNATURES = {
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                      P, I, P, I, P, P, I, P, c_size_t, P]),
     "ggpm_backward_defer_stash": (None, [P, P, P, P]),
+    "ggpm_stream_create_cu_mask": (I, [P, I, P]),
+    "ggpm_level_prefer_narrow": (None, [I]),
+    "ggpm_device_cu_count": (I, [P]),
     "ggpm_forward_gather_state": (None, [P, P, P]),
     "ggpm_backward_scatter_state": (None, [P, P, P]),
     "ggpm_weights_packed": (None, [I]),

@@ -656,11 +656,12 @@ inline int pick_tg(int E1, int NT) {
 }
 
 // two row tiles per workgroup where the level is large enough to be bound by the weight stream (see GGPM_RT2_MIN_ROW_TILES)
+thread_local bool g_prefer_narrow = false;       // ggpm_level_prefer_narrow
 inline bool use_rt2(int E1, int Hp, bool sparse) {
     static const int mode = [] { const char* e = getenv("GGPM_RT2"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
     if (mode == 0 || sparse) return false;
     if ((size_t)2 * 32 * (Hp + 4) * sizeof(float) > 160 * 1024) return false;
-    return mode == 2 || ggpm_ceil_div(E1, 16) >= GGPM_RT2_MIN_ROW_TILES;
+    return mode == 2 || g_prefer_narrow || ggpm_ceil_div(E1, 16) >= GGPM_RT2_MIN_ROW_TILES;
 }
 
 void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
@@ -812,6 +813,7 @@ bool ggpm_take_scatter_state(float** dst_h, float** dst_c, const int32_t** idx) 
     g_ss_h = g_ss_c = nullptr; g_ss_idx = nullptr;
     return v;
 }
+extern "C" void ggpm_level_prefer_narrow(int yes) { g_prefer_narrow = yes != 0; }
 namespace { thread_local bool g_packed = false; }
 extern "C" void ggpm_weights_packed(int yes) { g_packed = yes != 0; }
 bool ggpm_take_weights_packed() { const bool v = g_packed; g_packed = false; return v; }

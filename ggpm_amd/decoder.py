@@ -594,7 +594,8 @@ class HierMPNDecoder(ScoreHeads):
             return False
         D = schedule.to_device(dev)._dev
         main = torch.cuda.current_stream(dev)
-        side = self._ATOM_STREAMS.get(dev.index)
+        split = F_.cu_split(dev)
+        side = split[0] if split is not None else self._ATOM_STREAMS.get(dev.index)
         if side is None:
             # high priority: this chain of small dependent launches is the step's critical path, the encoder beside it
             # has slack -- where both have a kernel waiting for CUs, this one goes first (GGPM_ATOM_PRIORITY=0: default)

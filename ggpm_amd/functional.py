@@ -508,6 +508,43 @@ def side_stream_enabled() -> bool:
     return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
 
 
+_CU_SPLIT: dict = {}
+
+
+def cu_split(device):
+    """(atom-level stream, encoder stream) restricted to disjoint sets of compute units, or None.
+
+    In the full VAE step the decoder's atom level (a chain of ~250 small dependent launches per direction, the step's
+    critical path) runs beside the encoder (larger launches with slack).  Sharing all CUs, a chain launch that finds the
+    chip full of encoder workgroups waits for them to drain; with GGPM_CU_SPLIT=n the chain's stream owns n compute units
+    and the encoder's stream the rest (csrc/capi.hip: ggpm_stream_create_cu_mask).  0 / unset: off."""
+    n = int(os.environ.get("GGPM_CU_SPLIT", "0") or 0)
+    if n <= 0 or device.type != "cuda":
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key not in _CU_SPLIT:
+        import ctypes
+        lib = _lib.load()
+        total = ctypes.c_int(0)
+        made = None
+        with torch.cuda.device(device):
+            if lib.ggpm_device_cu_count(ctypes.byref(total)) == 0 and 0 < n < total.value:
+                words = (total.value + 31) // 32
+                streams = []
+                for lo, hi in ((0, n), (n, total.value)):
+                    mask = (ctypes.c_uint32 * words)()
+                    for i in range(lo, hi):
+                        mask[i // 32] |= 1 << (i % 32)
+                    out = ctypes.c_void_p(0)
+                    if lib.ggpm_stream_create_cu_mask(mask, words, ctypes.byref(out)) != 0 or not out.value:
+                        streams = None
+                        break
+                    streams.append(torch.cuda.ExternalStream(out.value, device=device))
+                made = tuple(streams) if streams else None
+        _CU_SPLIT[key] = made
+    return _CU_SPLIT[key]
+
+
 _HEAD: dict = {}
 
 
@@ -644,6 +681,7 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
     others, _DEFER["others"] = _DEFER["others"], []
     if side is None:
         _DEFER["task"] = None
+        mark("bwd: end-of-pass flush starts")
         if main is not None and _DEFER["early"] is not None:
             # what the early flush computed on the second stream is handed to .grad HERE, on the queueing stream, once
             # that stream is ordered behind it: every mutation of .grad stays on one stream, whatever order the engine

@@ -76,6 +76,15 @@ def _side_ptr(device):
     return side, ctypes.c_void_p(side.cuda_stream)
 
 
+# The stream of the caller's main line when the encoder is run on a stream of its own (property_vae: functional.cu_split).
+# Gradients that this node writes itself (flat gradient buffer) are then ordered in front of the caller's stream when the
+# backward pass ends.
+CALLER_STREAM = [None]
+# True while the caller runs the encoder beside another chain of launches (property_vae: the decoder's atom level): the
+# level kernels then take half as many workgroups (ggpm_level_prefer_narrow), forwards and backwards.
+NARROW = [False]
+
+
 class _HierEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dims: EncDims, tree_tensors, graph_tensors, roots, grad_sink, *params):
@@ -95,10 +104,17 @@ class _HierEncoder(torch.autograd.Function):
             saved.record_stream(side)
             roots.record_stream(side)
         P = F_._p
-        _lib.check(lib.ggpm_encoder_forward(ctypes.byref(dims), _ptr_array(params), P(tfnode), P(tfmess), P(tagraph),
-                                            P(tbgraph), P(tcgraph), P(gfnode), P(gfmess), P(gagraph), P(gbgraph),
-                                            P(roots), P(saved), saved_bytes, P(hroot), P(hnode), P(hinter), P(hatom),
-                                            F_._stream(), side_p), "encoder_forward")
+        narrow = bool(NARROW[0])
+        if narrow:
+            lib.ggpm_level_prefer_narrow(1)
+        try:
+            _lib.check(lib.ggpm_encoder_forward(ctypes.byref(dims), _ptr_array(params), P(tfnode), P(tfmess), P(tagraph),
+                                                P(tbgraph), P(tcgraph), P(gfnode), P(gfmess), P(gagraph), P(gbgraph),
+                                                P(roots), P(saved), saved_bytes, P(hroot), P(hnode), P(hinter), P(hatom),
+                                                F_._stream(), side_p), "encoder_forward")
+        finally:
+            if narrow:
+                lib.ggpm_level_prefer_narrow(0)
         if any(ctx.needs_input_grad):
             # everything the backward reads goes through save_for_backward: autograd then owns the arena and the
             # outputs (no ctx -> output -> grad_fn -> ctx cycle that would keep a 128 MiB-rounded arena alive after a
@@ -106,6 +122,8 @@ class _HierEncoder(torch.autograd.Function):
             # second time" error instead of failing on a cleared attribute
             ctx.save_for_backward(saved, roots, hroot, hnode, hinter, hatom, *params)
             ctx.dims, ctx.grad_sink = dims, grad_sink
+            ctx.caller_stream = CALLER_STREAM[0]
+            ctx.narrow = narrow
         return hroot, hnode, hinter, hatom
 
     @staticmethod
@@ -146,11 +164,20 @@ class _HierEncoder(torch.autograd.Function):
         parr, garr = _ptr_array(params), _ptr_array(grads)
 
         def run(phase):
-            _lib.check(lib.ggpm_encoder_backward(ctypes.byref(dims), parr, garr, P(roots), P(saved), saved.numel(),
-                                                 P(hroot), P(hnode), P(hinter), P(hatom), P(douts[0]), P(douts[1]),
-                                                 P(douts[2]), P(douts[3]), P(work), work_bytes, phase, F_._stream(),
-                                                 side_p), "encoder_backward")
+            if getattr(ctx, "narrow", False):
+                lib.ggpm_level_prefer_narrow(1)
+            try:
+                _lib.check(lib.ggpm_encoder_backward(ctypes.byref(dims), parr, garr, P(roots), P(saved), saved.numel(),
+                                                     P(hroot), P(hnode), P(hinter), P(hatom), P(douts[0]), P(douts[1]),
+                                                     P(douts[2]), P(douts[3]), P(work), work_bytes, phase, F_._stream(),
+                                                     side_p), "encoder_backward")
+            finally:
+                if getattr(ctx, "narrow", False):
+                    lib.ggpm_level_prefer_narrow(0)
 
+        caller = getattr(ctx, "caller_stream", None)
+        if caller is not None and caller != torch.cuda.current_stream():
+            F_._join_later(caller, torch.cuda.current_stream())
         if sink is not None and side is not None and sink.wants_early_bucket():
             run(1)                      # everything but the atom level; its gradients complete on the second stream
             with torch.cuda.stream(side):

@@ -46,6 +46,12 @@ int ggpm_version(void);
 const char* ggpm_error_string(int code);
 /* Padded feature stride used by the message kernels: H rounded up to a multiple of 16. */
 int ggpm_padded_hidden(int H);
+/* A stream restricted to the compute units named by `mask` (`words` uint32; bit i = CU i as the driver numbers them) and
+ * the device's CU count.  Used by ggpm_amd/decoder.py / property_vae.py to give the two independent chains of the full VAE
+ * step (HierMPNDecoder's atom level, ggpm/decoder.py:201-222, and HierMPNEncoder, ggpm/encoder.py:140-157) disjoint shares of
+ * the chip.  The stream is never destroyed.  GGPM_ERR_UNSUPPORTED when the runtime declines the mask. */
+int ggpm_stream_create_cu_mask(const uint32_t* mask, int words, void** out);
+int ggpm_device_cu_count(int* out);
 
 /* ------------------------------------------------------------------ graph layout
  * A0 (ggpm/mol_graph.py:238-281, create_pad_tensor ggpm/nnutils.py:105-110): agraph/bgraph/cgraph
@@ -328,6 +334,11 @@ void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
  *   ggpm_backward_scatter_state(dst_h, dst_c, idx): the NEXT ggpm_*_sparse_backward of this thread ADDS the gradient of the
  *   incoming state of row r to dst_h[idx[r]] (dst_c likewise; idx unique, rows with idx[r] < 0 dropped) inside its last
  *   launch; dHin / dCin are not written.  Rows are [Hp] floats.  One call consumes the setting. */
+/* ggpm_level_prefer_narrow(1): until switched off again, the dense GRU level calls of this thread use two row tiles per
+ * workgroup whatever the level's size, i.e. half as many workgroups (same arithmetic per row, bit-identical results).  For a
+ * level that runs BESIDE a latency-bound chain on another stream -- the encoder next to the decoder's atom level in the
+ * full VAE step (ggpm/property_vae.py:47-58 runs them one after the other) -- this leaves the chain's launches free CUs. */
+void ggpm_level_prefer_narrow(int yes);
 void ggpm_forward_gather_state(const float* src_h, const float* src_c, const int32_t* idx);
 void ggpm_backward_scatter_state(float* dst_h, float* dst_c, const int32_t* idx);
 size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows);
