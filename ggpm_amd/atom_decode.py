@@ -874,7 +874,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
                     F_.mark("bwd: atom level's tail issued")
                 main.wait_stream(atom_stream)
                 for prm, g in zip(params_ref, grads):
-                    g.record_stream(main)
+                    F_.hand_to(g, main)
                     F_._add_to_grad(prm, g)
             torch.autograd.Variable._execution_engine.queue_callback(finish)
             return (None,) * (10 + len(params))

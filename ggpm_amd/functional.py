@@ -563,10 +563,26 @@ def _side_stream(device) -> torch.cuda.Stream:
     return _SIDE[key]
 
 
+# A gradient tensor computed on a helper stream (second stream, atom-level stream) and then read on the main stream
+# (optimizer, clipping, the flat-buffer pack) would ordinarily be marked with ``record_stream(main)``.  On ROCm every such
+# mark costs an event record on that stream when the tensor is released -- ~4.7 us of queue time each, and the ~55
+# gradients of a VAE step are released together right in front of the optimizer launch (0.25 ms of idle GPU, measured:
+# tools/probe/free_stall_probe.py).  The mark is not needed here: a published gradient stays referenced by ``param.grad``
+# until the optimizer side releases it, i.e. after everything that reads it has been ENQUEUED on the main stream, and every
+# helper stream of this package waits for the main stream (``wait_stream(main)``) before the first allocation of its next use
+# -- the block cannot be handed out again in front of its readers.  GGPM_RECORD_GRADS=1 restores the marks.
+_RECORD_GRADS = os.environ.get("GGPM_RECORD_GRADS", "0") == "1"
+
+
+def hand_to(g: torch.Tensor, main: torch.cuda.Stream) -> None:
+    if _RECORD_GRADS:
+        g.record_stream(main)
+
+
 def _accumulate_grad(param: torch.Tensor, g: torch.Tensor, main: torch.cuda.Stream) -> None:
     """param.grad (+)= g on the CURRENT (side) stream."""
     if param.grad is None:
-        g.record_stream(main)
+        hand_to(g, main)
         param.grad = g
     else:
         param.grad.add_(g)
@@ -709,7 +725,7 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
 
     def publish(param, g):
         if side is not None:               # computed early: published by the end-of-backward flush (see above)
-            g.record_stream(main)
+            hand_to(g, main)
             _DEFER["pending"].append((param, g))
         else:
             _add_to_grad(param, g)
