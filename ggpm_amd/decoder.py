@@ -445,7 +445,10 @@ def _accuracy(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
 
 
 def _head_streams_enabled() -> bool:
-    return os.environ.get("GGPM_HEAD_STREAMS", "1") != "0"
+    # Opt-in experiment: the attachment head on a stream of its own measured -0.05 ms on a 9 ms step
+    # (the host, not the GPU, paces that part of the backward) and two gloo ranks sharing ONE GPU
+    # (tests/test_aa_data_parallel_gpu.py) stopped making progress with it.
+    return os.environ.get("GGPM_HEAD_STREAMS", "0") == "1"
 
 
 class HierMPNDecoder(ScoreHeads):

@@ -10,7 +10,12 @@ class A:
     steps, pool, host_input = 10, 4, False
 
 
-wl = bench.VaeWorkload(bench.CONFIGS[1], os.environ.get("RNN", "GRU"), A, torch.device("cuda:0"))
+if os.environ.get("ENCODER"):          # the headline workload: encoder + KL heads + optimizer
+    class B:
+        steps, pool, host_input, warmup, no_full_depth = 10, 4, False, 4, True
+    wl = bench.Workload(bench.CONFIGS[1], os.environ.get("RNN", "GRU"), B, 0, 1, torch.device("cuda:0"))
+else:
+    wl = bench.VaeWorkload(bench.CONFIGS[1], os.environ.get("RNN", "GRU"), A, torch.device("cuda:0"))
 if os.environ.get("IN_LOOP"):
     wl.step = wl.step_in_loop
 for i in range(6):
