@@ -306,6 +306,54 @@ def test_encoder_is_bitwise_reproducible(name):
 
 
 
+@pytest.mark.parametrize("name", ["tiny_gru_s1", "cfg_gru_s0", "cfg_gru_s1"])
+def test_narrow_level_kernels_agree_with_the_default_form(name):
+    """ggpm_level_prefer_narrow (the encoder beside the decoder's atom level in the full VAE step): two row tiles per
+    workgroup, half as many workgroups.  The same products in the same order per row; the two template instantiations
+    differ in how the compiler contracts the gate expressions into fused multiply-adds, so the results agree to rounding
+    (a few ulp per depth step; 5e-6 norm-wise after 20 steps at H = 300, a twentieth of the parity bar), not bit for bit.
+    The golden-vector tests of the full VAE step run WITH the narrow form."""
+    from ggpm_amd import fused
+    g = Golden(name)
+    model = _build_encoder(g)
+    res = []
+    for narrow in (False, True):
+        model.zero_grad(set_to_none=True)
+        fused.NARROW[0] = narrow
+        try:
+            z, kl, outs = model(g.numpy_tensors(), perturb_z=False)
+        finally:
+            fused.NARROW[0] = False
+        (kl + sum((o * o).sum() for o in outs)).backward()
+        res.append([o.detach().clone() for o in outs] + [p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*res):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-30), (float((a - b).abs().max()), scale)
+
+
+def test_cu_masked_stream_runs_kernels():
+    """ggpm_stream_create_cu_mask: a stream restricted to the first 64 compute units is a usable stream (the experiment
+    of DESIGN.md section 9; the entry point is part of the C ABI)."""
+    import ctypes
+    from ggpm_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_int(0)
+    assert lib.ggpm_device_cu_count(ctypes.byref(n)) == 0 and n.value >= 64
+    words = (n.value + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    mask[0] = mask[1] = 0xFFFFFFFF
+    out = ctypes.c_void_p(0)
+    assert lib.ggpm_stream_create_cu_mask(mask, words, ctypes.byref(out)) == 0 and out.value
+    s = torch.cuda.ExternalStream(out.value, device=_dev())
+    a = torch.randn(256, 256, device=_dev())
+    want = (a @ a).cpu()
+    with torch.cuda.stream(s):
+        got = a @ a
+    s.synchronize()
+    assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-4)
+    assert lib.ggpm_stream_create_cu_mask(None, words, ctypes.byref(out)) != 0
+
+
 @pytest.mark.parametrize("name", case_names(motif=True))
 def test_motif_encoder_matches_reference_golden(name):
     """MotifEncoder drop-in (reference ggpm/encoder.py:252-341) vs vectors produced by the reference itself."""

@@ -165,6 +165,30 @@ def test_schedule_ahead_loop_equals_the_plain_loop():
         assert torch.equal(pa[k], pb[k]), k
 
 
+def test_metrics_read_through_the_event_equal_the_blocking_read(monkeypatch):
+    """StepMetrics: the six values copied to pinned memory behind the forward and read through the copy's event are the
+    floats the blocking read returns (GGPM_METRICS_ASYNC=0) and the reference's ``.item()`` values (GGPM_LAZY_METRICS=0)."""
+    from ggpm_amd import synth
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(40, 120)
+    configs = _Configs(vocab, rnn_type="GRU", hidden_size=64, embed_size=64, latent_size=16, depthT=6, depthG=6, dropout=0.0)
+    torch.manual_seed(5)
+    model = HierPropertyVAE(configs).to(_dev())
+    _init_like_vae_train(model)
+    batch = synth.train_batch(synth.random_batch(21, 6, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120))
+    got = []
+    for lazy, asyn in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("GGPM_LAZY_METRICS", lazy)
+        monkeypatch.setenv("GGPM_METRICS_ASYNC", asyn)
+        loss, m = model(*batch, beta=0.3, perturb_z=False)
+        loss.backward()
+        model.zero_grad()
+        got.append({k: float(v) for k, v in m.items()})
+    assert set(got[0]) == {"Loss", "KL:", "Word", "I-Word", "Topo", "Assm"}
+    assert got[0] == got[1] == got[2], got
+
+
 def test_refilling_a_resident_index_tensor_rebuilds_its_csr():
     """VERDICT r2 weak #9: the CSR memo hangs on the index tensor object; an in-place refill must invalidate it."""
     from ggpm_amd import functional as F_
