@@ -652,6 +652,11 @@ inline int pick_tg(int E1, int NT) {
         int v = atoi(e);
         if (v >= 1 && v <= 64 && (E1 + 15) / 16 <= 64) return v < NT ? v : NT;
     }
+    static const char* const tg_large_env = getenv("GGPM_TG_LARGE");
+    if (const char* e = tg_large_env) {      // tuning override for the large (atom) levels only
+        int v = atoi(e);
+        if (v >= 1 && v <= 64 && (E1 + 15) / 16 > 64) return v < NT ? v : NT;
+    }
     return ggpm_tiles_per_group(E1, NT);
 }
 
