@@ -806,6 +806,143 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, in
         for (int j = 0; j < 5; ++j) slab[(i * 5 + j) * 64] = acc[i][j];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same contraction at fp32 accuracy on the bf16 matrix pipe ("split" operands).  Every fp32 value is the EXACT sum of
+// three bf16 values, x = x1 + x2 + x3 with x1 = rne(x), x2 = rne(x - x1), x3 = x - x1 - x2 (8 + 8 + 8 mantissa bits; both
+// subtractions are exact), so a product a*b is the sum of nine bf16 x bf16 products, each exact in the fp32 accumulator.
+// The three smallest (a2*b3, a3*b2, a3*b3: below 2^-24 of |a||b|, i.e. below the rounding of the fp32 product itself) are
+// dropped; the other six are six v_mfma_f32_16x16x32_bf16 per fragment pair instead of eight v_mfma_f32_16x16x4_f32 --
+// at 16x the rate, 2.7x less matrix-pipe time for the same sum to within fp32 rounding.  That makes the launch what the
+// bf16 one above is: bound by the operand stream from HBM, not by the pipe (H = 300, K = 54 200: 107 us on fp32 MFMA,
+// 49 us with rounded bf16 operands).  Structure as gemm_tn_tall_bf16; the LDS image holds three bf16 planes per operand
+// (129 KB for the two buffers: one workgroup per CU, which is enough here because the loads of step s + 2 fly under the six
+// products of step s).  Same fragment-order slabs, so tall_reduce serves all three kernels.
+__global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, int splits) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 Lsp[];      // [2 buffers][3 planes][BTK * BLD]
+    constexpr int PLANE = BTK * BLD;
+    const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const unsigned logical = xcd * xq + min(xcd, xr) + (L >> 3);        // tiles of one K chunk share an XCD's L2
+    const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y;
+    const int bzz = logical / (gridDim.x * gridDim.y);
+    const GemmArgs& g = gg.p[bzz / splits];
+    const int bz = bzz % splits;
+    const int m0 = by * TM, n0 = bx * TN;
+    const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+    const float* P = isb ? g.B : g.A;
+    const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
+    unsigned voff[10];
+    int loff[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int f = (threadIdx.x & 127) + 128 * i;
+        const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
+        loff[i] = k * BLD + isb * TM + c;
+        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
+    }
+    const unsigned vstep = (unsigned)BTK * ld * 4;
+    f32x4 r[10];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+            if (voff[i] != 0xffffff00u) voff[i] += vstep;
+        }
+    };
+    auto put = [&](int buf) {
+        __bf16* base = Lsp + (size_t)buf * 3 * PLANE;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            gbf16x4 w1, w2, w3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = r[i][e];
+                const __bf16 x1 = (__bf16)x;
+                const float r1 = x - (float)x1;          // exact
+                const __bf16 x2 = (__bf16)r1;
+                const float r2 = r1 - (float)x2;         // exact, and representable in 8 bits
+                w1[e] = x1; w2[e] = x2; w3[e] = (__bf16)r2;
+            }
+            *reinterpret_cast<gbf16x4*>(base + loff[i]) = w1;
+            *reinterpret_cast<gbf16x4*>(base + PLANE + loff[i]) = w2;
+            *reinterpret_cast<gbf16x4*>(base + 2 * PLANE + loff[i]) = w3;
+        }
+    };
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int fa0 = (4 * grp + q) * BLD + wm * 80 + 4 * pp;
+    const int fb0 = (4 * grp + q) * BLD + TM + wn * 80 + 4 * pp;
+    typedef __attribute__((address_space(3))) gs16x4* lds_v4;
+    auto frag = [&](const __bf16* base) -> gbf16x8 {
+        const gs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+        const gs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 16 * BLD));
+        gs16x4 v[2] = {lo, hi};
+        return __builtin_bit_cast(gbf16x8, v);
+    };
+
+    fetch();
+    put(0);
+    fetch();
+    ggpm_lds_barrier();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
+        const __bf16* img = Lsp + (size_t)cur * 3 * PLANE;
+        gbf16x8 fa[3][5], fb[3][5];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                fa[pl][i] = frag(img + pl * PLANE + fa0 + 16 * i);
+                fb[pl][i] = frag(img + pl * PLANE + fb0 + 16 * i);
+            }
+        put(cur ^ 1);
+        fetch();
+        // six passes over the 25 accumulators (smallest terms first): consecutive MFMAs never share an accumulator, so none
+        // of them waits for the one before it
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+        ggpm_lds_barrier();
+    }
+    f32x4* slab = reinterpret_cast<f32x4*>(g.ws) +
+                  ((((size_t)bz * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + wave) * 25) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) slab[(i * 5 + j) * 64] = acc[i][j];
+}
+constexpr size_t GGPM_TALL_SPLIT_LDS = (size_t)2 * 3 * BTK * BLD * sizeof(__bf16);
+// 0: fp32 MFMA for the fp32 tall contractions (the round-1 kernel); 1 (default): split operands on the bf16 pipe
+inline int tall_split_mode() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT"); return e ? atoi(e) : 1; }(); return v; }
+inline int tall_split_wgs() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT_WGS"); return e ? atoi(e) : 512; }(); return v; }
+inline void launch_tall_split(const GemmGroupArgs& gg, dim3 grid, int splits, hipStream_t s) {
+    static bool ready = false;
+    if (!ready) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_tall_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)GGPM_TALL_SPLIT_LDS);
+        ready = true;
+    }
+    gemm_tn_tall_split<<<grid, 256, GGPM_TALL_SPLIT_LDS, s>>>(gg, splits);
+}
+
 // Sums the fragment-order slabs of gemm_tn_tall over the K chunks (fixed order: four interleaved partial sums per
 // workgroup, combined as (0+1)+(2+3)) and writes C.  One workgroup per (tile, wave, 16 x 16 block).
 __global__ void __launch_bounds__(256) tall_reduce(GemmGroupArgs gg, int splits, int tiles_n, int tiles) {
@@ -1001,8 +1138,25 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
     if (use_tall && trans_a && !trans_b && g.vecA && g.vecB && lda >= ggpm_round_up(M, 4) && ldb >= ggpm_round_up(N, 4) &&
         tall_shape(M, N, K) && n_pad <= ggpm_round_up(N, TN) && (size_t)K * lda * 4 < 0xffffff00ull && (size_t)K * ldb * 4 < 0xffffff00ull) {
-        int splits = splitk_ws ? tall_splits(M, N, K) : 1;
         const size_t slab = tall_slab_bytes(M, N);
+        if (tall_split_mode() && splitk_ws && splitk_ws_bytes >= slab) {
+            // split operands on the bf16 pipe (fp32 accuracy, operand-stream bound): always through slabs + tall_reduce
+            // (which applies bias / accumulate / activation)
+            int sp = tall_splits(M, N, K, tall_split_wgs());
+            if ((size_t)sp * slab > splitk_ws_bytes) sp = (int)(splitk_ws_bytes / slab);
+            if (sp < 1) sp = 1;
+            g.k_chunk = ggpm_round_up(ggpm_ceil_div(K, sp), BTK);
+            sp = ggpm_ceil_div(K, g.k_chunk);
+            g.ws = splitk_ws;
+            const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
+            GemmGroupArgs gg;
+            for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
+            launch_tall_split(gg, dim3(tiles_n, tiles_m, sp), sp, s);
+            tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, sp, tiles_n, tiles_n * tiles_m);
+            GGPM_CHECK_LAUNCH();
+            return GGPM_OK;
+        }
+        int splits = splitk_ws ? tall_splits(M, N, K) : 1;
         if (splits > 1 && (size_t)splits * slab > splitk_ws_bytes) splits = (int)(splitk_ws_bytes / slab);
         if (splits < 1) splits = 1;
         g.k_chunk = ggpm_round_up(ggpm_ceil_div(K, splits), TK);
@@ -1097,16 +1251,17 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     // (bf16 operands exist in the tall kernel only: a group that does not qualify falls back to fp32 products, which is
     // the more accurate side of the stated tolerance)
     bool ok = use_tall && (count > 1 || bf16) && ws != nullptr;
+    const bool split = !bf16 && tall_split_mode() != 0;      // fp32 accuracy on the bf16 pipe (gemm_tn_tall_split)
     int splits = 1 << 30;
     for (int i = 0; i < count && ok; ++i) {
         ok = (p[i].lda & 3) == 0 && (p[i].ldb & 3) == 0 && ((uintptr_t)p[i].A & 15) == 0 && ((uintptr_t)p[i].B & 15) == 0 &&
              p[i].lda >= ggpm_round_up(M, 4) && p[i].ldb >= ggpm_round_up(N, 4) && tall_shape(M, N, K[i]) &&
              p[i].n_pad <= ggpm_round_up(N, TN) && p[i].n_pad >= N && p[i].n_pad <= p[i].ldc &&
              (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
-        splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : 0));
+        splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : (split ? tall_split_wgs() / count : 0)));
     }
     if (ok) splits = min(splits, (int)(ws_bytes / (count * slab)));      // the group shares the workspace
-    if (!ok || splits < (bf16 ? 1 : 2)) {
+    if (!ok || splits < ((bf16 || split) ? 1 : 2)) {
         for (int i = 0; i < count; ++i) {
             const int rc = ggpm_gemm(1, 0, M, N, K[i], p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].n_pad,
                                      p[i].bias, p[i].accumulate, p[i].act, p[i].zero_row0, ws, ws_bytes, stream);
@@ -1119,13 +1274,14 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     GemmGroupArgs gg;
     for (int i = 0; i < count; ++i) {
         fill_args(gg.p[i], M, N, K[i], p[i]);
-        gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), bf16 ? BTK : TK);
+        gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), (bf16 || split) ? BTK : TK);
         gg.p[i].ws = ws + (size_t)i * splits * (slab / sizeof(float));
     }
     for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
     if (bf16) gemm_tn_tall_bf16<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    else if (split) launch_tall_split(gg, dim3(tiles_n, tiles_m, splits * count), splits, s);
     else gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
     tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits, tiles_n, tiles_n * tiles_m);
     GGPM_CHECK_LAUNCH();

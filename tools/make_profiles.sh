@@ -29,6 +29,12 @@ rm -rf /tmp/prof_vae_loop
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_vae_loop -- python3 $B --only-vae --vae-profile in_loop > $OUT/prof_vae_loop.log 2>&1
 python3 $ROOT/tools/prof_summary.py /tmp/prof_vae_loop --steps 20 --label "full VAE step GRU as vae_train.py:78 calls it: host batch in, schedule + uploads inside the step, no memoised index structures" > $OUT/vae_GRU_in_loop_kernel_stats.txt
 
+# the unprofiled step: host / GPU time of the package's phase marks (no profiler attached)
+cd $ROOT
+PIPE=1 STEPS=30 python3 tools/vae_phase_times.py > $OUT/vae_GRU_phase_times.txt 2>&1
+RNN=LSTM PIPE=1 STEPS=30 python3 tools/vae_phase_times.py > $OUT/vae_LSTM_phase_times.txt 2>&1
+cd /tmp
+
 # HBM traffic of the depth kernels: two separate PMC passes
 for C in GRU LSTM; do
   for CTR in FETCH_SIZE WRITE_SIZE; do

@@ -29,7 +29,9 @@ for rows in (38500, 54200):
         _lib.check(lib.ggpm_lstm_weight_grads_stacked(rows, rq, H, P(A[0]), P(A[1]), P(A[2]), P(S), P(DQ), P(Hs), P(out[0]), H,
                                                       P(out[1]), H, P(out[2]), H, P(out[3]), H, P(ws), ws.numel() * 4, s), "lstm")
 
-    for name, fn, nm in (("GRU (3 products)", gru, 3), ("LSTM (4 products)", lstm, 4)):
+    for name, fn, nm, dt in (("GRU (3 products)", gru, 3, 0), ("LSTM (4 products)", lstm, 4, 0),
+                             ("GRU bf16 operands", gru, 3, 1), ("LSTM bf16 operands", lstm, 4, 1)):
+        lib.ggpm_level_gate_dtype(dt)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -40,3 +42,4 @@ for rows in (38500, 54200):
         ms = (time.perf_counter() - t0) / 20 * 1e3
         fl = 2.0 * H * H * (rows * (nm - 1) + rq)
         print("rows %d  %-18s %.3f ms  %.1f TFLOP/s" % (rows, name, ms, fl / ms / 1e9))
+    lib.ggpm_level_gate_dtype(0)
