@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, in
 // 49 us with rounded bf16 operands).  Structure as gemm_tn_tall_bf16; the LDS image holds three bf16 planes per operand
 // (129 KB for the two buffers: one workgroup per CU, which is enough here because the loads of step s + 2 fly under the six
 // products of step s).  Same fragment-order slabs, so tall_reduce serves all three kernels.
-__global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, int splits) {
+__global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, int splits) {
     extern __shared__ __attribute__((aligned(16))) __bf16 Lsp[];      // [2 buffers][3 planes][BTK * BLD]
     constexpr int PLANE = BTK * BLD;
     const unsigned T = gridDim.x * gridDim.y * gridDim.z;
@@ -830,28 +830,34 @@ __global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
     const int bz = bzz % splits;
     const int m0 = by * TM, n0 = bx * TN;
     const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    // eight waves: quadrant (wave & 3) of the 160 x 160 tile as in the other tall kernels, and HALF of the six products
+    // (wave >> 2): half 0 forms a1*b1 + a1*b2 + a1*b3, half 1 a2*b1 + a2*b2 + a3*b1.  Two waves per SIMD, so one wave's
+    // operand split / LDS traffic / barrier wait runs under the other's MFMAs; the two halves land in two slabs that
+    // tall_reduce adds like two K chunks.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int quad = wave & 3, half = wave >> 2;
+    const int wm = quad >> 1, wn = quad & 1;
 
-    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+    // waves 0-3 stage the A rows of a step, waves 4-7 the B rows: 32 rows x 40 float4 = 5 per thread
+    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const float* P = isb ? g.B : g.A;
     const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
-    unsigned voff[10];
-    int loff[10];
+    unsigned voff[5];
+    int loff[5];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const int f = (threadIdx.x & 127) + 128 * i;
+    for (int i = 0; i < 5; ++i) {
+        const int f = (threadIdx.x & 255) + 256 * i;
         const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
         loff[i] = k * BLD + isb * TM + c;
         voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
     }
     const unsigned vstep = (unsigned)BTK * ld * 4;
-    f32x4 r[10];
+    f32x4 r[5];
     auto fetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 5; ++i) {
             r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
             if (voff[i] != 0xffffff00u) voff[i] += vstep;
         }
@@ -859,7 +865,7 @@ __global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
     auto put = [&](int buf) {
         __bf16* base = Lsp + (size_t)buf * 3 * PLANE;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 5; ++i) {
             gbf16x4 w1, w2, w3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -892,6 +898,10 @@ __global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
         gs16x4 v[2] = {lo, hi};
         return __builtin_bit_cast(gbf16x8, v);
     };
+    // planes of the three products of this wave's half (smallest first): half 0: (a1,b3) (a1,b2) (a1,b1); half 1:
+    // (a3,b1) (a2,b2) (a2,b1) -- two distinct A planes and B planes at most, four fragment sets of five
+    const int pa0 = half ? 2 : 0, pa1 = half ? 1 : 0;       // A planes: first product / the other two
+    const int pb0 = half ? 0 : 2, pb1 = 1, pb2 = 0;          // B planes of the three products
 
     fetch();
     put(0);
@@ -900,30 +910,34 @@ __global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
         const __bf16* img = Lsp + (size_t)cur * 3 * PLANE;
-        gbf16x8 fa[3][5], fb[3][5];
+        gbf16x8 fa0v[5], fa1v[5], fb0v[5], fb1v[5], fb2v[5];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int i = 0; i < 5; ++i) {
+            fa0v[i] = frag(img + pa0 * PLANE + fa0 + 16 * i);
+            fa1v[i] = frag(img + pa1 * PLANE + fa0 + 16 * i);
+            fb0v[i] = frag(img + pb0 * PLANE + fb0 + 16 * i);
+            fb1v[i] = frag(img + pb1 * PLANE + fb0 + 16 * i);
+            fb2v[i] = frag(img + pb2 * PLANE + fb0 + 16 * i);
+        }
+        put(cur ^ 1);           // rows of step s+1 (loaded a step ago); every wave finished reading that buffer before the
+        fetch();                // barrier that ended step s-1.  Then the loads of step s+2 fly under this step's MFMAs
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                fa[pl][i] = frag(img + pl * PLANE + fa0 + 16 * i);
-                fb[pl][i] = frag(img + pl * PLANE + fb0 + 16 * i);
-            }
-        put(cur ^ 1);
-        fetch();
-        // six passes over the 25 accumulators (smallest terms first): consecutive MFMAs never share an accumulator, so none
-        // of them waits for the one before it
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0v[i], fb0v[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1v[i], fb1v[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1v[i], fb2v[j], acc[i][j], 0, 0, 0);
         ggpm_lds_barrier();
     }
+    // two slabs per K chunk (one per half) in the fragment order of gemm_tn_tall
     f32x4* slab = reinterpret_cast<f32x4*>(g.ws) +
-                  ((((size_t)bz * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + wave) * 25) * 64 + lane;
+                  (((((size_t)bz * 2 + half) * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + quad) * 25) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -932,7 +946,7 @@ __global__ void __launch_bounds__(256, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
 constexpr size_t GGPM_TALL_SPLIT_LDS = (size_t)2 * 3 * BTK * BLD * sizeof(__bf16);
 // 0: fp32 MFMA for the fp32 tall contractions (the round-1 kernel); 1 (default): split operands on the bf16 pipe
 inline int tall_split_mode() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT"); return e ? atoi(e) : 1; }(); return v; }
-inline int tall_split_wgs() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT_WGS"); return e ? atoi(e) : 512; }(); return v; }
+inline int tall_split_wgs() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT_WGS"); return e ? atoi(e) : 256; }(); return v; }
 inline void launch_tall_split(const GemmGroupArgs& gg, dim3 grid, int splits, hipStream_t s) {
     static bool ready = false;
     if (!ready) {
@@ -940,7 +954,7 @@ inline void launch_tall_split(const GemmGroupArgs& gg, dim3 grid, int splits, hi
                                   (int)GGPM_TALL_SPLIT_LDS);
         ready = true;
     }
-    gemm_tn_tall_split<<<grid, 256, GGPM_TALL_SPLIT_LDS, s>>>(gg, splits);
+    gemm_tn_tall_split<<<grid, 512, GGPM_TALL_SPLIT_LDS, s>>>(gg, splits);
 }
 
 // Sums the fragment-order slabs of gemm_tn_tall over the K chunks (fixed order: four interleaved partial sums per
@@ -1139,11 +1153,11 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     if (use_tall && trans_a && !trans_b && g.vecA && g.vecB && lda >= ggpm_round_up(M, 4) && ldb >= ggpm_round_up(N, 4) &&
         tall_shape(M, N, K) && n_pad <= ggpm_round_up(N, TN) && (size_t)K * lda * 4 < 0xffffff00ull && (size_t)K * ldb * 4 < 0xffffff00ull) {
         const size_t slab = tall_slab_bytes(M, N);
-        if (tall_split_mode() && splitk_ws && splitk_ws_bytes >= slab) {
+        if (tall_split_mode() && splitk_ws && splitk_ws_bytes >= 2 * slab) {
             // split operands on the bf16 pipe (fp32 accuracy, operand-stream bound): always through slabs + tall_reduce
             // (which applies bias / accumulate / activation)
             int sp = tall_splits(M, N, K, tall_split_wgs());
-            if ((size_t)sp * slab > splitk_ws_bytes) sp = (int)(splitk_ws_bytes / slab);
+            if ((size_t)2 * sp * slab > splitk_ws_bytes) sp = (int)(splitk_ws_bytes / (2 * slab));      // two slabs per K chunk
             if (sp < 1) sp = 1;
             g.k_chunk = ggpm_round_up(ggpm_ceil_div(K, sp), BTK);
             sp = ggpm_ceil_div(K, g.k_chunk);
@@ -1152,7 +1166,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
             GemmGroupArgs gg;
             for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
             launch_tall_split(gg, dim3(tiles_n, tiles_m, sp), sp, s);
-            tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, sp, tiles_n, tiles_n * tiles_m);
+            tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, 2 * sp, tiles_n, tiles_n * tiles_m);
             GGPM_CHECK_LAUNCH();
             return GGPM_OK;
         }
@@ -1260,7 +1274,8 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
              (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
         splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : (split ? tall_split_wgs() / count : 0)));
     }
-    if (ok) splits = min(splits, (int)(ws_bytes / (count * slab)));      // the group shares the workspace
+    const int slabs_per_chunk = split ? 2 : 1;      // (the split kernel leaves one slab per half of its six products)
+    if (ok) splits = min(splits, (int)(ws_bytes / (count * slab * slabs_per_chunk)));      // the group shares the workspace
     if (!ok || splits < ((bf16 || split) ? 1 : 2)) {
         for (int i = 0; i < count; ++i) {
             const int rc = ggpm_gemm(1, 0, M, N, K[i], p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].n_pad,
@@ -1275,7 +1290,7 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     for (int i = 0; i < count; ++i) {
         fill_args(gg.p[i], M, N, K[i], p[i]);
         gg.p[i].k_chunk = ggpm_round_up(ggpm_ceil_div(K[i], splits), (bf16 || split) ? BTK : TK);
-        gg.p[i].ws = ws + (size_t)i * splits * (slab / sizeof(float));
+        gg.p[i].ws = ws + (size_t)i * splits * slabs_per_chunk * (slab / sizeof(float));
     }
     for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
     hipStream_t s = (hipStream_t)stream;
@@ -1283,7 +1298,7 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     if (bf16) gemm_tn_tall_bf16<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
     else if (split) launch_tall_split(gg, dim3(tiles_n, tiles_m, splits * count), splits, s);
     else gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
-    tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits, tiles_n, tiles_n * tiles_m);
+    tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits * slabs_per_chunk, tiles_n, tiles_n * tiles_m);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
