@@ -79,6 +79,25 @@ def test_gemm_against_fp64(ta, tb, M, N, K):
     assert rel_err(C.cpu().numpy()[:, :N], ref2) < tol
 
 
+@pytest.mark.parametrize("M,N,K,ld", [(300, 300, 57011, 304), (600, 600, 20000, 608), (250, 250, 38500, 256)])
+def test_tall_contraction_on_split_operands_keeps_fp32_accuracy(M, N, K, ld):
+    """The weight-gradient contractions run on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16
+    values and six of the nine partial products kept (csrc/gemm.hip: gemm_tn_tall_split): the result must be as close to
+    the fp64 product of the SAME fp32 operands as an fp32 accumulation chain is -- no bf16-sized error.  Operands with a
+    wide dynamic range (rows scaled by 1e-3 ... 1e3) so that a dropped low-order term would show."""
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(K + M)
+    scale = np.exp(rs.uniform(np.log(1e-3), np.log(1e3), size=(K, 1))).astype(np.float32)
+    A = (rs.standard_normal((K, ld)) * scale).astype(np.float32)
+    B = (rs.standard_normal((K, ld)) / scale).astype(np.float32)
+    a, b = torch.from_numpy(A).to(_dev()), torch.from_numpy(B).to(_dev())
+    C = torch.empty(M, N, device=_dev())
+    F_.gemm(1, 0, M, N, K, a, ld, b, ld, C, N, N, splitk=True)
+    ref = A[:, :M].astype(np.float64).T @ B[:, :N].astype(np.float64)
+    err = rel_err(C.cpu().numpy(), ref)
+    assert err < 3e-6, err            # (rounded bf16 operands give ~3e-3 here: test_gemm_tn_bf16_against_fp64_...)
+
+
 @pytest.mark.parametrize("M,N,K,ld", [(300, 300, 57011, 304), (600, 600, 20000, 608), (290, 300, 9001, 304),
                                       (600, 600, 6150, 608), (160, 160, 6144, 160), (300, 600, 12345, 608)])
 def test_gemm_tn_bf16_against_fp64_of_the_rounded_operands(M, N, K, ld):
