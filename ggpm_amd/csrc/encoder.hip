@@ -165,6 +165,8 @@ inline int lq(int level, int which) { return P_LEVEL0 + level * Q_COUNT + which;
 inline int lwo(bool lstm, int level) { return lstm ? lq(level, Q_WO) : lp(level, L_WO); }
 inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level, L_BO); }
 
+// GGPM_SPLIT_TAIL=0: the input-half gradients of the last level behind its tall contractions on the second stream again
+inline bool split_tail_enabled() { static const bool v = !(getenv("GGPM_SPLIT_TAIL") && atoi(getenv("GGPM_SPLIT_TAIL")) == 0); return v; }
 inline int wgrad_overlap_mode() {
     static const int v = getenv("GGPM_WGRAD_OVERLAP") ? atoi(getenv("GGPM_WGRAD_OVERLAP")) : 0;
     return v;
@@ -641,7 +643,8 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
         float* const dW0 = dW[0]; float* const dW1 = dW[1]; float* const dW2 = dW[2]; float* const dW3 = dW[3];
         float* const db0 = db[0]; float* const db1 = db[1]; float* const db2 = db[2]; float* const db3 = db[3];
         const float* Hs = L.Hs; const float* St = L.St;
-        return st.on_side([=]() -> int {
+        // input halves + bias sums from the summed gate-input gradients
+        auto x_part = [=](ggpm_stream_t sx) -> int {
             float* const dWk[4] = {dW0, dW1, dW2, dW3};
             float* const dbk[4] = {db0, db1, db2, db3};
             if (skip_xsum) {
@@ -650,26 +653,36 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                 const int lo_ = blo < 1 ? 1 : blo;      // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
                 float* const src[3] = {DI, DO, DU};
                 for (int k = 0; k < 3; ++k)
-                    CK(ggpm_sum_slots(src[k] + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + (size_t)k * slot, sw));
+                    CK(ggpm_sum_slots(src[k] + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + (size_t)k * slot, sx));
             }
+            if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
+                GgpmGemmProblem gp[4];
+                for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
+                CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, sx));
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0,
+                                 wc.skws, wc.skws_bytes, sx));
+            }
+            for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, dbk[k], wc.csws, sx));
+            return GGPM_OK;
+        };
+        // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE,
+        // beside the tall contractions on the second stream, instead of behind them
+        const bool x_on_main = skip_xsum && st.side != nullptr && split_tail_enabled();
+        const int rc_side = st.on_side([=]() -> int {
+            float* const dWk[4] = {dW0, dW1, dW2, dW3};
+            if (!x_on_main) CK(x_part(sw));
             ggpm_wgrad_lo_depth(blo);
             {       // (thread-local like the hint above: this body may run on the side worker's thread)
                 GateDtypeScope tall_dtype(gate_dtype);
                 CK(ggpm_lstm_weight_grads(E1, H, depth, Hs, St, level_work, wc.level_work_bytes, dWk[0] + I, I + H, dWk[1] + I,
                                           I + H, dWk[2] + I, I + H, dWk[3] + I, I + H, sw));
             }
-            if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
-                GgpmGemmProblem gp[4];
-                for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
-                CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, sw));
-            } else {
-                for (int k = 0; k < 4; ++k)
-                    CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0,
-                                 wc.skws, wc.skws_bytes, sw));
-            }
-            for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, dbk[k], wc.csws, sw));
             return GGPM_OK;
         });
+        if (rc_side) return rc_side;
+        return x_on_main ? x_part(st.main) : GGPM_OK;
     }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
@@ -724,36 +737,45 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     const BwdWork wc = w;
     const float* Hs = L.Hs; const float* St = L.St;
     float* const dbu = G[lp(level, L_BU)]; float* const dbz = G[lp(level, L_BZ)]; float* const dbh = G[lp(level, L_BH)];
-    return st.on_side([=]() -> int {
+    auto x_part = [=](ggpm_stream_t sx) -> int {       // input halves + bias sums from the summed gate-input gradients
         if (skip_xsum) {
             float *DMP = nullptr, *DZP = nullptr;
             CK(ggpm_gru_backward_stashes(level_work, E1, H, depth, &DMP, &DZP));
             const int lo_ = blo < 1 ? 1 : blo;          // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
-            CK(ggpm_sum_slots(DZP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX, sw));
-            CK(ggpm_sum_slots(DMP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + 2 * slot, sw));
+            CK(ggpm_sum_slots(DZP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX, sx));
+            CK(ggpm_sum_slots(DMP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + 2 * slot, sx));
         }
+        if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
+            const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                           {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
+                                           {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
+            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, sx));
+        } else {
+            CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes, sx));
+            CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes,
+                         sx));
+            CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws,
+                         wc.skws_bytes, sx));
+        }
+        CK(ggpm_colsum(dX, Hp, E1, H, dbz, wc.csws, sx));
+        CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, dbh, wc.csws, sx));
+        return GGPM_OK;
+    };
+    // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE, beside
+    // the tall contractions on the second stream, instead of behind them
+    const bool x_on_main = skip_xsum && st.side != nullptr && !overlap && split_tail_enabled();
+    const int rc_side = st.on_side([=]() -> int {
+        if (!x_on_main) CK(x_part(sw));
         if (!overlap) {
             ggpm_wgrad_lo_depth(blo);
             GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)
             CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
                                      dbu, dWh + I, I + H, sw));
         }
-        if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
-            const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
-                                           {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
-                                           {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
-            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, sw));
-        } else {
-            CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes, sw));
-            CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes,
-                         sw));
-            CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws,
-                         wc.skws_bytes, sw));
-        }
-        CK(ggpm_colsum(dX, Hp, E1, H, dbz, wc.csws, sw));
-        CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, dbh, wc.csws, sw));
         return GGPM_OK;
     });
+    if (rc_side) return rc_side;
+    return x_on_main ? x_part(st.main) : GGPM_OK;
 }
 
 }  // namespace
