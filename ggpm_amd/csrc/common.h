@@ -83,6 +83,8 @@ int ggpm_take_wgrad_lo();
 bool ggpm_take_defer_stash(float* (&out)[4]);
 // ggpm_backward_skip_x_sums (include/ggpm_hip.h): consumed by the next dense level backward of this thread.
 bool ggpm_take_skip_x_sums();
+// ggpm_level_prefer_narrow (include/ggpm_hip.h): state of this thread's switch (mpn_gru.hip).
+bool ggpm_prefer_narrow();
 // ggpm_weights_packed (include/ggpm_hip.h): the next level / sparse call of this thread finds its packed weights in place.
 bool ggpm_take_weights_packed();
 // ggpm_forward_gather_state / ggpm_backward_scatter_state (include/ggpm_hip.h): consumed by the next sparse forward /

@@ -819,6 +819,7 @@ bool ggpm_take_scatter_state(float** dst_h, float** dst_c, const int32_t** idx) 
     return v;
 }
 extern "C" void ggpm_level_prefer_narrow(int yes) { g_prefer_narrow = yes != 0; }
+bool ggpm_prefer_narrow() { return g_prefer_narrow; }
 namespace { thread_local bool g_packed = false; }
 extern "C" void ggpm_weights_packed(int yes) { g_packed = yes != 0; }
 bool ggpm_take_weights_packed() { const bool v = g_packed; g_packed = false; return v; }

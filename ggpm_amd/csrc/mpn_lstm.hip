@@ -14,8 +14,7 @@
 
 namespace {
 
-constexpr int RT = 1;
-constexpr int ROWS = RT * 16;
+constexpr int ROWS = 16;      // rows of a row tile (the kernels take one or two per workgroup: template parameter RTT)
 
 struct LstmFwdArgs {
     int E1, Hp, tg;
@@ -39,8 +38,9 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time: s over the full row (GEMM operand), the
 // forget sum fc (and its backward coefficient) only over this workgroup's column group; then the first `tg`
 // waves run [Wi_h; Wo_h; Wu_h] . s for their output tile and the gate math.
-template <bool STASH, bool BF16>
+template <bool STASH, bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
+    constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;
@@ -122,69 +122,84 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
         if (!a.h0_zero && t < t_end) ggpm_ring_prefetch<3>(wps2, KC, t, lane, ring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
-    const int lr = lane & 15, row = r0 + lr;
+    const int lr = lane & 15;
     float* Th = lds + 2 * ROWS * LD;      // fused P3 only: the complete h' rows of this workgroup
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        const float4 xi = ggpm_ld4(a.Xi + o), xo = ggpm_ld4(a.Xo + o), xu = ggpm_ld4(a.Xu + o);
-        f32x4 acc[3][RT];
-        ggpm_zero_acc<3, RT>(acc);
+        float4 xi[RTT], xo[RTT], xu[RTT];
+        auto load_inputs = [&](int r) {
+            const int row = r0 + 16 * r + lr;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            xi[r] = ggpm_ld4(a.Xi + o); xo[r] = ggpm_ld4(a.Xo + o); xu[r] = ggpm_ld4(a.Xu + o);
+        };
+        if constexpr (RTT == 1) load_inputs(0);     // in flight under the GEMM (two row tiles: the registers go to the GEMM)
+        f32x4 acc[3][RTT];
+        ggpm_zero_acc<3, RTT>(acc);
         if (!a.h0_zero) {
             const float* const tiles[3] = {Ts, Ts, Ts};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
-        float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
-        if (row >= a.E1) {
-            if (a.fuse_b) ggpm_st4(Th + lr * LD + c, h);
-            continue;
-        }
-        if (a.frozen && a.frozen[row]) {
-            h = ggpm_ld4(a.Hprev + o);             // gates stashed as 0 => the backward passes dh, dc through
-            cn = ggpm_ld4(a.Cprev + o);
-        } else if (row != 0 || a.frozen) {
-            const float4 pi = ggpm_f4(acc[0][0]) + xi;
-            const float4 po = ggpm_f4(acc[1][0]) + xo;
-            const float4 pu = ggpm_f4(acc[2][0]) + xu;
-            const float4 fc = ggpm_ld4(Tf + lr * LD + c);
-            gi = ggpm_sigmoid4(pi);
-            go = ggpm_sigmoid4(po);
-            gu = make_float4(tanhf(pu.x), tanhf(pu.y), tanhf(pu.z), tanhf(pu.w));
-            cn = gi * gu + fc;
-            h = go * make_float4(tanhf(cn.x), tanhf(cn.y), tanhf(cn.z), tanhf(cn.w));
-        }
-        ggpm_st4(a.Hnew + o, h);
-        ggpm_st4(a.Cnew + o, cn);
-        if (a.fuse_b) ggpm_st4(Th + lr * LD + c, h);
-        if (STASH) {
-            ggpm_st4(a.I + o, gi);
-            ggpm_st4(a.O + o, go);
-            ggpm_st4(a.U + o, gu);
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            if constexpr (RTT != 1) load_inputs(r);
+            const int lrow = 16 * r + lr, row = r0 + lrow;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
+            if (row >= a.E1) {
+                if (a.fuse_b) ggpm_st4(Th + lrow * LD + c, h);
+                continue;
+            }
+            if (a.frozen && a.frozen[row]) {
+                h = ggpm_ld4(a.Hprev + o);             // gates stashed as 0 => the backward passes dh, dc through
+                cn = ggpm_ld4(a.Cprev + o);
+            } else if (row != 0 || a.frozen) {
+                const float4 pi = ggpm_f4(acc[0][r]) + xi[r];
+                const float4 po = ggpm_f4(acc[1][r]) + xo[r];
+                const float4 pu = ggpm_f4(acc[2][r]) + xu[r];
+                const float4 fc = ggpm_ld4(Tf + lrow * LD + c);
+                gi = ggpm_sigmoid4(pi);
+                go = ggpm_sigmoid4(po);
+                gu = make_float4(tanhf(pu.x), tanhf(pu.y), tanhf(pu.z), tanhf(pu.w));
+                cn = gi * gu + fc;
+                h = go * make_float4(tanhf(cn.x), tanhf(cn.y), tanhf(cn.z), tanhf(cn.w));
+            }
+            ggpm_st4(a.Hnew + o, h);
+            ggpm_st4(a.Cnew + o, cn);
+            if (a.fuse_b) ggpm_st4(Th + lrow * LD + c, h);
+            if (STASH) {
+                ggpm_st4(a.I + o, gi);
+                ggpm_st4(a.O + o, go);
+                ggpm_st4(a.U + o, gu);
+            }
         }
     }
     if (!a.fuse_b) return;
 
-    // ---- P3 (single column group only): qf' = Wf_h h' from the rows this workgroup already holds
-    const float* const wps3[1] = {a.Wf};
-    GgpmRing<1> ring3;
-    if constexpr (!BF16)
-        if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
-    ggpm_lds_barrier();
-    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
-        const float* const tiles[1] = {Th};
-        if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
-        else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
-        const int c = 16 * tt + 4 * (lane >> 4);
-        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+    // ---- P3 (single column group, RTT = 1 only): qf' = Wf_h h' from the rows this workgroup already holds
+    if constexpr (RTT == 1) {
+        const int row = r0 + lr;
+        const float* const wps3[1] = {a.Wf};
+        GgpmRing<1> ring3;
+        if constexpr (!BF16)
+            if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+        ggpm_lds_barrier();
+        for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+            f32x4 acc[1][1];
+            ggpm_zero_acc<1, 1>(acc);
+            const float* const tiles[1] = {Th};
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            const int c = 16 * tt + 4 * (lane >> 4);
+            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+        }
     }
 }
 
 // Kernel B (same geometry as A): qf' = Wf_h h'.
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
@@ -212,17 +227,20 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
         ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     }
     __syncthreads();
-    const int row = r0 + (lane & 15);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
+        f32x4 acc[1][RTT];
+        ggpm_zero_acc<1, RTT>(acc);
         {
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
-        if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            const int row = r0 + 16 * r + (lane & 15);
+            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][r]));
+        }
     }
 }
 
@@ -256,8 +274,9 @@ struct LstmBwdArgs {
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
 // gate derivatives; dXf += dFC * F.
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
+    constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T1 = lds;                      // dqf  (full rows)
@@ -338,135 +357,150 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
         if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dqf stash stores finish under the GEMM
 
-    const int lr = lane & 15, row = r0 + lr;
+    const int lr = lane & 15;
     float* Ta = lds + 3 * ROWS * LD;      // fused P3 only: complete di_pre / do_pre / du_pre rows
     float* Tb = lds + 4 * ROWS * LD;
     float* Tc = lds + 5 * ROWS * LD;
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
-        const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-        float4 gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4(), cc = ggpm_zero4(), fco = ggpm_zero4();
-        float4 oxi = ggpm_zero4(), oxo = ggpm_zero4(), oxu = ggpm_zero4(), oxf = ggpm_zero4();
-        if (!a.final_pass) {
-            gi = ggpm_ld4(a.I + o); go = ggpm_ld4(a.O + o); gu = ggpm_ld4(a.U + o); cc = ggpm_ld4(a.Ccur + o);
-            fco = ggpm_ld4(a.F + o);
-            if (!a.first) {        // depth D starts the dX sums
-                if (!a.skip_xsum) { oxi = ggpm_ld4(a.dXi + o); oxo = ggpm_ld4(a.dXo + o); oxu = ggpm_ld4(a.dXu + o); }
-                oxf = ggpm_ld4(a.dXf + o);
+        float4 gi[RTT], go[RTT], gu[RTT], cc[RTT], fco[RTT], oxi[RTT], oxo[RTT], oxu[RTT], oxf[RTT], dhd[RTT], dcd[RTT];
+        auto load_inputs = [&](int r) {
+            const int row = r0 + 16 * r + lr;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            gi[r] = go[r] = gu[r] = cc[r] = fco[r] = oxi[r] = oxo[r] = oxu[r] = oxf[r] = ggpm_zero4();
+            if (!a.final_pass) {
+                gi[r] = ggpm_ld4(a.I + o); go[r] = ggpm_ld4(a.O + o); gu[r] = ggpm_ld4(a.U + o); cc[r] = ggpm_ld4(a.Ccur + o);
+                fco[r] = ggpm_ld4(a.F + o);
+                if (!a.first) {        // depth D starts the dX sums
+                    if (!a.skip_xsum) { oxi[r] = ggpm_ld4(a.dXi + o); oxo[r] = ggpm_ld4(a.dXo + o); oxu[r] = ggpm_ld4(a.dXu + o); }
+                    oxf[r] = ggpm_ld4(a.dXf + o);
+                }
             }
-        }
-        const float4 dhd = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-        const float4 dcd = (a.first && a.dCD) ? ggpm_ld4(a.dCD + o) : ggpm_zero4();
-        f32x4 acc[1][RT];
-        ggpm_zero_acc<1, RT>(acc);
+            dhd[r] = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
+            dcd[r] = (a.first && a.dCD) ? ggpm_ld4(a.dCD + o) : ggpm_zero4();
+        };
+        if constexpr (RTT == 1) load_inputs(0);     // in flight under the GEMM (two row tiles: the registers go to the GEMM,
+                                                    // each tile's operands are fetched where its epilogue starts)
+        f32x4 acc[1][RTT];
+        ggpm_zero_acc<1, RTT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
         }
-        if (row >= a.E1) {
-            if (a.fuse_b) {
-                ggpm_st4(Ta + lr * LD + c, ggpm_zero4());
-                ggpm_st4(Tb + lr * LD + c, ggpm_zero4());
-                ggpm_st4(Tc + lr * LD + c, ggpm_zero4());
-            }
-            continue;
-        }
-        const bool frz = a.frozen && a.frozen[row];
-        if (a.final_pass) {        // gradient of the incoming (h, c): frozen rows only
-            float4 dh0 = ggpm_zero4(), dc0 = ggpm_zero4();
-            if (frz) {
-                dh0 = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c) + ggpm_ld4(a.carry_h + o);
-                dc0 = ggpm_ld4(T2 + lr * LD + c) + ggpm_ld4(a.carry_c + o);
-            }
-            if (a.scat_idx) {
-                const int id = frz ? a.scat_idx[row] : -1;
-                if (id >= 0) {
-                    float* dh_to = a.scat_h + (size_t)id * Hp + c;
-                    float* dc_to = a.scat_c + (size_t)id * Hp + c;
-                    ggpm_st4(dh_to, ggpm_ld4(dh_to) + dh0);
-                    ggpm_st4(dc_to, ggpm_ld4(dc_to) + dc0);
-                }
-            } else {
-                ggpm_st4(a.dHin + o, dh0);
-                ggpm_st4(a.dCin + o, dc0);
-            }
-            continue;
-        }
-        float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
-        if (row != 0 || a.frozen) {
-            float4 dh, dc;
-            if (a.first) { dh = dhd; dc = dcd; }
-            else { dh = ggpm_f4(acc[0][0]) + ggpm_ld4(T0 + lr * LD + c); dc = ggpm_ld4(T2 + lr * LD + c); }
-            if (frz) {             // (h, c)_t = (h, c)_{t-1}: carry both gradients to the previous depth
-                if (!a.first) {        // (the first backward depth starts the carries: no memset)
-                    dh = dh + ggpm_ld4(a.carry_h + o);
-                    dc = dc + ggpm_ld4(a.carry_c + o);
-                }
-                ggpm_st4(a.carry_h + o, dh);
-                ggpm_st4(a.carry_c + o, dc);
-                dh = ggpm_zero4();
-                dc = ggpm_zero4();
-            }
-            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
-            const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, ov[4] = {go.x, go.y, go.z, go.w};
-            const float uv[4] = {gu.x, gu.y, gu.z, gu.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
-            float r_i[4], r_o[4], r_u[4], r_c[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float tc = tanhf(cv[k]);
-                const float dct = dcv[k] + dhv[k] * ov[k] * (1.f - tc * tc);
-                r_c[k] = dct;
-                r_o[k] = dhv[k] * tc * ov[k] * (1.f - ov[k]);
-                r_i[k] = dct * uv[k] * iv[k] * (1.f - iv[k]);
-                r_u[k] = dct * iv[k] * (1.f - uv[k] * uv[k]);
+        for (int r = 0; r < RTT; ++r) {
+            if constexpr (RTT != 1) load_inputs(r);
+            const int lrow = 16 * r + lr, row = r0 + lrow;
+            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            if (row >= a.E1) {
+                if (a.fuse_b) {
+                    ggpm_st4(Ta + lrow * LD + c, ggpm_zero4());
+                    ggpm_st4(Tb + lrow * LD + c, ggpm_zero4());
+                    ggpm_st4(Tc + lrow * LD + c, ggpm_zero4());
+                }
+                continue;
             }
-            dip = make_float4(r_i[0], r_i[1], r_i[2], r_i[3]);
-            dop = make_float4(r_o[0], r_o[1], r_o[2], r_o[3]);
-            dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
-            dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
-        }
-        ggpm_st4(a.DI + o, dip);
-        ggpm_st4(a.DO + o, dop);
-        ggpm_st4(a.DU + o, dup);
-        ggpm_st4(a.dFCout + o, dfc);
-        if (!a.skip_xsum) {
-            ggpm_st4(a.dXi + o, oxi + dip);
-            ggpm_st4(a.dXo + o, oxo + dop);
-            ggpm_st4(a.dXu + o, oxu + dup);
-        }
-        ggpm_st4(a.dXf + o, oxf + dfc * fco);      // dXf_e += dFC_e * sum_p c_p f(1-f)
-        if (a.fuse_b) {
-            ggpm_st4(Ta + lr * LD + c, dip);
-            ggpm_st4(Tb + lr * LD + c, dop);
-            ggpm_st4(Tc + lr * LD + c, dup);
+            const bool frz = a.frozen && a.frozen[row];
+            if (a.final_pass) {        // gradient of the incoming (h, c): frozen rows only
+                float4 dh0 = ggpm_zero4(), dc0 = ggpm_zero4();
+                if (frz) {
+                    dh0 = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c) + ggpm_ld4(a.carry_h + o);
+                    dc0 = ggpm_ld4(T2 + lrow * LD + c) + ggpm_ld4(a.carry_c + o);
+                }
+                if (a.scat_idx) {
+                    const int id = frz ? a.scat_idx[row] : -1;
+                    if (id >= 0) {
+                        float* dh_to = a.scat_h + (size_t)id * Hp + c;
+                        float* dc_to = a.scat_c + (size_t)id * Hp + c;
+                        ggpm_st4(dh_to, ggpm_ld4(dh_to) + dh0);
+                        ggpm_st4(dc_to, ggpm_ld4(dc_to) + dc0);
+                    }
+                } else {
+                    ggpm_st4(a.dHin + o, dh0);
+                    ggpm_st4(a.dCin + o, dc0);
+                }
+                continue;
+            }
+            float4 dip = ggpm_zero4(), dop = ggpm_zero4(), dup = ggpm_zero4(), dfc = ggpm_zero4();
+            if (row != 0 || a.frozen) {
+                float4 dh, dc;
+                if (a.first) { dh = dhd[r]; dc = dcd[r]; }
+                else { dh = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c); dc = ggpm_ld4(T2 + lrow * LD + c); }
+                if (frz) {             // (h, c)_t = (h, c)_{t-1}: carry both gradients to the previous depth
+                    if (!a.first) {        // (the first backward depth starts the carries: no memset)
+                        dh = dh + ggpm_ld4(a.carry_h + o);
+                        dc = dc + ggpm_ld4(a.carry_c + o);
+                    }
+                    ggpm_st4(a.carry_h + o, dh);
+                    ggpm_st4(a.carry_c + o, dc);
+                    dh = ggpm_zero4();
+                    dc = ggpm_zero4();
+                }
+                const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+                const float iv[4] = {gi[r].x, gi[r].y, gi[r].z, gi[r].w}, ov[4] = {go[r].x, go[r].y, go[r].z, go[r].w};
+                const float uv[4] = {gu[r].x, gu[r].y, gu[r].z, gu[r].w}, cv[4] = {cc[r].x, cc[r].y, cc[r].z, cc[r].w};
+                float r_i[4], r_o[4], r_u[4], r_c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tc = tanhf(cv[k]);
+                    const float dct = dcv[k] + dhv[k] * ov[k] * (1.f - tc * tc);
+                    r_c[k] = dct;
+                    r_o[k] = dhv[k] * tc * ov[k] * (1.f - ov[k]);
+                    r_i[k] = dct * uv[k] * iv[k] * (1.f - iv[k]);
+                    r_u[k] = dct * iv[k] * (1.f - uv[k] * uv[k]);
+                }
+                dip = make_float4(r_i[0], r_i[1], r_i[2], r_i[3]);
+                dop = make_float4(r_o[0], r_o[1], r_o[2], r_o[3]);
+                dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
+                dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
+            }
+            ggpm_st4(a.DI + o, dip);
+            ggpm_st4(a.DO + o, dop);
+            ggpm_st4(a.DU + o, dup);
+            ggpm_st4(a.dFCout + o, dfc);
+            if (!a.skip_xsum) {
+                ggpm_st4(a.dXi + o, oxi[r] + dip);
+                ggpm_st4(a.dXo + o, oxo[r] + dop);
+                ggpm_st4(a.dXu + o, oxu[r] + dup);
+            }
+            ggpm_st4(a.dXf + o, oxf[r] + dfc * fco[r]);      // dXf_e += dFC_e * sum_p c_p f(1-f)
+            if (a.fuse_b) {
+                ggpm_st4(Ta + lrow * LD + c, dip);
+                ggpm_st4(Tb + lrow * LD + c, dop);
+                ggpm_st4(Tc + lrow * LD + c, dup);
+            }
         }
     }
     if (!a.fuse_b) return;
 
-    // ---- P3 (single column group only): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h from the rows held here
-    const float* const wps3[3] = {a.WiT, a.WoT, a.WuT};
-    GgpmRing<3> ring3;
-    if constexpr (!BF16)
-        if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
-    ggpm_lds_barrier();
-    for (int tt = wave; tt < NT; tt += GGPM_NWA) {
-        f32x4 acc[3][RT];
-        ggpm_zero_acc<3, RT>(acc);
-        {
-            const float* const tiles[3] = {Ta, Tb, Tc};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps3, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+    // ---- P3 (single column group, RTT = 1 only): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h from the rows held here
+    if constexpr (RTT == 1) {
+        const int row = r0 + lr;
+        const float* const wps3[3] = {a.WiT, a.WoT, a.WuT};
+        GgpmRing<3> ring3;
+        if constexpr (!BF16)
+            if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
+        ggpm_lds_barrier();
+        for (int tt = wave; tt < NT; tt += GGPM_NWA) {
+            f32x4 acc[3][1];
+            ggpm_zero_acc<3, 1>(acc);
+            {
+                const float* const tiles[3] = {Ta, Tb, Tc};
+                if constexpr (BF16) ggpm_wave_gemm_bf16<3, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+                else ggpm_wave_gemm_ring<3, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            }
+            const int c = 16 * tt + 4 * (lane >> 4);
+            if (row < a.E1)
+                ggpm_st4(a.dSout + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
         }
-        const int c = 16 * tt + 4 * (lane >> 4);
-        if (row < a.E1)
-            ggpm_st4(a.dSout + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
     }
 }
 
 // Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
-template <bool BF16>
+template <bool BF16, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
+    constexpr int ROWS = RTT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ta = lds;
@@ -485,18 +519,21 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
     ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
     __syncthreads();
-    const int e = r0 + (lane & 15);
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
-        f32x4 acc[3][RT];
-        ggpm_zero_acc<3, RT>(acc);
+        f32x4 acc[3][RTT];
+        ggpm_zero_acc<3, RTT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<3, RT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
-        if (e < a.E1)
-            ggpm_st4(a.dSout + (size_t)e * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
+#pragma unroll
+        for (int r = 0; r < RTT; ++r) {
+            const int e = r0 + 16 * r + (lane & 15);
+            if (e < a.E1)
+                ggpm_st4(a.dSout + (size_t)e * Hp + c, ggpm_f4(acc[0][r]) + ggpm_f4(acc[1][r]) + ggpm_f4(acc[2][r]));
+        }
     }
 }
 
@@ -513,7 +550,11 @@ inline void set_lds(K kernel, size_t bytes) {
     }
 }
 
-inline size_t lds_tiles(int n, int Hp) { return (size_t)n * ROWS * (Hp + 4) * sizeof(float); }
+inline size_t lds_tiles(int n, int Hp, int rows = ROWS) { return (size_t)n * rows * (Hp + 4) * sizeof(float); }
+// ggpm_level_prefer_narrow (mpn_gru.hip, common.h): two row tiles per workgroup for the dense fp32 level calls of this thread
+inline bool use_rt2(int Hp, bool sparse, int bf16) {
+    return ggpm_prefer_narrow() && !sparse && !bf16 && lds_tiles(3, Hp, 32) <= 160 * 1024;
+}
 
 // Environment switches are read once: getenv walks the whole environment (~0.5 us) and the launch helpers below run
 // ~120 times per training step.
@@ -533,42 +574,50 @@ inline int pick_tg(int E1, int NT) {
 
 void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
-    dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    a.fuse_b = (with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
+    const bool rt2 = use_rt2(Hp, a.frozen != nullptr, a.bf16);
+    const int rows = rt2 ? 32 : 16;
+    dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
+    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
-    const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp), lb = lds_tiles(1, Hp);
+    const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp, rows), lb = lds_tiles(1, Hp, rows);
     ggpm_timing_begin(2, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 3)) * flops1);     // the first depth has no gate products
     auto go = [&](auto kernel) {
         set_lds(kernel, la);
         kernel<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
     };
-    if (a.bf16) { if (stash) go(lstm_fwd_a<true, true>); else go(lstm_fwd_a<false, true>); }
-    else { if (stash) go(lstm_fwd_a<true, false>); else go(lstm_fwd_a<false, false>); }
+    if (rt2) { if (stash) go(lstm_fwd_a<true, false, 2>); else go(lstm_fwd_a<false, false, 2>); }
+    else if (a.bf16) { if (stash) go(lstm_fwd_a<true, true, 1>); else go(lstm_fwd_a<false, true, 1>); }
+    else { if (stash) go(lstm_fwd_a<true, false, 1>); else go(lstm_fwd_a<false, false, 1>); }
     ggpm_timing_end(2, s);
     if (with_b) {
         ggpm_timing_begin(6, s, 1 * flops1);
-        if (a.bf16) { set_lds(lstm_fwd_b<true>, lb); lstm_fwd_b<true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
-        else { set_lds(lstm_fwd_b<false>, lb); lstm_fwd_b<false><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        if (rt2) { set_lds(lstm_fwd_b<false, 2>, lb); lstm_fwd_b<false, 2><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else if (a.bf16) { set_lds(lstm_fwd_b<true, 1>, lb); lstm_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else { set_lds(lstm_fwd_b<false, 1>, lb); lstm_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         ggpm_timing_end(6, s);
     }
 }
 
 void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
-    dim3 grid_a(ggpm_ceil_div(a.E1, ROWS), ggpm_ceil_div(NT, a.tg));
-    const size_t l3 = lds_tiles(3, Hp);
-    a.fuse_b = (with_b && !a.final_pass && grid_a.y == 1 && lds_tiles(6, Hp) <= 160 * 1024 &&
+    const bool rt2 = use_rt2(Hp, a.frozen != nullptr, a.bf16);
+    const int rows = rt2 ? 32 : 16;
+    dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
+    const size_t l3 = lds_tiles(3, Hp, rows);
+    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && lds_tiles(6, Hp) <= 160 * 1024 &&
                 !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
     const size_t la = a.fuse_b ? lds_tiles(6, Hp) : l3;
     ggpm_timing_begin(3, s, (a.fuse_b ? 4 : 1) * flops1);
-    if (a.bf16) { set_lds(lstm_bwd_a<true>, la); lstm_bwd_a<true><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
-    else { set_lds(lstm_bwd_a<false>, la); lstm_bwd_a<false><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    if (rt2) { set_lds(lstm_bwd_a<false, 2>, la); lstm_bwd_a<false, 2><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else if (a.bf16) { set_lds(lstm_bwd_a<true, 1>, la); lstm_bwd_a<true, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else { set_lds(lstm_bwd_a<false, 1>, la); lstm_bwd_a<false, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     ggpm_timing_end(3, s);
     if (with_b) {
         ggpm_timing_begin(7, s, 3 * flops1);
-        if (a.bf16) { set_lds(lstm_bwd_b<true>, l3); lstm_bwd_b<true><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
-        else { set_lds(lstm_bwd_b<false>, l3); lstm_bwd_b<false><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        if (rt2) { set_lds(lstm_bwd_b<false, 2>, l3); lstm_bwd_b<false, 2><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else if (a.bf16) { set_lds(lstm_bwd_b<true, 1>, l3); lstm_bwd_b<true, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else { set_lds(lstm_bwd_b<false, 1>, l3); lstm_bwd_b<false, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         ggpm_timing_end(7, s);
     }
 }
@@ -636,8 +685,8 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         if (gathered) { a0.src_h = gs_h; a0.src_c = gs_c; a0.src_idx = gs_idx; a0.Cnew = Cs; }
         const size_t lb = lds_tiles(1, Hp);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg));
-        if (bf16) { set_lds(lstm_fwd_b<true>, lb); lstm_fwd_b<true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
-        else { set_lds(lstm_fwd_b<false>, lb); lstm_fwd_b<false><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        if (bf16) { set_lds(lstm_fwd_b<true, 1>, lb); lstm_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        else { set_lds(lstm_fwd_b<false, 1>, lb); lstm_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
     } else {
         (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
         (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);

@@ -334,7 +334,7 @@ void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
  *   ggpm_backward_scatter_state(dst_h, dst_c, idx): the NEXT ggpm_*_sparse_backward of this thread ADDS the gradient of the
  *   incoming state of row r to dst_h[idx[r]] (dst_c likewise; idx unique, rows with idx[r] < 0 dropped) inside its last
  *   launch; dHin / dCin are not written.  Rows are [Hp] floats.  One call consumes the setting. */
-/* ggpm_level_prefer_narrow(1): until switched off again, the dense GRU level calls of this thread use two row tiles per
+/* ggpm_level_prefer_narrow(1): until switched off again, the dense fp32 level calls of this thread (GRU and LSTM) use two row tiles per
  * workgroup whatever the level's size, i.e. half as many workgroups (the same products in the same order per row; results
  * agree with the default form to rounding, 5e-6 norm-wise after 20 depth steps -- the two instantiations contract the gate
  * expressions differently).  For a

@@ -325,7 +325,7 @@ def test_encoder_is_bitwise_reproducible(name):
 
 
 
-@pytest.mark.parametrize("name", ["tiny_gru_s1", "cfg_gru_s0", "cfg_gru_s1"])
+@pytest.mark.parametrize("name", ["tiny_gru_s1", "cfg_gru_s0", "cfg_gru_s1", "tiny_lstm_s0", "cfg_lstm_s0", "cfg_lstm_s2"])
 def test_narrow_level_kernels_agree_with_the_default_form(name):
     """ggpm_level_prefer_narrow (the encoder beside the decoder's atom level in the full VAE step): two row tiles per
     workgroup, half as many workgroups.  The same products in the same order per row; the two template instantiations
