@@ -890,9 +890,14 @@ def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, 
         Wz, bz, Wr, Ur, bu, Wh, bh, Wout, bout = params
     x_ld = F_._ld(hmess)
 
+    # input halves dW_k[:, :I] = dX_k^T hmess of all gates in ONE grouped launch (as the encoder's drivers form them)
+    gate_ws = (Wi, Wo_g, Wu, Wf) if lstm else (Wz, Wr, Wh)
+    bufs = [torch.empty_like(W) for W in gate_ws]
+    F_.gemm_grouped(1, 0, H, I, E1, [dict(A=dX_tot[k], lda=Hp, B=hmess, ldb=x_ld, C=b, ldc=b.stride(0), n_pad=I)
+                                      for k, b in enumerate(bufs)])
+
     def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
-        dW = torch.empty_like(W)
-        F_.gemm(1, 0, H, I, E1, dX_tot[k], Hp, hmess, x_ld, dW, dW.stride(0), I, splitk=True)
+        dW = bufs[k]
         if hidden is not None:
             dW[:, I:] = hidden
         return dW
