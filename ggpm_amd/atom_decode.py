@@ -781,7 +781,14 @@ class _AtomDecodeCompact(torch.autograd.Function):
         DG_all = torch.empty(3 if lstm else 2, roff[-1], Hp, **f32)
         DQ_all = torch.zeros(qoff[-1], Hp, **f32)
         nh = 4 if lstm else 3                                   # hidden-half weight gradients (+ GRU: b_u)
-        acc = [torch.empty(H, H, **f32) for _ in range(nh)] + ([] if lstm else [torch.empty(H, **f32)])
+        # the [H, I + H] gradient buffers of the gate weights exist from the start: the stacked contractions write their
+        # hidden halves in place (leading dimension I + H), the grouped input-half launch fills the rest -- no copies
+        gate_ws = (Wi, Wo_g, Wu, Wf) if lstm else (Wz, Wr, Wh)
+        bufs = [torch.empty_like(w) for w in gate_ws]
+        if lstm:
+            acc = [b[:, I:] for b in bufs]
+        else:           # acc order of the GRU: Wz_h, U_r, Wh_h, b_u (W_r has no hidden half: U_r is its own matrix)
+            acc = [bufs[0][:, I:], torch.empty(H, H, **f32), bufs[2][:, I:], torch.empty(H, **f32)]
         nmax = max(plan.nloc)
         wb = int((lib.ggpm_lstm_backward_workspace_bytes if lstm else lib.ggpm_gru_backward_workspace_bytes)(nmax, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
@@ -849,15 +856,16 @@ class _AtomDecodeCompact(torch.autograd.Function):
             R, RQ = roff[-1], qoff[-1]
             wsb = int(lib.ggpm_weight_grads_stacked_workspace_bytes(H, max(R, RQ)))
             ws = torch.empty((wsb + 3) // 4, **f32)
+            ld = [a.stride(0) for a in acc[:nh]]
             if lstm:        # acc: Wi_h, Wo_h, Wu_h, Wf_h; St_all[0] = S
                 _lib.check(lib.ggpm_lstm_weight_grads_stacked(
-                    R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
-                    H, P(acc[2]), H, P(acc[3]), H, P(ws), ws.numel() * 4, s_), "lstm_weight_grads_stacked")
+                    R, RQ, H, P(DG_all[0]), P(DG_all[1]), P(DG_all[2]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), ld[0],
+                    P(acc[1]), ld[1], P(acc[2]), ld[2], P(acc[3]), ld[3], P(ws), ws.numel() * 4, s_), "lstm_weight_grads_stacked")
             else:           # acc: Wz_h, U_r, Wh_h, b_u; St_all: S, G, Z, M, R
                 _lib.check(lib.ggpm_gru_weight_grads_stacked(
-                    R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), H, P(acc[1]),
-                    H, P(acc[3]), P(acc[2]), H, P(ws), ws.numel() * 4, s_), "gru_weight_grads_stacked")
-            return _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot)
+                    R, RQ, H, P(DG_all[0]), P(St_all[1]), P(DG_all[1]), P(St_all[0]), P(DQ_all), P(Hs_all), P(acc[0]), ld[0],
+                    P(acc[1]), ld[1], P(acc[3]), P(acc[2]), ld[2], P(ws), ws.numel() * 4, s_), "gru_weight_grads_stacked")
+            return _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot, bufs=bufs)
 
         if go_async:
             # The loop is being issued by the worker; this node returns now so that the engine can issue the encoder's
@@ -881,7 +889,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
         return (None,) * 10 + tail()
 
 
-def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot):
+def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, Fdim, E1, ns_tot, bufs=None):
     """Parameter gradients of the atom-level decode from the summed gate-input gradients, the accumulated hidden halves
     and the stacked read-out rows (shared by both forms)."""
     if lstm:
@@ -892,13 +900,15 @@ def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, 
 
     # input halves dW_k[:, :I] = dX_k^T hmess of all gates in ONE grouped launch (as the encoder's drivers form them)
     gate_ws = (Wi, Wo_g, Wu, Wf) if lstm else (Wz, Wr, Wh)
-    bufs = [torch.empty_like(W) for W in gate_ws]
+    in_place = bufs is not None             # the hidden halves are already there (written by the stacked contractions)
+    if bufs is None:
+        bufs = [torch.empty_like(W) for W in gate_ws]
     F_.gemm_grouped(1, 0, H, I, E1, [dict(A=dX_tot[k], lda=Hp, B=hmess, ldb=x_ld, C=b, ldc=b.stride(0), n_pad=I)
                                       for k, b in enumerate(bufs)])
 
     def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
         dW = bufs[k]
-        if hidden is not None:
+        if hidden is not None and not in_place:
             dW[:, I:] = hidden
         return dW
 
