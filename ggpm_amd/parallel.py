@@ -124,14 +124,10 @@ class FlatGradSync:
             mark("pack: before the copy")
             torch._foreach_copy_(views, grads)
             mark("pack: after the copy")
-        import os
-        if os.environ.get("GGPM_PROBE_KEEP_GRADS") == "1":      # probe: do not release the packed gradients here
-            self._held = [p.grad for p in self.params]
-            mark("pack: (grads held)")
-            return
         for p, v in zip(self.params, self.views):
             p.grad = v
-        mark("pack: grads re-pointed")
+        if views:
+            mark("pack: grads re-pointed")
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks then divide by world size (mean of per-rank batch-mean losses)."""
