@@ -830,72 +830,82 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
     const int bz = bzz % splits;
     const int m0 = by * TM, n0 = bx * TN;
     const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
-    // eight waves: quadrant (wave & 3) of the 160 x 160 tile as in the other tall kernels, and HALF of the six products
-    // (wave >> 2): half 0 forms a1*b1 + a1*b2 + a1*b3, half 1 a2*b1 + a2*b2 + a3*b1.  Two waves per SIMD, so one wave's
-    // operand split / LDS traffic / barrier wait runs under the other's MFMAs; the two halves land in two slabs that
-    // tall_reduce adds like two K chunks.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int quad = wave & 3, half = wave >> 2;
-    const int wm = quad >> 1, wn = quad & 1;
-
-    // waves 0-3 stage the A rows of a step, waves 4-7 the B rows: 32 rows x 40 float4 = 5 per thread
-    const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    const float* P = isb ? g.B : g.A;
-    const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
-    unsigned voff[5];
-    int loff[5];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Eight waves, two roles (wave w sits on SIMD w % 4: every SIMD holds one of each).  Waves 4-7 PRODUCE: they fetch the
+    // operands of step s + 2, split the ones of step s + 1 into their three bf16 planes and write the LDS image.  Waves 0-3
+    // CONSUME: one quadrant of the 160 x 160 tile each, fragments of step s out of the other buffer, six MFMAs per fragment
+    // pair.  The vector instructions of the split (the bulk of a step's issue slots) are then issued by a wave that has no
+    // MFMA of its own to wait for, beside the MFMA stream of its SIMD partner; one LDS-only barrier per step hands the buffers over.
+    if (wave >= 4) {
+        const int ptid = threadIdx.x - 256;
+        const int isb = __builtin_amdgcn_readfirstlane(ptid >> 7);      // waves 4-5: A rows, waves 6-7: B rows
+        const float* P = isb ? g.B : g.A;
+        const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
+        unsigned voff[10];
+        int loff[10];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int f = (threadIdx.x & 255) + 256 * i;
-        const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
-        loff[i] = k * BLD + isb * TM + c;
-        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
-    }
-    const unsigned vstep = (unsigned)BTK * ld * 4;
-    f32x4 r[5];
-    auto fetch = [&]() {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
-            if (voff[i] != 0xffffff00u) voff[i] += vstep;
+        for (int i = 0; i < 10; ++i) {
+            const int f = (ptid & 127) + 128 * i;
+            const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
+            loff[i] = k * BLD + isb * TM + c;
+            voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
         }
-    };
-    // x1 = rne(x) (v_cvt_pk_bf16_f32), r1 = x - x1 (exact, <= 16 significant bits, |r1| <= 2^-9 |x|), x2 = the upper half of
-    // r1's bits (truncation: one v_and), r2 = r1 - x2 (exact, <= 8 significant bits: ITS upper half is x3, exactly).  The
-    // launch is paced by vector-instruction issue, not by the matrix pipe (an MFMA leaves 8 of its 16 cycles to other
-    // instructions): 5.5 instructions per value here instead of the ~15 of three roundings.
-    auto put = [&](int buf) {
-        __bf16* base = Lsp + (size_t)buf * 3 * PLANE;
+        const unsigned vstep = (unsigned)BTK * ld * 4;
+        f32x4 r[10];
+        auto fetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            gbf16x4 w1;
-            unsigned r1b[4], r2b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = r[i][e];
-                w1[e] = (__bf16)x;
-                const float r1 = x - (float)w1[e];
-                r1b[e] = __builtin_bit_cast(unsigned, r1);
-                const float x2f = __builtin_bit_cast(float, r1b[e] & 0xffff0000u);
-                r2b[e] = __builtin_bit_cast(unsigned, r1 - x2f);
+            for (int i = 0; i < 10; ++i) {
+                r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+                if (voff[i] != 0xffffff00u) voff[i] += vstep;
             }
-            // upper halves of two registers into one: bytes {lo.2, lo.3, hi.2, hi.3}
-            const unsigned w2a = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), w2b = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
-            const unsigned w3a = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), w3b = __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u);
-            *reinterpret_cast<gbf16x4*>(base + loff[i]) = w1;
-            *reinterpret_cast<uint2*>(base + PLANE + loff[i]) = make_uint2(w2a, w2b);
-            *reinterpret_cast<uint2*>(base + 2 * PLANE + loff[i]) = make_uint2(w3a, w3b);
+        };
+        // x1 = rne(x) (v_cvt_pk_bf16_f32), r1 = x - x1 (exact, <= 16 significant bits, |r1| <= 2^-9 |x|), x2 = the upper half
+        // of r1's bits (truncation: one v_and), r2 = r1 - x2 (exact, <= 8 significant bits: ITS upper half is x3, exactly)
+        auto put = [&](int buf) {
+            __bf16* base = Lsp + (size_t)buf * 3 * PLANE;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                gbf16x4 w1;
+                unsigned r1b[4], r2b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = r[i][e];
+                    w1[e] = (__bf16)x;
+                    const float r1 = x - (float)w1[e];
+                    r1b[e] = __builtin_bit_cast(unsigned, r1);
+                    const float x2f = __builtin_bit_cast(float, r1b[e] & 0xffff0000u);
+                    r2b[e] = __builtin_bit_cast(unsigned, r1 - x2f);
+                }
+                // upper halves of two registers into one: bytes {lo.2, lo.3, hi.2, hi.3}
+                const unsigned w2a = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), w2b = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
+                const unsigned w3a = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), w3b = __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u);
+                *reinterpret_cast<gbf16x4*>(base + loff[i]) = w1;
+                *reinterpret_cast<uint2*>(base + PLANE + loff[i]) = make_uint2(w2a, w2b);
+                *reinterpret_cast<uint2*>(base + 2 * PLANE + loff[i]) = make_uint2(w3a, w3b);
+            }
+        };
+        fetch();
+        put(0);
+        fetch();
+        ggpm_lds_barrier();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
+            put(cur ^ 1);           // rows of step s+1 (loaded a step ago); the consumers finished reading that buffer before
+            fetch();                // the barrier that ended step s-1.  The loads of step s+2 fly under this step
+            ggpm_lds_barrier();
         }
-    };
+        return;
+    }
 
+    const int wm = wave >> 1, wn = wave & 1;
     f32x4 acc[5][5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int fa0 = (4 * grp + q) * BLD + wm * 80 + 4 * pp;
     const int fb0 = (4 * grp + q) * BLD + TM + wn * 80 + 4 * pp;
@@ -906,46 +916,43 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
         gs16x4 v[2] = {lo, hi};
         return __builtin_bit_cast(gbf16x8, v);
     };
-    // planes of the three products of this wave's half (smallest first): half 0: (a1,b3) (a1,b2) (a1,b1); half 1:
-    // (a3,b1) (a2,b2) (a2,b1) -- two distinct A planes and B planes at most, four fragment sets of five
-    const int pa0 = half ? 2 : 0, pa1 = half ? 1 : 0;       // A planes: first product / the other two
-    const int pb0 = half ? 0 : 2, pb1 = 1, pb2 = 0;          // B planes of the three products
-
-    fetch();
-    put(0);
-    fetch();
     ggpm_lds_barrier();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
         const __bf16* img = Lsp + (size_t)cur * 3 * PLANE;
-        gbf16x8 fa0v[5], fa1v[5], fb0v[5], fb1v[5], fb2v[5];
+        gbf16x8 fb[3][5], fa[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            fa0v[i] = frag(img + pa0 * PLANE + fa0 + 16 * i);
-            fa1v[i] = frag(img + pa1 * PLANE + fa0 + 16 * i);
-            fb0v[i] = frag(img + pb0 * PLANE + fb0 + 16 * i);
-            fb1v[i] = frag(img + pb1 * PLANE + fb0 + 16 * i);
-            fb2v[i] = frag(img + pb2 * PLANE + fb0 + 16 * i);
-        }
-        put(cur ^ 1);           // rows of step s+1 (loaded a step ago); every wave finished reading that buffer before the
-        fetch();                // barrier that ended step s-1.  Then the loads of step s+2 fly under this step's MFMAs
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) fb[pl][j] = frag(img + pl * PLANE + fb0 + 16 * j);
+        // smallest terms first: a3*b1; a2*b2, a2*b1; a1*b3, a1*b2, a1*b1 -- one A plane in registers at a time
+#pragma unroll
+        for (int i = 0; i < 5; ++i) fa[i] = frag(img + 2 * PLANE + fa0 + 16 * i);
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0v[i], fb0v[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 5; ++i) fa[i] = frag(img + PLANE + fa0 + 16 * i);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1v[i], fb1v[j], acc[i][j], 0, 0, 0);
+        for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1v[i], fb2v[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[pl][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) fa[i] = frag(img + fa0 + 16 * i);
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[pl][j], acc[i][j], 0, 0, 0);
         ggpm_lds_barrier();
     }
-    // two slabs per K chunk (one per half) in the fragment order of gemm_tn_tall
+    // split-K slab in the fragment order of gemm_tn_tall (lane l: rows 4*(l>>4) + 0..3, column l & 15 of every block)
     f32x4* slab = reinterpret_cast<f32x4*>(g.ws) +
-                  (((((size_t)bz * 2 + half) * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + quad) * 25) * 64 + lane;
+                  ((((size_t)bz * (gridDim.x * gridDim.y) + by * gridDim.x + bx) * 4 + wave) * 25) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -1161,11 +1168,11 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     if (use_tall && trans_a && !trans_b && g.vecA && g.vecB && lda >= ggpm_round_up(M, 4) && ldb >= ggpm_round_up(N, 4) &&
         tall_shape(M, N, K) && n_pad <= ggpm_round_up(N, TN) && (size_t)K * lda * 4 < 0xffffff00ull && (size_t)K * ldb * 4 < 0xffffff00ull) {
         const size_t slab = tall_slab_bytes(M, N);
-        if (tall_split_mode() && splitk_ws && splitk_ws_bytes >= 2 * slab) {
+        if (tall_split_mode() && splitk_ws && splitk_ws_bytes >= slab) {
             // split operands on the bf16 pipe (fp32 accuracy, operand-stream bound): always through slabs + tall_reduce
             // (which applies bias / accumulate / activation)
             int sp = tall_splits(M, N, K, tall_split_wgs());
-            if ((size_t)2 * sp * slab > splitk_ws_bytes) sp = (int)(splitk_ws_bytes / (2 * slab));      // two slabs per K chunk
+            if ((size_t)sp * slab > splitk_ws_bytes) sp = (int)(splitk_ws_bytes / slab);
             if (sp < 1) sp = 1;
             g.k_chunk = ggpm_round_up(ggpm_ceil_div(K, sp), BTK);
             sp = ggpm_ceil_div(K, g.k_chunk);
@@ -1174,7 +1181,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
             GemmGroupArgs gg;
             for (int i = 0; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = g;
             launch_tall_split(gg, dim3(tiles_n, tiles_m, sp), sp, s);
-            tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, 2 * sp, tiles_n, tiles_n * tiles_m);
+            tall_reduce<<<tiles_n * tiles_m * 100, 256, 0, s>>>(gg, sp, tiles_n, tiles_n * tiles_m);
             GGPM_CHECK_LAUNCH();
             return GGPM_OK;
         }
@@ -1282,7 +1289,7 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
              (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
         splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : (split ? tall_split_wgs() / count : 0)));
     }
-    const int slabs_per_chunk = split ? 2 : 1;      // (the split kernel leaves one slab per half of its six products)
+    const int slabs_per_chunk = 1;
     if (ok) splits = min(splits, (int)(ws_bytes / (count * slab * slabs_per_chunk)));      // the group shares the workspace
     if (!ok || splits < ((bf16 || split) ? 1 : 2)) {
         for (int i = 0; i < count; ++i) {
