@@ -169,3 +169,28 @@ def test_state_dict_keys_are_the_references(name):
     extra = set(model.state_dict()) - ours
     assert extra and all(k.startswith(("decoder.rnn_cell.", "decoder.E_assm.")) or (g.tie and k.startswith("decoder.hmpn.E_"))
                          for k in extra), sorted(extra)
+
+
+def test_cu_split_is_off_unless_asked_for(monkeypatch):
+    """functional.cu_split: no masked streams without GGPM_CU_SPLIT, never on the CPU"""
+    from ggpm_amd import functional as F_
+    monkeypatch.delenv("GGPM_CU_SPLIT", raising=False)
+    assert F_.cu_split(torch.device("cpu")) is None
+    monkeypatch.setenv("GGPM_CU_SPLIT", "128")
+    assert F_.cu_split(torch.device("cpu")) is None
+
+
+def test_published_gradients_are_not_stream_marked_by_default():
+    """functional.hand_to: a gradient handed from a helper stream to the main stream gets no record_stream mark (on ROCm
+    each mark is an event record on that stream when the tensor is released); GGPM_RECORD_GRADS=1 at import restores it"""
+    from ggpm_amd import functional as F_
+
+    class Probe:
+        marks = 0
+
+        def record_stream(self, stream):
+            Probe.marks += 1
+
+    F_.hand_to(Probe(), object())
+    assert Probe.marks == (1 if F_._RECORD_GRADS else 0)
+
