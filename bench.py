@@ -802,6 +802,12 @@ def main():
                                   cfg["latent"], cfg["batch"], rnn, " + RCCL all-reduce" if world > 1 else ""),
                    "baseline_config_index": a.config, "rnn_type": rnn, "global_batch": cfg["batch"] * world,
                    "parallelism": "dp%d" % world,
+                   "arithmetic": "fp32 state, stashes, gate math and accumulation; gate products of the depth loops on "
+                                 "v_mfma_f32_16x16x4_f32%s; tall weight-gradient contractions %s" % (
+                                     " (bf16 operands under --dtype bf16 / the \"bf16\" leg)" if a.config == 4 else "",
+                                     "on fp32 MFMA (GGPM_TALL_SPLIT=0)" if os.environ.get("GGPM_TALL_SPLIT") == "0" else
+                                     "with every fp32 operand split exactly into three bf16 terms, six of the nine partial "
+                                     "products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32 accuracy: 3e-6 from fp64)"),
                    "algorithmic_gflop_per_step_per_gpu": m["algorithmic_gflop_per_step_per_gpu"],
                    "executed_gflop_per_step_per_gpu": m["executed_gflop_per_step_per_gpu"]},
         "host_enqueue_ms_per_step": m["host_enqueue_ms_per_step"],
