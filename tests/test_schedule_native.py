@@ -18,6 +18,12 @@ CASES = {
     "polymers": dict(seed=606, B=3, motifs=(46, 58), vocab=(60, 180)),
     "mix": dict(seed=11, B=12, motifs="mix", vocab=(721, 6214)),
 }
+# a seeded sweep over ragged batches: batch sizes 1 ... 9, molecules from a single motif (no tree message at all) to 14
+_rs = np.random.RandomState(2026)
+for _i in range(16):
+    _lo = int(_rs.randint(1, 4))
+    CASES["sweep_%02d" % _i] = dict(seed=int(_rs.randint(1, 10 ** 6)), B=int(_rs.randint(1, 10)),
+                                    motifs=(_lo, _lo + int(_rs.randint(0, 12))), vocab=(40, 120))
 
 
 def _batch(c):
