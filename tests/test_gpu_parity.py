@@ -1205,6 +1205,12 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     ("LSTM", 250, 24, 20, 20, (6, 14), (721, 6489), False, 77),       # configs[0]: the pretrained model's shape (9 attachments per motif)
     ("GRU", 300, 32, 20, 64, (1, 3), (500, 1500), False, 78),         # configs[2]: QM9-shaped, single-motif molecules among them
     ("LSTM", 600, 24, 20, 8, (6, 14), (721, 6489), True, 79),         # configs[3]'s model: H=600, tied embeddings
+    # ragged little batches: one molecule, single-motif molecules only (no tree message: the step-by-step forms), mixtures
+    ("GRU", 48, 12, 4, 1, (5, 5), (40, 120), False, 301),
+    ("LSTM", 48, 12, 4, 3, (1, 1), (40, 120), False, 302),
+    ("GRU", 48, 12, 4, 5, (1, 4), (40, 120), True, 303),
+    ("LSTM", 48, 12, 4, 7, (1, 6), (40, 120), False, 304),
+    ("GRU", 40, 40, 3, 4, (2, 9), (40, 120), False, 305),              # latent size = hidden size (no W_root projection)
 ])
 def test_vae_step_at_config_shapes_matches_oracle(rnn, H, L, depth, B, motifs, vocab, tie, seed):
     """The full VAE step (encoder, rsample, teacher-forced decoder, four losses, backward) against oracle/ref_decoder.
