@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0..4] [--rnn GRU|LSTM]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+``--gpus N`` (N > 1) without WORLD_SIZE in the environment starts the N rank processes itself (ggpm_amd/launcher.py: the
+parent makes no HIP call, every rank is a fresh process with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set); under
+torch.distributed.run the ranks exist already and this file is one of them.
+
 Default workload = BASELINE.json configs[1]: synthetic random-motif molecules (~40 atoms, motif vocab 500),
 hidden = embed = 300, depthT = depthG = 20, batch 32 per GPU, fp32, GRU message function (the LSTM run of the same
 workload is reported in the same line under "lstm").  ``--config N`` selects configs[N] of BASELINE.json (CONFIGS
@@ -30,16 +34,12 @@ import os
 import sys
 import time
 
-# The encoder uses two HIP streams per process and RCCL brings its own; with the default of 4 hardware queues an
-# eagerly created communicator takes them first and the encoder's second stream ends up sharing a queue with the main
-# one (measured: 5.94 instead of 5.45 ms/step).  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import ggpm_amd          # noqa: E402  (sets GPU_MAX_HW_QUEUES=8 before the HIP runtime starts; see ggpm_amd/__init__.py)
+import numpy as np       # noqa: E402
+import torch             # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBS = 8000.0
@@ -709,8 +709,7 @@ def _emit(obj):
         os.write(_REAL_STDOUT, line)
 
 
-def main():
-    _claim_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -742,7 +741,28 @@ def main():
                          "that the trace ends with the steps to be cut out (tools/prof_summary.py --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(a, argv):
+    """``python bench.py --gpus N`` with nobody having set up the ranks: this process -- which has made no HIP call and
+    makes none -- starts N fresh copies of itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (ggpm_amd/launcher.py), relays rank 0's JSON line and exits non-zero if any rank does."""
+    from ggpm_amd import launcher
+    have = torch.cuda.device_count()                 # (counting devices does not initialise HIP)
+    if have < a.gpus and not os.environ.get("GGPM_BENCH_ONE_DEVICE"):
+        raise SystemExit("--gpus %d but this node shows %d GPU(s) (rehearsal on one GPU: GGPM_BENCH_ONE_DEVICE=1 "
+                         "--backend gloo)" % (a.gpus, have))
+    log("starting %d rank processes (backend %s)" % (a.gpus, a.backend))
+    return launcher.run_ranks(os.path.abspath(__file__), argv, a.gpus,
+                              timeout=float(os.environ.get("GGPM_LAUNCH_TIMEOUT", "1500")))
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    _claim_stdout()
     cfg = dict(CONFIGS[a.config])
     for k in ("hidden", "depth", "batch", "latent"):
         if getattr(a, k) is not None:
@@ -757,7 +777,7 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("--gpus %d but WORLD_SIZE=1" % a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if os.environ.get("GGPM_BENCH_ONE_DEVICE"):      # rehearsal of N ranks on a 1-GPU box (use --backend gloo)
@@ -799,7 +819,9 @@ def main():
         "config": {"workload": "BASELINE %s: %.1f atoms/molecule, motif vocab %d/%d, hidden=%d depth=%d latent=%d "
                                "batch=%d per GPU, %s cell; step = zero_grad + encoder fwd + KL + bwd%s + Adam"
                                % (cfg["tag"], m["atoms_per_molecule"], n_motif, n_attach, cfg["hidden"], cfg["depth"],
-                                  cfg["latent"], cfg["batch"], rnn, " + RCCL all-reduce" if world > 1 else ""),
+                                  cfg["latent"], cfg["batch"], rnn,
+                                  "" if world == 1 else " + RCCL all-reduce" if a.backend == "nccl" else
+                                  " + %s all-reduce (rehearsal backend, not RCCL)" % a.backend),
                    "baseline_config_index": a.config, "rnn_type": rnn, "global_batch": cfg["batch"] * world,
                    "parallelism": "dp%d" % world,
                    "arithmetic": "fp32 state, stashes, gate math and accumulation; gate products of the depth loops on "

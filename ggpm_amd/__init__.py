@@ -3,6 +3,15 @@
 Host side: Python mirror of the reference's classes (rnn.GRU/LSTM, encoder.MPNEncoder/HierMPNEncoder);
 device side: hand-written HIP kernels behind the C ABI in include/ggpm_hip.h (ggpm_amd/libggpm_hip.so).
 """
+import os as _os
+
+# One process uses up to five HIP streams (main, the high-priority atom-level stream, the second stream for transposes and
+# weight gradients, a copy stream, the collective's own) and RCCL brings its own; with the default of 4 hardware queues
+# streams share a queue and the encoder's second stream ends up behind the main one (measured: 5.94 instead of
+# 5.45 ms/step).  Read by the HIP runtime when it starts, so it is set HERE -- importing the package comes before the
+# first HIP call of any program that uses it -- and never overrides a value the user chose.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "IncMPNEncoder", "IncHierMPNEncoder",
            "IncEncoder", "HierEncoderVAE", "rsample", "make_cuda", "DevicePrefetcher"]
 
