@@ -59,9 +59,7 @@ SIGNATURES = {
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                      P, I, P, I, P, P, I, P, c_size_t, P]),
     "ggpm_backward_defer_stash": (None, [P, P, P, P]),
-    "ggpm_stream_create_cu_mask": (I, [P, I, P]),
     "ggpm_level_prefer_narrow": (None, [I]),
-    "ggpm_device_cu_count": (I, [P]),
     "ggpm_forward_gather_state": (None, [P, P, P]),
     "ggpm_backward_scatter_state": (None, [P, P, P]),
     "ggpm_weights_packed": (None, [I]),
@@ -93,14 +91,6 @@ SIGNATURES = {
     "ggpm_encoder_work_bytes": (c_size_t, [P]),
     "ggpm_encoder_forward": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
     "ggpm_encoder_backward": (I, [P, P, P, P, P, c_size_t, P, P, P, P, P, P, P, P, P, c_size_t, I, P, P]),
-    "ggpm_build_clusters": (I, [P, P, I, I, P, P, P]),
-    "ggpm_gru_persistent_supported": (I, [I]),
-    "ggpm_gru_persistent_ncg": (I, [I]),
-    "ggpm_gru_persistent_target_rows": (I, [I, I]),
-    "ggpm_gru_persistent_workspace_floats": (c_size_t, [I, I]),
-    "ggpm_gru_forward_persistent": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, I, P, P, P, P, P, P, P, P, P,
-                                        P, P]),
-    "ggpm_persistent_timeout": (I, [P, P]),
     "ggpm_timing_enable": (I, [I]),
     "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     # host-only decode schedule (csrc/schedule.hip): in: ggpm_sched_in*

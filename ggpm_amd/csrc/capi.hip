@@ -18,31 +18,6 @@ extern "C" const char* ggpm_error_string(int code) {
 
 extern "C" int ggpm_padded_hidden(int H) { return ggpm_round_up(H, 16); }
 
-// A stream whose kernels only run on the compute units named by `mask` (bit i of word i / 32; on a multi-XCD device the
-// driver deals the bits round-robin over the XCDs).  Two chains of small launches that do not depend on each other -- the
-// decoder's atom level and the encoder, in the full VAE step -- each get their own share of the chip instead of taking
-// turns on the same CUs.  The stream lives until the process ends.  -> 0, or an error code when the runtime declines.
-extern "C" int ggpm_stream_create_cu_mask(const uint32_t* mask, int words, void** out) {
-    GGPM_CLEAR_STALE_ERROR();
-    if (!mask || words <= 0 || !out) return GGPM_ERR_ARG;
-    hipStream_t s = nullptr;
-    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess || !s) {
-        (void)hipGetLastError();
-        return GGPM_ERR_UNSUPPORTED;
-    }
-    *out = (void*)s;
-    return GGPM_OK;
-}
-
-extern "C" int ggpm_device_cu_count(int* out) {
-    if (!out) return GGPM_ERR_ARG;
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return GGPM_ERR_LAUNCH;
-    *out = n;
-    return GGPM_OK;
-}
-
 // ---------------------------------------------------------------- timing sink (debug/bench only)
 namespace {
 struct Span { hipEvent_t a, b; double flops; };

@@ -444,13 +444,6 @@ def _accuracy(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return (pred.long() == labels).float().sum() / labels.numel()
 
 
-def _head_streams_enabled() -> bool:
-    # Opt-in experiment: the attachment head on a stream of its own measured -0.05 ms on a 9 ms step
-    # (the host, not the GPU, paces that part of the backward) and two gloo ranks sharing ONE GPU
-    # (tests/test_aa_data_parallel_gpu.py) stopped making progress with it.
-    return os.environ.get("GGPM_HEAD_STREAMS", "0") == "1"
-
-
 class HierMPNDecoder(ScoreHeads):
     """reference ggpm/decoder.py:19-301 (training forward)"""
 
@@ -513,14 +506,12 @@ class HierMPNDecoder(ScoreHeads):
             init_vecs = src_root_vecs
         else:
             init_vecs = F_.linear([src_root_vecs.contiguous()], [L], self.W_root.weight, self.W_root.bias)[:, :H]
-        assm_ctx = dict(src=src_graph_vecs)
         if os.environ.get("GGPM_DECODER_BATCHED", "1") != "0" and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_batched(schedule, D, tree_tensors, graph_tensors,
-                                                                            init_vecs, assm_ctx)
+                                                                            init_vecs)
         else:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_stepwise(D, tree_tensors, graph_tensors, init_vecs)
-        return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev,
-                            assm_ctx)
+        return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev)
 
     def _states_stepwise(self, D, tree_tensors, graph_tensors, init_vecs):
         """The reference's loop, step by step (ggpm/decoder.py:175-259): three incremental encoder calls per step."""
@@ -597,8 +588,7 @@ class HierMPNDecoder(ScoreHeads):
             return False
         D = schedule.to_device(dev)._dev
         main = torch.cuda.current_stream(dev)
-        split = F_.cu_split(dev)
-        side = split[0] if split is not None else self._ATOM_STREAMS.get(dev.index)
+        side = self._ATOM_STREAMS.get(dev.index)
         if side is None:
             # high priority: this chain of small dependent launches is the step's critical path, the encoder beside it
             # has slack -- where both have a kernel waiting for CUs, this one goes first (GGPM_ATOM_PRIORITY=0: default)
@@ -629,7 +619,7 @@ class HierMPNDecoder(ScoreHeads):
             return out
         return (out[0], out[1], ap) + tuple(out[2:])
 
-    def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs, assm_ctx=None):
+    def _states_batched(self, schedule, D, tree_tensors, graph_tensors, init_vecs):
         """Same vectors as ``_states_stepwise`` with the two tree-side levels de-sequentialised: only the atom level
         (diterG interacting iterations per step) keeps the step loop; the attachment and motif levels are ONE call each
         over all their messages (a DAG in decode time, DecodeSchedule._level_plan) and ONE read-out over all visits."""
@@ -670,24 +660,7 @@ class HierMPNDecoder(ScoreHeads):
                     assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
                     assm_dest.append(meta[k]["dest"])
 
-            if assm_ctx is not None and _head_streams_enabled() and dev.type == "cuda":
-                # The attachment head reads the atom level only (candidate atom vectors + the latent vector), not the two
-                # tree-side levels: it is issued HERE, on a stream of its own, and runs beside those levels -- forwards
-                # and, since autograd runs a node's backward on the stream of its forward, backwards too.
-                main = torch.cuda.current_stream(dev)
-                hs = F_.head_stream(dev, 0)
-                F_._MAIN_OF_PASS[0] = main
-                hs.wait_stream(main)
-                cand.record_stream(hs)
-                assm_ctx["src"].record_stream(hs)
-                _note_stream(D, hs)
-                with torch.cuda.stream(hs):
-                    ap.to_device(dev)                      # (notes the stream for the plan's own tables)
-                    attach_rows()
-                    assm_ctx["result"] = self._assm_head(schedule, D, assm_ctx["src"], assm_vecs, assm_dest, dev)
-                assm_ctx["stream"] = hs
-            else:
-                attach_rows()
+            attach_rows()
             steps = []
         else:
             # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot
@@ -769,8 +742,7 @@ class HierMPNDecoder(ScoreHeads):
         assm_acc = (s[:, 0] == s.max(dim=-1)[0]).float().sum() / P      # get_accuracy_sym
         return assm_loss, assm_acc
 
-    def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev,
-                assm_ctx=None):
+    def _losses(self, schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev):
         """The three batched heads and their losses / accuracies (ggpm/decoder.py:261-284)."""
         H = self.hidden_size
         topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch32"], topo_vecs)
@@ -781,14 +753,6 @@ class HierMPNDecoder(ScoreHeads):
                                                         D["cls_ilab"])
         cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
 
-        if assm_ctx is not None and "result" in assm_ctx:      # issued beside the tree-side levels on its own stream
-            assm_loss, assm_acc = assm_ctx["result"]
-            main = torch.cuda.current_stream(dev)
-            main.wait_stream(assm_ctx["stream"])
-            for t_ in (assm_loss, assm_acc):
-                if isinstance(t_, torch.Tensor):
-                    t_.record_stream(main)
-        else:
-            assm_loss, assm_acc = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev)
+        assm_loss, assm_acc = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev)
         loss = (topo_loss + cls_loss + assm_loss) / B
         return loss, cls_acc, icls_acc, topo_acc, assm_acc

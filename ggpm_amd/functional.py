@@ -62,20 +62,6 @@ class CSR:
         self._T: Optional["CSR"] = None
         self._T_event = None
         self._keep = None
-        self._clusters = {}
-
-    def clusters(self, target: int) -> torch.Tensor:
-        """Closed row ranges of >= ``target`` rows (molecule clusters) for the persistent depth-loop kernels:
-        int32 [n, bound_0 = 0, ..., bound_n = rows], built on the device (no host sync)."""
-        tab = self._clusters.get(target)
-        if tab is None:
-            dev = self.col.device
-            tab = torch.empty(self.rows + 4, dtype=torch.int32, device=dev)
-            scratch = torch.empty(3 * self.rows, dtype=torch.int32, device=dev)
-            _lib.check(_lib.load().ggpm_build_clusters(_p(self.rowptr), _p(self.col), self.rows, target, _p(tab),
-                                                       _p(scratch), _stream()), "build_clusters")
-            self._clusters[target] = tab
-        return tab
 
     def _build_T(self) -> "CSR":
         lib = _lib.load()
@@ -508,54 +494,6 @@ def side_stream_enabled() -> bool:
     return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
 
 
-_CU_SPLIT: dict = {}
-
-
-def cu_split(device):
-    """(atom-level stream, encoder stream) restricted to disjoint sets of compute units, or None.
-
-    In the full VAE step the decoder's atom level (a chain of ~250 small dependent launches per direction, the step's
-    critical path) runs beside the encoder (larger launches with slack).  Sharing all CUs, a chain launch that finds the
-    chip full of encoder workgroups waits for them to drain; with GGPM_CU_SPLIT=n the chain's stream owns n compute units
-    and the encoder's stream the rest (csrc/capi.hip: ggpm_stream_create_cu_mask).  0 / unset: off."""
-    n = int(os.environ.get("GGPM_CU_SPLIT", "0") or 0)
-    if n <= 0 or device.type != "cuda":
-        return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
-    if key not in _CU_SPLIT:
-        import ctypes
-        lib = _lib.load()
-        total = ctypes.c_int(0)
-        made = None
-        with torch.cuda.device(device):
-            if lib.ggpm_device_cu_count(ctypes.byref(total)) == 0 and 0 < n < total.value:
-                words = (total.value + 31) // 32
-                streams = []
-                for lo, hi in ((0, n), (n, total.value)):
-                    mask = (ctypes.c_uint32 * words)()
-                    for i in range(lo, hi):
-                        mask[i // 32] |= 1 << (i % 32)
-                    out = ctypes.c_void_p(0)
-                    if lib.ggpm_stream_create_cu_mask(mask, words, ctypes.byref(out)) != 0 or not out.value:
-                        streams = None
-                        break
-                    streams.append(torch.cuda.ExternalStream(out.value, device=device))
-                made = tuple(streams) if streams else None
-        _CU_SPLIT[key] = made
-    return _CU_SPLIT[key]
-
-
-_HEAD: dict = {}
-
-
-def head_stream(device, which: int = 0) -> torch.cuda.Stream:
-    """Streams for branches of the decoder's heads that do not depend on each other (decoder._losses)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
-    if key not in _HEAD:
-        _HEAD[key] = torch.cuda.Stream(device=device)
-    return _HEAD[key]
-
-
 def _side_stream(device) -> torch.cuda.Stream:
     key = (device.index if device.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
@@ -613,8 +551,7 @@ def mark(name: str) -> None:
 # backward pass ends (autograd engine callback) every parameter gets ONE contraction over the stacked rows of all its
 # visits -- dW = [dpre_1; dpre_2; ...]^T [x_1; x_2; ...], the same sum in a different order -- and other per-visit
 # parameter gradients (the message functions', the embedding tables') are summed by one stacked reduction each.
-_DEFER = {"linear": {}, "sum": {}, "gather": {}, "task": None, "stream": None, "early": None, "pending": [],
-          "others": []}      # others: streams other than "stream" that queued entries since the last flush (head streams)
+_DEFER = {"linear": {}, "sum": {}, "gather": {}, "task": None, "stream": None, "early": None, "pending": []}
 
 
 def defer_wgrads_enabled() -> bool:
@@ -633,11 +570,6 @@ def can_publish(*params) -> bool:
     return all(p is None or (getattr(p, "is_leaf", False) and p.requires_grad and not _has_hooks(p)) for p in params)
 
 
-# The stream the step's main line runs on, told by whoever forks work onto other streams (decoder head streams): a
-# backward pass may reach a node of a forked branch first, and the deferred queue must still hang on the main stream.
-_MAIN_OF_PASS = [None]
-
-
 def _defer_register() -> None:
     """Queue the end-of-backward flush once per backward pass.  A pass is identified by the autograd engine's graph
     task id: a pass that RAISED never ran its callbacks, so whatever it left queued is dropped when the next pass
@@ -647,14 +579,10 @@ def _defer_register() -> None:
         _DEFER["linear"].clear()
         _DEFER["sum"].clear()
         _DEFER["gather"].clear()
-        _DEFER["pending"], _DEFER["early"], _DEFER["others"] = [], None, []
+        _DEFER["pending"], _DEFER["early"] = [], None
         _DEFER["task"] = task
-        _DEFER["stream"] = _MAIN_OF_PASS[0] or torch.cuda.current_stream()
+        _DEFER["stream"] = torch.cuda.current_stream()
         torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
-    if torch.cuda.is_available():
-        cur = torch.cuda.current_stream()
-        if cur != _DEFER["stream"] and cur not in _DEFER["others"]:
-            _DEFER["others"].append(cur)      # the flush orders itself behind this stream too
 
 
 def _defer_linear(weight, bias, dpre, xs, Ks) -> None:
@@ -694,7 +622,6 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
     _DEFER["sum"].clear()
     _DEFER["gather"].clear()
     main = _DEFER["stream"]
-    others, _DEFER["others"] = _DEFER["others"], []
     if side is None:
         _DEFER["task"] = None
         mark("bwd: end-of-pass flush starts")
@@ -715,11 +642,9 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
         side.wait_stream(main)
         stream = side
         _DEFER["early"] = side
-    for o in others:                       # entries queued by nodes that ran on other streams (the decoder's head streams)
-        stream.wait_stream(o)
 
     def use(t):                            # queued on one stream, read on another: keep the allocator from recycling it early
-        if (side is not None or others) and isinstance(t, torch.Tensor) and t.is_cuda:
+        if side is not None and isinstance(t, torch.Tensor) and t.is_cuda:
             t.record_stream(stream)
         return t
 
@@ -771,29 +696,6 @@ def flush_deferred_early() -> None:
     _defer_flush(side=_side_stream(main.device))       # (the end-of-backward callback stays registered: it publishes)
 
 
-# ----------------------------------------------------------------------------- persistent depth loops
-# GGPM_PERSISTENT=1 (opt-in, experimental): one launch per level runs all forward depth steps (molecule clusters,
-# csrc/mpn_gru_persist.hip); the default keeps the two-launches-per-depth kernels of csrc/mpn_gru.hip, which
-# measured faster end to end on MI355X ("persistent depth loop").
-_PERSIST = {"sync": None}
-
-
-def persistent_enabled() -> bool:
-    return os.environ.get("GGPM_PERSISTENT", "0") != "0"
-
-
-def persistent_max_rows() -> int:
-    return int(os.environ.get("GGPM_PERSISTENT_MAX_ROWS", "32"))
-
-
-def persistent_timeout() -> int:
-    """Timeout word of the most recent persistent launch (synchronises; 0 = all cluster waits completed)."""
-    sync = _PERSIST["sync"]
-    if sync is None:
-        return 0
-    return int(_lib.load().ggpm_persistent_timeout(_p(sync), _stream()))
-
-
 def _split_cols(W: torch.Tensor, I: int):
     """(x-half view, h-half view) of a [H, I+H] gate weight; both share W's row stride."""
     return W[:, :I], W[:, I:]
@@ -832,24 +734,11 @@ class _GruLevel(torch.autograd.Function):
             Hs = torch.empty(2, E1, Hp, **f32)
             Qs = torch.empty(2, E1, Hp, **f32)
             Ss = Gs = Zs = Ms = Rs = None
-        target = int(lib.ggpm_gru_persistent_target_rows(E1, H)) if save and persistent_enabled() else 0
-        # the one-launch cluster kernel wins where the level is latency bound (few rows per molecule cluster); big
-        # levels are MFMA / L2 bound either way and keep the two-launches-per-depth kernels
-        if target and target <= persistent_max_rows() and lib.ggpm_gru_persistent_supported(H):
-            table = pred.clusters(target)
-            xwork = torch.empty(int(lib.ggpm_gru_persistent_workspace_floats(E1, H)), **f32)
-            sync = torch.empty(8 + E1 // target + 4, dtype=torch.int32, device=x.device)
-            _lib.check(lib.ggpm_gru_forward_persistent(
-                E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0), _p(b_u),
-                _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(table), target, _p(Hs), _p(Qs), _p(Ss),
-                _p(Gs), _p(Zs), _p(Ms), _p(Rs), _p(wpack), _p(xwork), _p(sync), _stream()), "gru_forward_persistent")
-            _PERSIST["sync"] = sync
-        else:
-            with _gate_dtype(gate_dtype):
-                _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0),
-                                                _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr),
-                                                _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
-                                                _p(wpack), int(save), _stream()), "gru_forward")
+        with _gate_dtype(gate_dtype):
+            _lib.check(lib.ggpm_gru_forward(E1, H, depth, _p(X[0]), _p(X[1]), _p(X[2]), _p(Wz_h), W_z.stride(0),
+                                            _p(U_r), U_r.stride(0), _p(b_u), _p(Wh_h), W_h.stride(0), _p(pred.rowptr),
+                                            _p(pred.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                            _p(wpack), int(save), _stream()), "gru_forward")
         if save:
             ctx.save_for_backward(x, W_z, W_r, U_r, W_h)
             ctx.stash = (X[1], Hs, Qs, Ss, Gs, Zs, Ms, Rs)

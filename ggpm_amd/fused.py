@@ -76,10 +76,6 @@ def _side_ptr(device):
     return side, ctypes.c_void_p(side.cuda_stream)
 
 
-# The stream of the caller's main line when the encoder is run on a stream of its own (property_vae: functional.cu_split).
-# Gradients that this node writes itself (flat gradient buffer) are then ordered in front of the caller's stream when the
-# backward pass ends.
-CALLER_STREAM = [None]
 # True while the caller runs the encoder beside another chain of launches (property_vae: the decoder's atom level): the
 # level kernels then take half as many workgroups (ggpm_level_prefer_narrow), forwards and backwards.
 NARROW = [False]
@@ -122,7 +118,6 @@ class _HierEncoder(torch.autograd.Function):
             # second time" error instead of failing on a cleared attribute
             ctx.save_for_backward(saved, roots, hroot, hnode, hinter, hatom, *params)
             ctx.dims, ctx.grad_sink = dims, grad_sink
-            ctx.caller_stream = CALLER_STREAM[0]
             ctx.narrow = narrow
         return hroot, hnode, hinter, hatom
 
@@ -175,9 +170,6 @@ class _HierEncoder(torch.autograd.Function):
                 if getattr(ctx, "narrow", False):
                     lib.ggpm_level_prefer_narrow(0)
 
-        caller = getattr(ctx, "caller_stream", None)
-        if caller is not None and caller != torch.cuda.current_stream():
-            F_._join_later(caller, torch.cuda.current_stream())
         if sink is not None and side is not None and sink.wants_early_bucket():
             run(1)                      # everything but the atom level; its gradients complete on the second stream
             with torch.cuda.stream(side):

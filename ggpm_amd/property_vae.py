@@ -252,33 +252,15 @@ class HierPropertyVAE(nn.Module):
         F_.mark("fwd: inputs on the device")
         self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
         F_.mark("fwd: atom level posted")
-        split = F_.cu_split(tree_tensors[0].device) if getattr(self.decoder, "_atom_ahead", None) is not None else None
-        if split is not None:
-            # the encoder on the compute units the atom level's stream does not own (functional.cu_split); its backward
-            # runs on the same stream, beside the atom level's backward
-            from . import fused
-            main, enc = torch.cuda.current_stream(), split[1]
-            enc.wait_stream(main)
-            for t in list(tree_tensors[:5]) + list(graph_tensors[:4]):
-                t.record_stream(enc)
-            fused.CALLER_STREAM[0] = main
-            try:
-                with torch.cuda.stream(enc):
-                    root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
-            finally:
-                fused.CALLER_STREAM[0] = None
-            main.wait_stream(enc)
-            root_vecs.record_stream(main)
-        else:
-            # beside the atom level's chain of small launches the encoder's levels take half as many (twice as large)
-            # workgroups: the chain's launches then find free compute units instead of waiting for the encoder's to drain
-            from . import fused
-            beside = getattr(self.decoder, "_atom_ahead", None) is not None and os.environ.get("GGPM_ENC_NARROW", "1") != "0"
-            fused.NARROW[0] = beside
-            try:
-                root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
-            finally:
-                fused.NARROW[0] = False
+        # beside the atom level's chain of small launches the encoder's levels take half as many (twice as large)
+        # workgroups: the chain's launches then find free compute units instead of waiting for the encoder's to drain
+        from . import fused
+        beside = getattr(self.decoder, "_atom_ahead", None) is not None and os.environ.get("GGPM_ENC_NARROW", "1") != "0"
+        fused.NARROW[0] = beside
+        try:
+            root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
+        finally:
+            fused.NARROW[0] = False
         root_vecs, kl_div = rsample(root_vecs, self.R_mean, self.R_var, perturb_z)
         F_.mark("fwd: encoder + rsample issued")
         loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,

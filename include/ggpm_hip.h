@@ -46,12 +46,6 @@ int ggpm_version(void);
 const char* ggpm_error_string(int code);
 /* Padded feature stride used by the message kernels: H rounded up to a multiple of 16. */
 int ggpm_padded_hidden(int H);
-/* A stream restricted to the compute units named by `mask` (`words` uint32; bit i = CU i as the driver numbers them) and
- * the device's CU count.  Used by ggpm_amd/decoder.py / property_vae.py to give the two independent chains of the full VAE
- * step (HierMPNDecoder's atom level, ggpm/decoder.py:201-222, and HierMPNEncoder, ggpm/encoder.py:140-157) disjoint shares of
- * the chip.  The stream is never destroyed.  GGPM_ERR_UNSUPPORTED when the runtime declines the mask. */
-int ggpm_stream_create_cu_mask(const uint32_t* mask, int words, void** out);
-int ggpm_device_cu_count(int* out);
 
 /* ------------------------------------------------------------------ graph layout
  * A0 (ggpm/mol_graph.py:238-281, create_pad_tensor ggpm/nnutils.py:105-110): agraph/bgraph/cgraph
@@ -468,28 +462,6 @@ int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* params, float
                           const float* hatom, const float* d_hroot, const float* d_hnode, const float* d_hinter,
                           const float* d_hatom, void* work, size_t work_bytes, int phase, ggpm_stream_t stream,
                           ggpm_stream_t side_stream);
-
-/* ------------------------------------------------------------------ persistent depth loop (molecule clusters)
- * The message recurrence of ggpm/rnn.py:41-50 only couples messages of one molecule.  ggpm_build_clusters cuts the
- * level's rows into closed ranges of >= target_rows rows (table: int32[E1+4], scratch: int32[3*E1]); the persistent
- * forward runs ALL depth steps in one launch, each cluster owned by ggpm_gru_persistent_ncg(H) workgroups that keep
- * their gate-weight slices in registers and synchronise per cluster only.  Same outputs and stashes as ggpm_gru_forward
- * with save_for_backward = 1 (Qs has `depth` slots).  xwork: ggpm_gru_persistent_workspace_floats floats; sync:
- * 8 + E1/target_rows uint32 words (zeroed by the call).  ggpm_persistent_timeout synchronises the stream and returns
- * the launch's timeout word (0 = every cluster wait completed). */
-int ggpm_build_clusters(const int32_t* pred_rowptr, const int32_t* pred_col, int E1, int target_rows, int32_t* table,
-                        int32_t* scratch, ggpm_stream_t stream);
-int ggpm_gru_persistent_supported(int H);
-int ggpm_gru_persistent_ncg(int H);
-int ggpm_gru_persistent_target_rows(int E1, int H);
-size_t ggpm_gru_persistent_workspace_floats(int E1, int H);
-int ggpm_gru_forward_persistent(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
-                                const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
-                                const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
-                                const int32_t* clusters, int target_rows, float* Hs, float* Qs, float* Ss, float* Gs,
-                                float* Zs, float* Ms, float* Rs, float* wpack, float* xwork, uint32_t* sync,
-                                ggpm_stream_t stream);
-int ggpm_persistent_timeout(uint32_t* sync, ggpm_stream_t stream);
 
 /* ------------------------------------------------------------------ instrumentation
  * When a timing sink is installed, every depth-step kernel launch is bracketed by HIP events on its own

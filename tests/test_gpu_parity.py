@@ -350,29 +350,6 @@ def test_narrow_level_kernels_agree_with_the_default_form(name):
         assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-30), (float((a - b).abs().max()), scale)
 
 
-def test_cu_masked_stream_runs_kernels():
-    """ggpm_stream_create_cu_mask: a stream restricted to the first 64 compute units is a usable stream (the experiment
-    of DESIGN.md section 9; the entry point is part of the C ABI)."""
-    import ctypes
-    from ggpm_amd import _lib
-    lib = _lib.load()
-    n = ctypes.c_int(0)
-    assert lib.ggpm_device_cu_count(ctypes.byref(n)) == 0 and n.value >= 64
-    words = (n.value + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    mask[0] = mask[1] = 0xFFFFFFFF
-    out = ctypes.c_void_p(0)
-    assert lib.ggpm_stream_create_cu_mask(mask, words, ctypes.byref(out)) == 0 and out.value
-    s = torch.cuda.ExternalStream(out.value, device=_dev())
-    a = torch.randn(256, 256, device=_dev())
-    want = (a @ a).cpu()
-    with torch.cuda.stream(s):
-        got = a @ a
-    s.synchronize()
-    assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-4)
-    assert lib.ggpm_stream_create_cu_mask(None, words, ctypes.byref(out)) != 0
-
-
 @pytest.mark.parametrize("name", case_names(motif=True))
 def test_motif_encoder_matches_reference_golden(name):
     """MotifEncoder drop-in (reference ggpm/encoder.py:252-341) vs vectors produced by the reference itself."""
@@ -699,42 +676,6 @@ def test_incremental_encoder_teacher_forced_matches_reference_golden(name):
         grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
         e = rel_err(grad, g.z["grad/" + k]) if np.abs(g.z["grad/" + k]).max() > 0 else float(np.abs(grad).max())
         assert e < TOL, "%s grad %s rel err %.3e" % (name, k, e)
-
-
-# ------------------------------------------------------------------------------------------ persistent depth loop
-@pytest.mark.parametrize("rnn,H,depth,motifs,B", [("GRU", 16, 3, (2, 4), 3), ("GRU", 24, 4, (1, 5), 5),
-                                                  ("GRU", 100, 5, (4, 7), 6), ("GRU", 300, 20, (8, 12), 32),
-                                                  ("GRU", 250, 6, (30, 40), 2)])
-def test_persistent_depth_loop_matches_stepwise_kernels(rnn, H, depth, motifs, B, monkeypatch):
-    """The one-launch-per-level cluster kernels (csrc/mpn_gru_persist.hip) against the two-launches-per-depth
-    kernels on the same level: final state, every stash the backward reads, and the gradients; no cluster wait
-    may have timed out."""
-    from ggpm_amd import synth, rnn as R, functional as F_
-    dev = _dev()
-    specs = synth.random_batch(H + depth, B, motifs=motifs, n_motif_vocab=11, n_attach_vocab=33)
-    tree, graph = synth.tensorize(specs)
-    for tens, I in ((graph, 62), (tree, H + 20)):
-        bg = torch.from_numpy(tens[3].astype(np.int64)).to(dev)
-        E1 = bg.shape[0]
-        torch.manual_seed(E1)
-        x = torch.randn(E1, I, device=dev)
-        x[0] = 0
-        mod = (R.GRU if rnn == "GRU" else R.LSTM)(I, H, depth).to(dev)
-        coef = torch.randn(E1, H, device=dev)
-        res = []
-        for flag in ("0", "1"):
-            monkeypatch.setenv("GGPM_PERSISTENT", flag)
-            monkeypatch.setenv("GGPM_PERSISTENT_MAX_ROWS", "100000")
-            mod.zero_grad(set_to_none=True)
-            xg = x.clone().requires_grad_(True)
-            h = mod(xg, bg)
-            (h * coef).sum().backward()
-            assert F_.persistent_timeout() == 0
-            res.append([h.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in mod.parameters()])
-        assert F_._PERSIST["sync"] is not None          # the persistent path did run
-        for a, b in zip(*res):
-            scale = max(float(a.abs().max()), 1e-6)
-            assert float((a - b).abs().max()) <= 2e-5 * scale
 
 
 # ------------------------------------------------------------------------------------------ whole-encoder C++ drivers
@@ -1384,8 +1325,8 @@ def test_softmax_ce_and_bce_kernels_against_torch(M, N, masked):
     assert float((s.grad - s2.grad).abs().max()) <= 2e-6
 
 
-def test_csr_table4_and_cluster_builder():
-    """ggpm_csr_table4 (first four entries, overflow marker) and ggpm_build_clusters (closed row ranges) vs numpy."""
+def test_csr_table4():
+    """ggpm_csr_table4 (first four entries, overflow marker) vs numpy."""
     import ctypes
     from ggpm_amd import _lib, synth, functional as F_
     dev = _dev()
@@ -1405,13 +1346,3 @@ def test_csr_table4_and_cluster_builder():
         if len(ent) > 4:
             exp[3] = -1
         assert list(got[r]) == exp
-    for target in (8, 40, 10 ** 6):
-        table = csr.clusters(target).cpu().numpy()
-        n = int(table[0])
-        bounds = table[1:n + 2]
-        assert bounds[0] == 0 and bounds[-1] == E1 and (np.diff(bounds) > 0).all()
-        assert all(b - a >= target for a, b in zip(bounds[:-2], bounds[1:-1]))
-        for a, b in zip(bounds[:-1], bounds[1:]):           # closed: every predecessor of a row lies in its own range
-            sub = pad[a:b]
-            nz = sub[sub != 0]
-            assert nz.size == 0 or (nz.min() >= a and nz.max() < b)

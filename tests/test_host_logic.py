@@ -171,15 +171,6 @@ def test_state_dict_keys_are_the_references(name):
                          for k in extra), sorted(extra)
 
 
-def test_cu_split_is_off_unless_asked_for(monkeypatch):
-    """functional.cu_split: no masked streams without GGPM_CU_SPLIT, never on the CPU"""
-    from ggpm_amd import functional as F_
-    monkeypatch.delenv("GGPM_CU_SPLIT", raising=False)
-    assert F_.cu_split(torch.device("cpu")) is None
-    monkeypatch.setenv("GGPM_CU_SPLIT", "128")
-    assert F_.cu_split(torch.device("cpu")) is None
-
-
 def test_published_gradients_are_not_stream_marked_by_default():
     """functional.hand_to: a gradient handed from a helper stream to the main stream gets no record_stream mark (on ROCm
     each mark is an event record on that stream when the tensor is released); GGPM_RECORD_GRADS=1 at import restores it"""
