@@ -32,17 +32,24 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:
+    """Compile every source for gfx950 and link ggpm_amd/libggpm_hip.so.
+
+    ``variant`` / ``defines``: a second build of the same sources with compile-time tuning or ablation switches
+    (``-DGGPM_...``), written to ggpm_amd/libggpm_hip.<variant>.so and selected at run time with GGPM_LIB_PATH -- how the
+    A/B figures of DESIGN.md were measured without a runtime switch in the product."""
+    lib = LIB_PATH if not variant else LIB_PATH.replace(".so", ".%s.so" % variant)
+    if not variant and not force and not needs_build():
         return LIB_PATH
     objs, procs = [], []
-    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+    bdir = os.path.join(PKG_DIR, "build" if not variant else "build_" + variant)
+    os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             raise FileNotFoundError(path)
-        obj = os.path.join(PKG_DIR, "build", src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-c", path, "-o", obj]
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17"] + list(defines) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))
@@ -50,13 +57,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB_PATH)
+    # python -m ggpm_amd.build [--force] [--variant NAME -DGGPM_X=1 ...]
+    name = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, variant=name, defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

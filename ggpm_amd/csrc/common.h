@@ -27,6 +27,15 @@ __device__ __forceinline__ float ggpm_sigmoid(float x) { return 1.0f / (1.0f + e
 __device__ __forceinline__ float4 ggpm_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void ggpm_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// base (uniform, in scalar registers) + a 32-bit BYTE offset per lane: the backend then addresses with the scalar base and ONE
+// offset register for every array that shares the offset, instead of a 64-bit address pair per array
+__device__ __forceinline__ float4 ggpm_ld4o(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void ggpm_st4o(float* base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
@@ -39,7 +48,11 @@ __device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
 __device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // sigmoid on the hardware exp2 / rcp units (~2 ulp): the gather phases of the depth kernels evaluate one per gathered
 // neighbour element and were VALU bound with the libm expf + IEEE division forms
+#ifdef GGPM_ABL_EXACT_GATHER_SIGMOID      // ablation build (python -m ggpm_amd.build --variant exactsig -DGGPM_ABL_EXACT_GATHER_SIGMOID):
+__device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_sigmoid(x); }      // libm expf + IEEE division in the gathers too
+#else
 __device__ __forceinline__ float ggpm_fsigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+#endif
 // tanh(x) = 1 - 2 / (1 + exp(2x)) on the same units (absolute error ~2e-7)
 __device__ __forceinline__ float ggpm_ftanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {

@@ -63,7 +63,7 @@ struct Dims {
     int tree_chain;                // longest dependency chain of the tree messages (0: unknown)
     float dropout;                 // training-mode drop probability (0: none)
     unsigned int seed_lo, seed_hi;
-    int gate_dtype;                // 0 fp32, 1 bf16 operands for the gate products of the depth loops
+    int gate_dtype;                // 0 fp32, 1 bf16 operands for the gate products of the depth loops, 2 fp32 on fp32 MFMA only
 };
 
 // the level calls of this thread take the gate-product dtype from a thread-local (tile_mma.h) for the driver's duration
@@ -92,7 +92,7 @@ Dims make_dims(const ggpm_enc_dims* d) {
     x.lstm = d->rnn_type == 1; x.nX = x.lstm ? 4 : 3; x.lcount = x.lstm ? 10 : 9;
     x.tree_chain = d->tree_chain;
     x.dropout = d->dropout; x.seed_lo = d->seed_lo; x.seed_hi = d->seed_hi;
-    x.gate_dtype = d->gate_dtype == 1 ? 1 : 0;
+    x.gate_dtype = (d->gate_dtype >= 1 && d->gate_dtype <= 3) ? d->gate_dtype : 0;
     return x;
 }
 

@@ -30,6 +30,27 @@ __global__ void ggpm_pack_weight_kernel(GgpmPackArgs a) {
     const float* __restrict__ W = a.W[m];
     const int ldw = a.ldw[m];
     const int out = 16 * t + (lane & 15);
+    if (a.bf16 == 2) {                       // three bf16 planes (ggpm_wave_gemm_split); grid.x = kc32(Hp) chunks of 32 columns
+        const int KC32 = ggpm_kc32_dev(Hp);
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 32 * kc + 8 * (lane >> 4) + i;
+            x[i] = (out < H && k < H) ? (a.transpose ? W[(size_t)k * ldw + out] : W[(size_t)out * ldw + k]) : 0.f;
+        }
+        uint2 lo[3], hi[3];
+        ggpm_split3(make_float4(x[0], x[1], x[2], x[3]), lo[0], lo[1], lo[2]);
+        ggpm_split3(make_float4(x[4], x[5], x[6], x[7]), hi[0], hi[1], hi[2]);
+        __bf16* dst = reinterpret_cast<__bf16*>(a.dst) + (size_t)m * 2 * ggpm_packed_matrix_floats(Hp, 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint4*>(dst + ggpm_pack_index_split(t, kc, KC32, pl, lane)) = make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y);
+        if (a.bias && m == 0 && t == 0 && kc * 64 + lane < Hp) {
+            const int c = kc * 64 + lane;
+            a.bias_out[c] = (c < H) ? a.bias[c] : 0.f;
+        }
+        return;
+    }
     if (a.bf16) {                            // grid.x = kc32(Hp) chunks of 32 columns
         const int KC32 = ggpm_kc32_dev(Hp);
         bf16x8 v;
@@ -70,11 +91,14 @@ void ggpm_launch_pack(const GgpmPackArgs& a, int nmat, hipStream_t s) {
 }
 
 namespace { thread_local int g_gate_dtype = 0; }
-void ggpm_set_gate_dtype(int dtype) { g_gate_dtype = dtype == 1 ? 1 : 0; }
+// 0: fp32 (gate products on split operands where the level's shape allows, see gate_mode below); 1: bf16 operands;
+// 2: fp32 on v_mfma_f32_16x16x4_f32 only, 3: fp32 on split operands wherever they fit the LDS (the two forms every fp32
+// call chooses between, selectable so that they can be compared on one shape)
+void ggpm_set_gate_dtype(int dtype) { g_gate_dtype = (dtype >= 1 && dtype <= 3) ? dtype : 0; }
 int ggpm_gate_dtype() { return g_gate_dtype; }
 extern "C" int ggpm_level_gate_dtype(int dtype) {
     const int prev = g_gate_dtype;
-    if (dtype == 0 || dtype == 1) g_gate_dtype = dtype;
+    if (dtype >= 0 && dtype <= 3) g_gate_dtype = dtype;
     return prev;
 }
 
@@ -106,7 +130,8 @@ struct GruFwdArgs {
     int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
     unsigned long long* dbg;       // optional phase stamps of workgroup (0,0) (GGPM_ADEBUG; dev only)
     const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
-    int bf16;                      // gate products on bf16 operands (packed weights are bf16 fragments then)
+    int bf16;                      // gate mode: 0 fp32 MFMA, 1 bf16 operands (packed weights are bf16 fragments), 2 fp32 on
+                                   // split operands (three bf16 planes per operand, tile_mma.h)
     int h0_zero;                   // first depth of a dense level: h^0 = 0, so s = g = 0 without a gather and the gate
                                    // products vanish (h^1 = sigmoid(x_z) tanh(x_h)); H^0 / Q^0 are neither built nor read
     const float* src_h;            // kernel B of a sparse forward's q^0 launch (ggpm_forward_gather_state): row r of the
@@ -124,13 +149,22 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time (full Hp width: two 256-column sweeps
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
-template <bool STASH, bool BF16, int RTT>
+template <bool STASH, int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;
     float* Tg = lds + ROWS * LD;
+    // split operands: Ts stays (the epilogue reads s in fp32); behind it the bf16 images of s, g and (fused q') h'
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp);
+    const int IMG = ggpm_split_image_halves(ROWS, Hp);
+    __bf16* Is = reinterpret_cast<__bf16*>(lds + ROWS * LD);
+    __bf16* Ig = Is + IMG;
+    __bf16* Ih = Ig + IMG;
+    if constexpr (SPLIT) ggpm_split_init(Is, a.fuse_b ? 3 : 2, ROWS, Hp);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
@@ -193,7 +227,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             for (int k = 0; k < 2; ++k) {
                 if (!on[k]) continue;
                 ggpm_st4(Ts + lr * LD + c[k], s[k]);
-                ggpm_st4(Tg + lr * LD + c[k], g[k]);
+                if constexpr (SPLIT) {
+                    ggpm_split_store(Is, PLANE, LDH, lr, c[k], s[k]);
+                    ggpm_split_store(Ig, PLANE, LDH, lr, c[k], g[k]);
+                } else {
+                    ggpm_st4(Tg + lr * LD + c[k], g[k]);
+                }
                 if (STASH && row < a.E1 && (c[k] >> 4) / a.tg == grp) {
                     const size_t o = (size_t)row * Hp + c[k];
                     ggpm_st4(a.S + o, s[k]);
@@ -210,9 +249,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     const int t_end = min(NT, (grp + 1) * a.tg);
     const bool p2_gemm = !(a.ablate & 2) && !a.h0_zero;
     const float* const wps2[2] = {a.Wz, a.Wh};
-    GgpmRing<2> ring2;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<2>, GgpmNoRing> ring2;
+    std::conditional_t<SPLIT, GgpmSplitRing<2>, GgpmNoRing> sring2;
+    if constexpr (GM == 0)
         if (p2_gemm && t < t_end) ggpm_ring_prefetch<2>(wps2, KC, t, lane, ring2);
+    if constexpr (SPLIT)
+        if (p2_gemm && t < t_end) ggpm_split_ring_prefetch<2>(wps2, KC32, t, lane, sring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
@@ -235,8 +277,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
         ggpm_zero_acc<2, RTT>(acc);
         if (p2_gemm) {
             const float* const tiles[2] = {Ts, Tg};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[2] = {Is, Ig};
+                ggpm_wave_gemm_split<2>(imgs, PLANE, LDH, wps2, KC32, tt, tn, lane, acc, sring2);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps2, KC, tt, tn, lane, acc, ring2);
         }
         if constexpr (RTT != 1) load_inputs();
         if (dbg_on) a.dbg[3] = wall_clock64();
@@ -245,8 +291,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             const int lrow = 16 * r + lr, row = r0 + lrow;
             const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
             float4 h = ggpm_zero4(), z = ggpm_zero4(), m = ggpm_zero4();
+            auto keep_h = [&](float4 v) {          // the complete h' rows for the fused q' phase
+                if constexpr (SPLIT) ggpm_split_store(Ih, PLANE, LDH, lrow, c, v);
+                else ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, v);
+            };
             if (row >= a.E1) {
-                if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, h);
+                if (a.fuse_b) keep_h(h);
                 continue;
             }
             if (a.frozen && a.frozen[row]) {
@@ -260,7 +310,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                                 (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
             }
             ggpm_st4(a.Hnew + o, h);
-            if (a.fuse_b) ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, h);
+            if (a.fuse_b) keep_h(h);
             if (STASH) {
                 ggpm_st4(a.Z + o, z);
                 ggpm_st4(a.M + o, m);
@@ -274,9 +324,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     if constexpr (RTT == 1) {
         const int row = r0 + lr;
         const float* const wps3[1] = {a.Ur};
-        GgpmRing<1> ring3;
-        if constexpr (!BF16)
+        std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring3;
+        std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring3;
+        if constexpr (GM == 0)
             if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+        if constexpr (SPLIT)
+            if (wave < NT) ggpm_split_ring_prefetch<1>(wps3, KC32, wave, lane, sring3);
         ggpm_lds_barrier();
         const float* Th = lds + 2 * ROWS * LD;
         for (int tt = wave; tt < NT; tt += GGPM_NWA) {
@@ -285,31 +338,47 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
             f32x4 acc[1][1];
             ggpm_zero_acc<1, 1>(acc);
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            const int tn = tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[1] = {Ih};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
         }
     }
 }
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp);
+    __bf16* Ih = reinterpret_cast<__bf16*>(lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[1] = {a.Ur};
-    GgpmRing<1> ring;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring;
+    std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring;
+    if constexpr (GM == 0)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
-    if (a.src_idx) ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
-    else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+    if constexpr (SPLIT) {
+        if (grp * a.tg + wave < t_end) ggpm_split_ring_prefetch<1>(wps, KC32, grp * a.tg + wave, lane, sring);
+        ggpm_split_init(Ih, 1, ROWS, Hp);
+        if (a.src_idx) ggpm_gather_rows_to_lds_split<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, Ih, PLANE, LDH, grp == 0 ? a.Hnew : nullptr);
+        else ggpm_load_rows_to_lds_split<ROWS>(a.Hnew, r0, a.E1, Hp, Ih, PLANE, LDH);
+    } else {
+        if (a.src_idx) ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
+        else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+    }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
@@ -318,8 +387,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
         ggpm_zero_acc<1, RTT>(acc);
         if (!(a.ablate & 2)) {
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[1] = {Ih};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps, KC32, tt, tn, lane, acc, sring);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tn, lane, acc, ring);
         }
 #pragma unroll
         for (int r = 0; r < RTT; ++r) {
@@ -361,13 +434,22 @@ struct GruBwdArgs {
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
 // gate derivatives for this workgroup's column group.
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T0 = lds;                  // dh partial
     float* T1 = lds + ROWS * LD;      // dq
+    // split operands: T0 stays fp32 (epilogue only); behind it the bf16 images of dq and (fused dS / dG) dz_pre, dm_pre
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp);
+    const int IMG = ggpm_split_image_halves(ROWS, Hp);
+    __bf16* I1 = reinterpret_cast<__bf16*>(lds + ROWS * LD);
+    __bf16* Iz = I1 + IMG;
+    __bf16* Im = Iz + IMG;
+    if constexpr (SPLIT) ggpm_split_init(I1, a.fuse_b ? 3 : 1, ROWS, Hp);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
@@ -429,7 +511,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 for (int k = 0; k < 2; ++k) {
                     if (!on[k]) continue;
                     ggpm_st4(T0 + lr * LD + c[k], dh[k]);
-                    ggpm_st4(T1 + lr * LD + c[k], dq[k]);
+                    if constexpr (SPLIT) ggpm_split_store(I1, PLANE, LDH, lr, c[k], dq[k]);
+                    else ggpm_st4(T1 + lr * LD + c[k], dq[k]);
                     if (p < a.E1 && (c[k] >> 4) / a.tg == grp) ggpm_st4(a.DQ + (size_t)p * Hp + c[k], dq[k]);
                 }
             }
@@ -439,9 +522,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     if (dbg_on) a.dbg[1] = wall_clock64();
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[1] = {a.UrT};
-    GgpmRing<1> ring2;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring2;
+    std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring2;
+    if constexpr (GM == 0)
         if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
+    if constexpr (SPLIT)
+        if (!a.first && t < t_end) ggpm_split_ring_prefetch<1>(wps2, KC32, t, lane, sring2);
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dq stash stores finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
 
@@ -470,8 +556,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         ggpm_zero_acc<1, RTT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[1] = {I1};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps2, KC32, tt, tn, lane, acc, sring2);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tn, lane, acc, ring2);
         }
         if constexpr (RTT != 1) load_inputs();
         if (dbg_on) a.dbg[3] = wall_clock64();
@@ -479,11 +569,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
         for (int r = 0; r < RTT; ++r) {
             const int lrow = 16 * r + lr, row = r0 + lrow;
             const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-            if (row >= a.E1) {
-                if (a.fuse_b) {
-                    ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, ggpm_zero4());
-                    ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, ggpm_zero4());
+            auto keep_zm = [&](float4 vz, float4 vm) {      // the complete dz_pre / dm_pre rows for the fused dS / dG phase
+                if constexpr (SPLIT) {
+                    ggpm_split_store(Iz, PLANE, LDH, lrow, c, vz);
+                    ggpm_split_store(Im, PLANE, LDH, lrow, c, vm);
+                } else {
+                    ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, vz);
+                    ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, vm);
                 }
+            };
+            if (row >= a.E1) {
+                if (a.fuse_b) keep_zm(ggpm_zero4(), ggpm_zero4());
                 continue;
             }
             const bool frz = a.frozen && a.frozen[row];
@@ -529,8 +625,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 ggpm_st4(a.dXh + o, oxh[r] + dmp);
             }
             if (a.fuse_b) {
-                ggpm_st4(lds + 2 * ROWS * LD + lrow * LD + c, dzp);
-                ggpm_st4(lds + 3 * ROWS * LD + lrow * LD + c, dmp);
+                keep_zm(dzp, dmp);
                 if (it == 0) dsd_keep[0] = dsdir; else dsd_keep[1] = dsdir;
             } else {
                 ggpm_st4(a.DSD + o, dsdir);
@@ -545,9 +640,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     if constexpr (RTT == 1) {
         const int row = r0 + lr;
         const float* const wps3[2] = {a.WhT, a.WzT};
-        GgpmRing<2> ring3;
-        if constexpr (!BF16)
+        std::conditional_t<GM == 0, GgpmRing<2>, GgpmNoRing> ring3;
+        std::conditional_t<SPLIT, GgpmSplitRing<2>, GgpmNoRing> sring3;
+        if constexpr (GM == 0)
             if (wave < NT) ggpm_ring_prefetch<2>(wps3, KC, wave, lane, ring3);
+        if constexpr (SPLIT)
+            if (wave < NT) ggpm_split_ring_prefetch<2>(wps3, KC32, wave, lane, sring3);
         ggpm_lds_barrier();
         it = 0;
         for (int tt = wave; tt < NT; tt += GGPM_NWA, ++it) {
@@ -559,8 +657,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
             ggpm_zero_acc<2, 1>(acc);
             {
                 const float* const tiles[2] = {lds + 3 * ROWS * LD, lds + 2 * ROWS * LD};
-                if constexpr (BF16) ggpm_wave_gemm_bf16<2, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
-                else ggpm_wave_gemm_ring<2, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+                const int tn = tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1;
+                if constexpr (SPLIT) {
+                    const __bf16* const imgs[2] = {Im, Iz};
+                    ggpm_wave_gemm_split<2>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
+                } else if constexpr (BF16) ggpm_wave_gemm_bf16<2, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+                else ggpm_wave_gemm_ring<2, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             }
             if (row >= a.E1) continue;
             const float4 dg = ggpm_f4(acc[0][0]);
@@ -573,24 +675,37 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 
 // Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* T1 = lds;                  // dz_pre rows
     float* T2 = lds + ROWS * LD;      // dm_pre rows
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp);
+    __bf16* Iz = reinterpret_cast<__bf16*>(lds);
+    __bf16* Im = Iz + ggpm_split_image_halves(ROWS, Hp);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[2] = {a.WhT, a.WzT};
-    GgpmRing<2> ring;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<2>, GgpmNoRing> ring;
+    std::conditional_t<SPLIT, GgpmSplitRing<2>, GgpmNoRing> sring;
+    if constexpr (GM == 0)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<2>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
-    ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
-    ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
+    if constexpr (SPLIT) {
+        if (grp * a.tg + wave < t_end) ggpm_split_ring_prefetch<2>(wps, KC32, grp * a.tg + wave, lane, sring);
+        ggpm_split_init(Iz, 2, ROWS, Hp);
+        ggpm_load_rows_to_lds_split<ROWS>(a.DZP, r0, a.E1, Hp, Iz, PLANE, LDH);
+        ggpm_load_rows_to_lds_split<ROWS>(a.DMP, r0, a.E1, Hp, Im, PLANE, LDH);
+    } else {
+        ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
+        ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
+    }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
@@ -609,8 +724,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
         ggpm_zero_acc<2, RTT>(acc);
         {
             const float* const tiles[2] = {T2, T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[2] = {Im, Iz};
+                ggpm_wave_gemm_split<2>(imgs, PLANE, LDH, wps, KC32, tt, tn, lane, acc, sring);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<2, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<2, RTT>(tiles, LD, wps, KC, tt, tn, lane, acc, ring);
         }
         if constexpr (RTT != 1) load_inputs();
 #pragma unroll
@@ -669,13 +788,36 @@ inline bool use_rt2(int E1, int Hp, bool sparse) {
     return mode == 2 || g_prefer_narrow || ggpm_ceil_div(E1, 16) >= GGPM_RT2_MIN_ROW_TILES;
 }
 
+// Gate mode of a level call (GruFwdArgs.bf16): the caller's dtype 1 (bf16 operands) stays; an fp32 call runs its gate products
+// on split operands (mode 2: fp32 accuracy on the bf16 matrix pipe, tile_mma.h) where that form is the faster one -- DENSE
+// levels whose row tiles alone fill the chip (one column group: one 16-wave workgroup per 16 messages owns all gate columns,
+// four waves per SIMD take turns on the pipe; the atom level: 33.9 -> 31.4 / 39.1 -> 35.8 us per launch, LSTM 46.2 -> 36.7 /
+// 49.7 -> 42.0) and whose fp32 tile + two bf16 images fit the LDS -- and on fp32 MFMA (mode 0) otherwise: with column groups
+// (the tree-side levels, the decode steps) ONE wave per SIMD streams three weight planes with nothing to hide their latency
+// behind and the launch gets slower (attachment level gru_bwd_a 11.7 -> 16.7 us).  Sparse calls are always mode 0, so a
+// sequence of them sharing one packed weight set (ggpm_weights_packed) agrees on it.  dtype 3 forces mode 2 wherever it
+// fits (tests); GGPM_GATE_SPLIT=0: mode 0 everywhere (A/B runs).
+inline int gate_mode(int dtype, int Hp, bool rt2, bool single_group, bool sparse) {
+    if (dtype == 1) return 1;
+    if (dtype == 2) return 0;
+    static const bool on = [] { const char* e = getenv("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
+    if (!on || rt2) return 0;
+    if (dtype != 3 && (!single_group || sparse)) return 0;
+    const size_t need = (size_t)16 * (Hp + 4) * sizeof(float) + 2 * ggpm_split_image_bytes(16, Hp);
+    return need <= 160 * 1024 ? 2 : 0;
+}
+inline bool single_group(int E1, int Hp) { return pick_tg(E1, Hp / 16) >= Hp / 16; }
+
 void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     const bool rt2 = use_rt2(a.E1, Hp, a.frozen != nullptr);
     const int rows = rt2 ? 32 : 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
-    const size_t lds_b = (size_t)rows * (Hp + 4) * sizeof(float);
-    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && 3 * lds_b <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
+    const bool split = a.bf16 == 2;
+    const size_t tile_b = (size_t)rows * (Hp + 4) * sizeof(float), img_b = ggpm_split_image_bytes(rows, Hp);
+    const size_t lds_b = split ? img_b : tile_b;
+    const size_t lds_fused = split ? tile_b + 3 * img_b : 3 * tile_b;
+    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && lds_fused <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
@@ -684,18 +826,19 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
         a.dbg = dbg_buf;
     }
     if (a.fuse_b) with_b = false;
-    const size_t lds_a = (a.fuse_b ? 3 : 2) * lds_b;
+    const size_t lds_a = a.fuse_b ? lds_fused : split ? tile_b + 2 * img_b : 2 * tile_b;
     ggpm_timing_begin(0, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 2)) * flops1);     // the first depth has no gate products
     auto go = [&](auto kernel) {
         set_lds(kernel, lds_a);
         kernel<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     };
     if (rt2) {
-        if (a.bf16) { if (stash) go(gru_fwd_a<true, true, 2>); else go(gru_fwd_a<false, true, 2>); }
-        else { if (stash) go(gru_fwd_a<true, false, 2>); else go(gru_fwd_a<false, false, 2>); }
+        if (a.bf16 == 1) { if (stash) go(gru_fwd_a<true, 1, 2>); else go(gru_fwd_a<false, 1, 2>); }
+        else { if (stash) go(gru_fwd_a<true, 0, 2>); else go(gru_fwd_a<false, 0, 2>); }
     } else {
-        if (a.bf16) { if (stash) go(gru_fwd_a<true, true, 1>); else go(gru_fwd_a<false, true, 1>); }
-        else { if (stash) go(gru_fwd_a<true, false, 1>); else go(gru_fwd_a<false, false, 1>); }
+        if (a.bf16 == 2) { if (stash) go(gru_fwd_a<true, 2, 1>); else go(gru_fwd_a<false, 2, 1>); }
+        else if (a.bf16 == 1) { if (stash) go(gru_fwd_a<true, 1, 1>); else go(gru_fwd_a<false, 1, 1>); }
+        else { if (stash) go(gru_fwd_a<true, 0, 1>); else go(gru_fwd_a<false, 0, 1>); }
     }
     ggpm_timing_end(0, s);
     if (a.dbg && (++dbg_count % 97) == 0) {
@@ -712,8 +855,8 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
             kernel<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a);
         };
         ggpm_timing_begin(4, s, 1 * flops1);
-        if (rt2) { if (a.bf16) gob(gru_fwd_b<true, 2>); else gob(gru_fwd_b<false, 2>); }
-        else { if (a.bf16) gob(gru_fwd_b<true, 1>); else gob(gru_fwd_b<false, 1>); }
+        if (rt2) { if (a.bf16 == 1) gob(gru_fwd_b<1, 2>); else gob(gru_fwd_b<0, 2>); }
+        else { if (a.bf16 == 2) gob(gru_fwd_b<2, 1>); else if (a.bf16 == 1) gob(gru_fwd_b<1, 1>); else gob(gru_fwd_b<0, 1>); }
         ggpm_timing_end(4, s);
     }
 }
@@ -723,11 +866,14 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const bool rt2 = use_rt2(a.E1, Hp, a.frozen != nullptr);
     const int rows = rt2 ? 32 : 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
-    const size_t lds = (size_t)2 * rows * (Hp + 4) * sizeof(float);
-    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && 2 * lds <= 160 * 1024 &&
+    const bool split = a.bf16 == 2;
+    const size_t tile_b = (size_t)rows * (Hp + 4) * sizeof(float), img_b = ggpm_split_image_bytes(rows, Hp);
+    const size_t lds = split ? 2 * img_b : 2 * tile_b;                        // kernel B: the dz_pre and dm_pre rows
+    const size_t lds_fused = split ? tile_b + 3 * img_b : 4 * tile_b;
+    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && NT <= 2 * GGPM_NWA && lds_fused <= 160 * 1024 &&
                 !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
-    const size_t lds_a = a.fuse_b ? 2 * lds : lds;
+    const size_t lds_a = a.fuse_b ? lds_fused : split ? tile_b + img_b : 2 * tile_b;
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_count = 0;
     a.dbg = nullptr;
@@ -740,8 +886,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
         kernel<<<grid_a, GGPM_NWA * 64, bytes, s>>>(a);
     };
     ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
-    if (rt2) { if (a.bf16) go(gru_bwd_a<true, 2>, lds_a); else go(gru_bwd_a<false, 2>, lds_a); }
-    else { if (a.bf16) go(gru_bwd_a<true, 1>, lds_a); else go(gru_bwd_a<false, 1>, lds_a); }
+    if (rt2) { if (a.bf16 == 1) go(gru_bwd_a<1, 2>, lds_a); else go(gru_bwd_a<0, 2>, lds_a); }
+    else { if (a.bf16 == 2) go(gru_bwd_a<2, 1>, lds_a); else if (a.bf16 == 1) go(gru_bwd_a<1, 1>, lds_a); else go(gru_bwd_a<0, 1>, lds_a); }
     ggpm_timing_end(1, s);
     if (a.dbg && !a.first && (++dbg_count % 89) == 0) {
         unsigned long long h[5];
@@ -753,8 +899,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     }
     if (with_b) {
         ggpm_timing_begin(5, s, 2 * flops1);
-        if (rt2) { if (a.bf16) go(gru_bwd_b<true, 2>, lds); else go(gru_bwd_b<false, 2>, lds); }
-        else { if (a.bf16) go(gru_bwd_b<true, 1>, lds); else go(gru_bwd_b<false, 1>, lds); }
+        if (rt2) { if (a.bf16 == 1) go(gru_bwd_b<1, 2>, lds); else go(gru_bwd_b<0, 2>, lds); }
+        else { if (a.bf16 == 2) go(gru_bwd_b<2, 1>, lds); else if (a.bf16 == 1) go(gru_bwd_b<1, 1>, lds); else go(gru_bwd_b<0, 1>, lds); }
         ggpm_timing_end(5, s);
     }
 }
@@ -762,8 +908,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t ggpm_gru_pack_floats(int H) {
-    const size_t Hp = (size_t)ggpm_padded_hidden(H);
-    return 3 * Hp * Hp + Hp;
+    const int Hp = ggpm_padded_hidden(H);
+    return 3 * ggpm_packed_matrix_slot(Hp) + (size_t)Hp;
 }
 
 static int gru_shape_ok(int Hp) {
@@ -846,9 +992,10 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     if (!gru_shape_ok(Hp)) return GGPM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
-    float* pWz = wpack; float* pWh = wpack + mstep; float* pUr = wpack + 2 * mstep; float* pbu = wpack + 3 * HH;
+    const int bf16 = gate_mode(ggpm_gate_dtype(), Hp, use_rt2(E1, Hp, frozen != nullptr), single_group(E1, Hp), frozen != nullptr);      // gate mode 0 / 1 / 2
+    const size_t mstep = ggpm_packed_matrix_floats(Hp, bf16);
+    float* pWz = wpack; float* pWh = wpack + mstep; float* pUr = wpack + 2 * mstep;
+    float* pbu = wpack + 3 * ggpm_packed_matrix_slot(Hp);
     {
         GgpmPackArgs pk = {};
         pk.W[0] = Wz_h; pk.ldw[0] = ld_wz; pk.W[1] = Wh_h; pk.ldw[1] = ld_wh; pk.W[2] = Ur; pk.ldw[2] = ld_ur;
@@ -867,10 +1014,11 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         GruFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg0; a0.Hnew = Hs; a0.Qnew = Qs; a0.Ur = pUr; a0.bu = pbu; a0.bf16 = bf16;
         if (gathered) { a0.src_h = gs_h; a0.src_idx = gs_idx; }
-        const size_t lds_b = (size_t)ROWS * (Hp + 4) * sizeof(float);
+        const size_t lds_b = bf16 == 2 ? ggpm_split_image_bytes(ROWS, Hp) : (size_t)ROWS * (Hp + 4) * sizeof(float);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg0));
-        if (bf16) { set_lds(gru_fwd_b<true, 1>, lds_b); gru_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
-        else { set_lds(gru_fwd_b<false, 1>, lds_b); gru_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        if (bf16 == 2) { set_lds(gru_fwd_b<2, 1>, lds_b); gru_fwd_b<2, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        else if (bf16 == 1) { set_lds(gru_fwd_b<1, 1>, lds_b); gru_fwd_b<1, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
+        else { set_lds(gru_fwd_b<0, 1>, lds_b); gru_fwd_b<0, 1><<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a0); }
     }
     // dense levels start from h^0 = 0: the first depth launch knows that (h0_zero), so H^0 / Q^0 are never materialised
 
@@ -944,7 +1092,7 @@ extern "C" size_t ggpm_gru_backward_workspace_bytes(int E1, int H, int depth) {
     f += 2 * (size_t)depth * slot;                     // DMP, DZP
     f += (size_t)depth * slot;                         // DQ (slot t = dq^t; slot 0 only used by sparse_forward)
     f += 6 * slot;                                     // dS/dG double buffers + ds_dir scratch + carry
-    f += 3 * Hp * Hp;                                  // packed transposes
+    f += 3 * ggpm_packed_matrix_slot((int)Hp);         // packed transposes (the largest gate mode's)
     f += 256 * Hp;                                     // colsum scratch
     size_t bytes = f * sizeof(float);
     bytes += ggpm_gemm_workspace_bytes(H, H, depth * E1);   // split-K slabs (largest contraction)
@@ -994,9 +1142,9 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
     // (the packed transposes come first: their place does not depend on E1, so a sequence of calls that shares one
     // `work` buffer and one set of weights packs them once -- ggpm_weights_packed)
     float* w = work;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
-    float* pWzT = w; float* pWhT = w + mstep; float* pUrT = w + 2 * mstep; w += 3 * HH;
+    const int bf16 = gate_mode(ggpm_gate_dtype(), Hp, use_rt2(E1, Hp, frozen != nullptr), single_group(E1, Hp), frozen != nullptr);      // gate mode 0 / 1 / 2
+    const size_t mstep = ggpm_packed_matrix_floats(Hp, bf16);
+    float* pWzT = w; float* pWhT = w + mstep; float* pUrT = w + 2 * mstep; w += 3 * ggpm_packed_matrix_slot(Hp);
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
     float* DQ = w; w += (size_t)depth * slot;
@@ -1190,7 +1338,7 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* w = work + 3 * HH;             // (layout of gru_backward_impl)
+    float* w = work + 3 * ggpm_packed_matrix_slot(Hp);             // (layout of gru_backward_impl)
     float* DMP = w; w += (size_t)depth * slot;
     float* DZP = w; w += (size_t)depth * slot;
     float* DQ = w; w += (size_t)depth * slot;
@@ -1214,12 +1362,12 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         gp[2].A = dq0;
         gp[2].B = Hs + (size_t)first_slot * slot;
         Ks[2] = KQ;
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
         if (rc) return rc;
         rc = ggpm_colsum(dq0, Hp, KQ, H, dbu, csws, stream);
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
+        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
@@ -1252,7 +1400,7 @@ extern "C" int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, f
 extern "C" int ggpm_gru_backward_stashes(float* work, int E1, int H, int depth, float** DMP, float** DZP) {
     if (!work || !DMP || !DZP || E1 <= 0 || H <= 0 || depth <= 0) return GGPM_ERR_ARG;
     const size_t Hp = (size_t)ggpm_padded_hidden(H), slot = (size_t)E1 * Hp;
-    *DMP = work + 3 * Hp * Hp;
+    *DMP = work + 3 * ggpm_packed_matrix_slot((int)Hp);
     *DZP = *DMP + (size_t)depth * slot;
     return GGPM_OK;
 }

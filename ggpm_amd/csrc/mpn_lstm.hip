@@ -38,13 +38,21 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time: s over the full row (GEMM operand), the
 // forget sum fc (and its backward coefficient) only over this workgroup's column group; then the first `tg`
 // waves run [Wi_h; Wo_h; Wu_h] . s for their output tile and the gate math.
-template <bool STASH, bool BF16, int RTT>
+template <bool STASH, int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;      // gate mode (LstmFwdArgs.bf16): 0 fp32 MFMA, 1 bf16, 2 split operands
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
-    float* Ts = lds;
-    float* Tf = lds + ROWS * LD;      // fc, full-width tile of which only the group's columns are written/read
+    // split operands (tile_mma.h): fc keeps its fp32 tile (epilogue only) at the head; behind it the bf16 images of s and,
+    // for the fused qf' phase, h' (s itself is a GEMM operand only)
+    float* Ts = SPLIT ? nullptr : lds;
+    float* Tf = SPLIT ? lds : lds + ROWS * LD;      // fc, full-width tile of which only the group's columns are written/read
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp), IMG = ggpm_split_image_halves(ROWS, Hp);
+    __bf16* Is = reinterpret_cast<__bf16*>(lds + ROWS * LD);
+    __bf16* Ih = Is + IMG;
+    if constexpr (SPLIT) ggpm_split_init(Is, a.fuse_b ? 2 : 1, ROWS, Hp);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
@@ -101,7 +109,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (!on[k]) continue;
-                ggpm_st4(Ts + lr * LD + c[k], s[k]);
+                if constexpr (SPLIT) ggpm_split_store(Is, PLANE, LDH, lr, c[k], s[k]);
+                else ggpm_st4(Ts + lr * LD + c[k], s[k]);
                 if (mine[k]) {
                     ggpm_st4(Tf + lr * LD + c[k], fc[k]);
                     if (STASH && row < a.E1) {
@@ -117,9 +126,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     // the first weight fragments of P2 travel from L2 while this wave waits for the slower gatherers
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[3] = {a.Wi, a.Wo, a.Wu};
-    GgpmRing<3> ring2;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<3>, GgpmNoRing> ring2;
+    std::conditional_t<SPLIT, GgpmSplitRing<3>, GgpmNoRing> sring2;
+    if constexpr (GM == 0)
         if (!a.h0_zero && t < t_end) ggpm_ring_prefetch<3>(wps2, KC, t, lane, ring2);
+    if constexpr (SPLIT)
+        if (!a.h0_zero && t < t_end) ggpm_split_ring_prefetch<3>(wps2, KC32, t, lane, sring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
 
     const int lr = lane & 15;
@@ -132,22 +144,31 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
             const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
             xi[r] = ggpm_ld4(a.Xi + o); xo[r] = ggpm_ld4(a.Xo + o); xu[r] = ggpm_ld4(a.Xu + o);
         };
-        if constexpr (RTT == 1) load_inputs(0);     // in flight under the GEMM (two row tiles: the registers go to the GEMM)
+        if constexpr (RTT == 1 && !SPLIT) load_inputs(0);     // in flight under the GEMM (two row tiles / split operands: the
+                                                              // registers go to the GEMM)
         f32x4 acc[3][RTT];
         ggpm_zero_acc<3, RTT>(acc);
         if (!a.h0_zero) {
             const float* const tiles[3] = {Ts, Ts, Ts};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[3] = {Is, Is, Is};
+                ggpm_wave_gemm_split<3, true>(imgs, PLANE, LDH, wps2, KC32, tt, tn, lane, acc, sring2);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps2, KC, tt, tn, lane, acc, ring2);
         }
 #pragma unroll
         for (int r = 0; r < RTT; ++r) {
-            if constexpr (RTT != 1) load_inputs(r);
+            if constexpr (RTT != 1 || SPLIT) load_inputs(r);
             const int lrow = 16 * r + lr, row = r0 + lrow;
             const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
             float4 h = ggpm_zero4(), cn = ggpm_zero4(), gi = ggpm_zero4(), go = ggpm_zero4(), gu = ggpm_zero4();
+            auto keep_h = [&](float4 v) {          // the complete h' rows for the fused qf' phase
+                if constexpr (SPLIT) ggpm_split_store(Ih, PLANE, LDH, lrow, c, v);
+                else ggpm_st4(Th + lrow * LD + c, v);
+            };
             if (row >= a.E1) {
-                if (a.fuse_b) ggpm_st4(Th + lrow * LD + c, h);
+                if (a.fuse_b) keep_h(h);
                 continue;
             }
             if (a.frozen && a.frozen[row]) {
@@ -166,7 +187,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
             }
             ggpm_st4(a.Hnew + o, h);
             ggpm_st4(a.Cnew + o, cn);
-            if (a.fuse_b) ggpm_st4(Th + lrow * LD + c, h);
+            if (a.fuse_b) keep_h(h);
             if (STASH) {
                 ggpm_st4(a.I + o, gi);
                 ggpm_st4(a.O + o, go);
@@ -180,16 +201,23 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
     if constexpr (RTT == 1) {
         const int row = r0 + lr;
         const float* const wps3[1] = {a.Wf};
-        GgpmRing<1> ring3;
-        if constexpr (!BF16)
+        std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring3;
+        std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring3;
+        if constexpr (GM == 0)
             if (wave < NT) ggpm_ring_prefetch<1>(wps3, KC, wave, lane, ring3);
+        if constexpr (SPLIT)
+            if (wave < NT) ggpm_split_ring_prefetch<1>(wps3, KC32, wave, lane, sring3);
         ggpm_lds_barrier();
         for (int tt = wave; tt < NT; tt += GGPM_NWA) {
             f32x4 acc[1][1];
             ggpm_zero_acc<1, 1>(acc);
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+            const int tn = tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[1] = {Ih};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             const int c = 16 * tt + 4 * (lane >> 4);
             if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
         }
@@ -197,23 +225,33 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
 }
 
 // Kernel B (same geometry as A): qf' = Wf_h h'.
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Th = lds;
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp);
+    __bf16* Ih = reinterpret_cast<__bf16*>(lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[1] = {a.Wf};
-    GgpmRing<1> ring;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring;
+    std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring;
+    if constexpr (GM == 0)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<1>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copy
+    if constexpr (SPLIT) {
+        if (grp * a.tg + wave < t_end) ggpm_split_ring_prefetch<1>(wps, KC32, grp * a.tg + wave, lane, sring);
+        ggpm_split_init(Ih, 1, ROWS, Hp);
+    }
     if (a.src_idx) {
-        ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
+        if constexpr (SPLIT) ggpm_gather_rows_to_lds_split<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, Ih, PLANE, LDH, grp == 0 ? a.Hnew : nullptr);
+        else ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
         if (grp == 0) {            // the cell state of the same rows: copied through, not a GEMM operand
             const int q = Hp >> 2;
             for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
@@ -224,7 +262,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
             }
         }
     } else {
-        ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+        if constexpr (SPLIT) ggpm_load_rows_to_lds_split<ROWS>(a.Hnew, r0, a.E1, Hp, Ih, PLANE, LDH);
+        else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
     }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -232,8 +271,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
         ggpm_zero_acc<1, RTT>(acc);
         {
             const float* const tiles[1] = {Th};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[1] = {Ih};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps, KC32, tt, tn, lane, acc, sring);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps, KC, tt, tn, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
 #pragma unroll
@@ -274,14 +317,24 @@ struct LstmBwdArgs {
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
 // gate derivatives; dXf += dFC * F.
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
+    // split operands: the fp32 tiles of dh partial and dc (epilogue only) at the head, behind them the bf16 images of dqf
+    // and, for the fused dS phase, di_pre / do_pre / du_pre
     float* T1 = lds;                      // dqf  (full rows)
-    float* T0 = lds + ROWS * LD;          // dh partial (group columns)
-    float* T2 = lds + 2 * ROWS * LD;      // dc         (group columns)
+    float* T0 = SPLIT ? lds : lds + ROWS * LD;                    // dh partial (group columns)
+    float* T2 = SPLIT ? lds + ROWS * LD : lds + 2 * ROWS * LD;    // dc         (group columns)
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp), IMG = ggpm_split_image_halves(ROWS, Hp);
+    __bf16* I1 = reinterpret_cast<__bf16*>(lds + 2 * ROWS * LD);
+    __bf16* Ia = I1 + IMG;
+    __bf16* Ib = Ia + IMG;
+    __bf16* Ic = Ib + IMG;
+    if constexpr (SPLIT) ggpm_split_init(I1, a.fuse_b ? 4 : 1, ROWS, Hp);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
@@ -339,7 +392,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (!on[k]) continue;
-                    ggpm_st4(T1 + lr * LD + c[k], dq[k]);
+                    if constexpr (SPLIT) ggpm_split_store(I1, PLANE, LDH, lr, c[k], dq[k]);
+                    else ggpm_st4(T1 + lr * LD + c[k], dq[k]);
                     if (mine[k]) {
                         ggpm_st4(T0 + lr * LD + c[k], dh[k]);
                         ggpm_st4(T2 + lr * LD + c[k], dc[k]);
@@ -352,9 +406,12 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
 
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps2[1] = {a.WfT};
-    GgpmRing<1> ring2;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<1>, GgpmNoRing> ring2;
+    std::conditional_t<SPLIT, GgpmSplitRing<1>, GgpmNoRing> sring2;
+    if constexpr (GM == 0)
         if (!a.first && t < t_end) ggpm_ring_prefetch<1>(wps2, KC, t, lane, ring2);      // under the wait for the gatherers
+    if constexpr (SPLIT)
+        if (!a.first && t < t_end) ggpm_split_ring_prefetch<1>(wps2, KC32, t, lane, sring2);
     if (!a.first) ggpm_lds_barrier();      // LDS tiles only: the dqf stash stores finish under the GEMM
 
     const int lr = lane & 15;
@@ -362,51 +419,75 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     float* Tb = lds + 4 * ROWS * LD;
     float* Tc = lds + 5 * ROWS * LD;
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
-        const int c = 16 * tt + 4 * (lane >> 4);
+        // split operands: everything the epilogue derives from the lane id (row, column, LDS and global addresses) is formed
+        // BEHIND the GEMM from an opaque copy of it -- hoisted in front of the tile loop those ~20 values lived across the
+        // GEMM beside its ring and spilled
+        int lane_e = lane;
+        int c = 16 * tt + 4 * (lane >> 4), lr = lane & 15;
         float4 gi[RTT], go[RTT], gu[RTT], cc[RTT], fco[RTT], oxi[RTT], oxo[RTT], oxu[RTT], oxf[RTT], dhd[RTT], dcd[RTT];
         auto load_inputs = [&](int r) {
             const int row = r0 + 16 * r + lr;
-            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
+            const unsigned o = ((unsigned)(row < a.E1 ? row : 0) * (unsigned)Hp + (unsigned)c) * 4u;      // BYTES (E1 * Hp < 2^29, checked by the host)
             gi[r] = go[r] = gu[r] = cc[r] = fco[r] = oxi[r] = oxo[r] = oxu[r] = oxf[r] = ggpm_zero4();
             if (!a.final_pass) {
-                gi[r] = ggpm_ld4(a.I + o); go[r] = ggpm_ld4(a.O + o); gu[r] = ggpm_ld4(a.U + o); cc[r] = ggpm_ld4(a.Ccur + o);
-                fco[r] = ggpm_ld4(a.F + o);
+                gi[r] = ggpm_ld4o(a.I, o); go[r] = ggpm_ld4o(a.O, o); gu[r] = ggpm_ld4o(a.U, o); cc[r] = ggpm_ld4o(a.Ccur, o);
+                fco[r] = ggpm_ld4o(a.F, o);
                 if (!a.first) {        // depth D starts the dX sums
-                    if (!a.skip_xsum) { oxi[r] = ggpm_ld4(a.dXi + o); oxo[r] = ggpm_ld4(a.dXo + o); oxu[r] = ggpm_ld4(a.dXu + o); }
-                    oxf[r] = ggpm_ld4(a.dXf + o);
+                    if (!a.skip_xsum) { oxi[r] = ggpm_ld4o(a.dXi, o); oxo[r] = ggpm_ld4o(a.dXo, o); oxu[r] = ggpm_ld4o(a.dXu, o); }
+                    oxf[r] = ggpm_ld4o(a.dXf, o);
                 }
             }
-            dhd[r] = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
-            dcd[r] = (a.first && a.dCD) ? ggpm_ld4(a.dCD + o) : ggpm_zero4();
+            dhd[r] = a.first ? ggpm_ld4o(a.dHD, o) : ggpm_zero4();
+            dcd[r] = (a.first && a.dCD) ? ggpm_ld4o(a.dCD, o) : ggpm_zero4();
         };
-        if constexpr (RTT == 1) load_inputs(0);     // in flight under the GEMM (two row tiles: the registers go to the GEMM,
-                                                    // each tile's operands are fetched where its epilogue starts)
+        if constexpr (RTT == 1 && !SPLIT) load_inputs(0);     // in flight under the GEMM (two row tiles / split operands: the
+                                                              // registers go to the GEMM, each tile's operands are fetched
+                                                              // where its epilogue starts)
         f32x4 acc[1][RTT];
         ggpm_zero_acc<1, RTT>(acc);
         if (!a.first) {
             const float* const tiles[1] = {T1};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring2);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                // (the ring is NOT carried into the epilogue -- its eleven operand loads need the registers: a wave's second
+                // tile fetches its first fragments here)
+                if (tt != t) ggpm_split_ring_prefetch<1>(wps2, KC32, tt, lane, sring2);
+                const __bf16* const imgs[1] = {I1};
+                ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps2, KC32, tt, -1, lane, acc, sring2);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, RTT>(tiles, LD, wps2, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<1, RTT>(tiles, LD, wps2, KC, tt, tn, lane, acc, ring2);
+        }
+        if constexpr (SPLIT) {
+            asm volatile("" : "+v"(lane_e));
+            c = 16 * tt + 4 * (lane_e >> 4);
+            lr = lane_e & 15;
         }
 #pragma unroll
         for (int r = 0; r < RTT; ++r) {
-            if constexpr (RTT != 1) load_inputs(r);
+            if constexpr (RTT != 1 || SPLIT) load_inputs(r);
             const int lrow = 16 * r + lr, row = r0 + lrow;
-            const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
-            if (row >= a.E1) {
-                if (a.fuse_b) {
-                    ggpm_st4(Ta + lrow * LD + c, ggpm_zero4());
-                    ggpm_st4(Tb + lrow * LD + c, ggpm_zero4());
-                    ggpm_st4(Tc + lrow * LD + c, ggpm_zero4());
+            const unsigned o = ((unsigned)(row < a.E1 ? row : 0) * (unsigned)Hp + (unsigned)c) * 4u;      // BYTES (E1 * Hp < 2^29, checked by the host)
+            auto keep_iou = [&](float4 vi, float4 vo, float4 vu) {      // the complete gate-gradient rows for the fused dS phase
+                if constexpr (SPLIT) {
+                    ggpm_split_store(Ia, PLANE, LDH, lrow, c, vi);
+                    ggpm_split_store(Ib, PLANE, LDH, lrow, c, vo);
+                    ggpm_split_store(Ic, PLANE, LDH, lrow, c, vu);
+                } else {
+                    ggpm_st4(Ta + lrow * LD + c, vi);
+                    ggpm_st4(Tb + lrow * LD + c, vo);
+                    ggpm_st4(Tc + lrow * LD + c, vu);
                 }
+            };
+            if (row >= a.E1) {
+                if (a.fuse_b) keep_iou(ggpm_zero4(), ggpm_zero4(), ggpm_zero4());
                 continue;
             }
             const bool frz = a.frozen && a.frozen[row];
             if (a.final_pass) {        // gradient of the incoming (h, c): frozen rows only
                 float4 dh0 = ggpm_zero4(), dc0 = ggpm_zero4();
                 if (frz) {
-                    dh0 = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c) + ggpm_ld4(a.carry_h + o);
-                    dc0 = ggpm_ld4(T2 + lrow * LD + c) + ggpm_ld4(a.carry_c + o);
+                    dh0 = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c) + ggpm_ld4o(a.carry_h, o);
+                    dc0 = ggpm_ld4(T2 + lrow * LD + c) + ggpm_ld4o(a.carry_c, o);
                 }
                 if (a.scat_idx) {
                     const int id = frz ? a.scat_idx[row] : -1;
@@ -417,8 +498,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                         ggpm_st4(dc_to, ggpm_ld4(dc_to) + dc0);
                     }
                 } else {
-                    ggpm_st4(a.dHin + o, dh0);
-                    ggpm_st4(a.dCin + o, dc0);
+                    ggpm_st4o(a.dHin, o, dh0);
+                    ggpm_st4o(a.dCin, o, dc0);
                 }
                 continue;
             }
@@ -429,11 +510,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                 else { dh = ggpm_f4(acc[0][r]) + ggpm_ld4(T0 + lrow * LD + c); dc = ggpm_ld4(T2 + lrow * LD + c); }
                 if (frz) {             // (h, c)_t = (h, c)_{t-1}: carry both gradients to the previous depth
                     if (!a.first) {        // (the first backward depth starts the carries: no memset)
-                        dh = dh + ggpm_ld4(a.carry_h + o);
-                        dc = dc + ggpm_ld4(a.carry_c + o);
+                        dh = dh + ggpm_ld4o(a.carry_h, o);
+                        dc = dc + ggpm_ld4o(a.carry_c, o);
                     }
-                    ggpm_st4(a.carry_h + o, dh);
-                    ggpm_st4(a.carry_c + o, dc);
+                    ggpm_st4o(a.carry_h, o, dh);
+                    ggpm_st4o(a.carry_c, o, dc);
                     dh = ggpm_zero4();
                     dc = ggpm_zero4();
                 }
@@ -455,21 +536,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                 dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
                 dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
             }
-            ggpm_st4(a.DI + o, dip);
-            ggpm_st4(a.DO + o, dop);
-            ggpm_st4(a.DU + o, dup);
-            ggpm_st4(a.dFCout + o, dfc);
+            ggpm_st4o(a.DI, o, dip);
+            ggpm_st4o(a.DO, o, dop);
+            ggpm_st4o(a.DU, o, dup);
+            ggpm_st4o(a.dFCout, o, dfc);
             if (!a.skip_xsum) {
-                ggpm_st4(a.dXi + o, oxi[r] + dip);
-                ggpm_st4(a.dXo + o, oxo[r] + dop);
-                ggpm_st4(a.dXu + o, oxu[r] + dup);
+                ggpm_st4o(a.dXi, o, oxi[r] + dip);
+                ggpm_st4o(a.dXo, o, oxo[r] + dop);
+                ggpm_st4o(a.dXu, o, oxu[r] + dup);
             }
-            ggpm_st4(a.dXf + o, oxf[r] + dfc * fco[r]);      // dXf_e += dFC_e * sum_p c_p f(1-f)
-            if (a.fuse_b) {
-                ggpm_st4(Ta + lrow * LD + c, dip);
-                ggpm_st4(Tb + lrow * LD + c, dop);
-                ggpm_st4(Tc + lrow * LD + c, dup);
-            }
+            ggpm_st4o(a.dXf, o, oxf[r] + dfc * fco[r]);      // dXf_e += dFC_e * sum_p c_p f(1-f)
+            if (a.fuse_b) keep_iou(dip, dop, dup);
         }
     }
     if (!a.fuse_b) return;
@@ -478,17 +555,24 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     if constexpr (RTT == 1) {
         const int row = r0 + lr;
         const float* const wps3[3] = {a.WiT, a.WoT, a.WuT};
-        GgpmRing<3> ring3;
-        if constexpr (!BF16)
+        std::conditional_t<GM == 0, GgpmRing<3>, GgpmNoRing> ring3;
+        std::conditional_t<SPLIT, GgpmSplitRing<3>, GgpmNoRing> sring3;
+        if constexpr (GM == 0)
             if (wave < NT) ggpm_ring_prefetch<3>(wps3, KC, wave, lane, ring3);
+        if constexpr (SPLIT)
+            if (wave < NT) ggpm_split_ring_prefetch<3>(wps3, KC32, wave, lane, sring3);
         ggpm_lds_barrier();
         for (int tt = wave; tt < NT; tt += GGPM_NWA) {
             f32x4 acc[3][1];
             ggpm_zero_acc<3, 1>(acc);
             {
                 const float* const tiles[3] = {Ta, Tb, Tc};
-                if constexpr (BF16) ggpm_wave_gemm_bf16<3, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
-                else ggpm_wave_gemm_ring<3, 1>(tiles, LD, wps3, KC, tt, tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1, lane, acc, ring3);
+                const int tn = tt + GGPM_NWA < NT ? tt + GGPM_NWA : -1;
+                if constexpr (SPLIT) {      // (the three products are summed: one accumulator pair, acc[0]; acc[1], acc[2] stay 0)
+                    const __bf16* const imgs[3] = {Ia, Ib, Ic};
+                    ggpm_wave_gemm_split<3, false, true>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
+                } else if constexpr (BF16) ggpm_wave_gemm_bf16<3, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
+                else ggpm_wave_gemm_ring<3, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             }
             const int c = 16 * tt + 4 * (lane >> 4);
             if (row < a.E1)
@@ -498,34 +582,53 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
 }
 
 // Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
-template <bool BF16, int RTT>
+template <int GM, int RTT>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;
+    constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
+    static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ta = lds;
     float* Tb = lds + ROWS * LD;
     float* Tc = lds + 2 * ROWS * LD;
+    const int LDH = ggpm_split_ldh(Hp), PLANE = ROWS * LDH, KC32 = ggpm_kc32_dev(Hp), IMG = ggpm_split_image_halves(ROWS, Hp);
+    __bf16* Ia = reinterpret_cast<__bf16*>(lds);
+    __bf16* Ib = Ia + IMG;
+    __bf16* Ic = Ib + IMG;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.x * ROWS;
     const int grp = blockIdx.y;
     const int t_end = min(NT, (grp + 1) * a.tg);
     const float* const wps[3] = {a.WiT, a.WoT, a.WuT};
-    GgpmRing<3> ring;
-    if constexpr (!BF16)
+    std::conditional_t<GM == 0, GgpmRing<3>, GgpmNoRing> ring;
+    std::conditional_t<SPLIT, GgpmSplitRing<3>, GgpmNoRing> sring;
+    if constexpr (GM == 0)
         if (grp * a.tg + wave < t_end) ggpm_ring_prefetch<3>(wps, KC, grp * a.tg + wave, lane, ring);     // under the row copies
-    ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
-    ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
-    ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
+    if constexpr (SPLIT) {
+        if (grp * a.tg + wave < t_end) ggpm_split_ring_prefetch<3>(wps, KC32, grp * a.tg + wave, lane, sring);
+        ggpm_split_init(Ia, 3, ROWS, Hp);
+        ggpm_load_rows_to_lds_split<ROWS>(a.DI, r0, a.E1, Hp, Ia, PLANE, LDH);
+        ggpm_load_rows_to_lds_split<ROWS>(a.DO, r0, a.E1, Hp, Ib, PLANE, LDH);
+        ggpm_load_rows_to_lds_split<ROWS>(a.DU, r0, a.E1, Hp, Ic, PLANE, LDH);
+    } else {
+        ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
+        ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
+        ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
+    }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
         f32x4 acc[3][RTT];
         ggpm_zero_acc<3, RTT>(acc);
         {
             const float* const tiles[3] = {Ta, Tb, Tc};
-            if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
-            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps, KC, tt, tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1, lane, acc, ring);
+            const int tn = tt + GGPM_NWA < t_end ? tt + GGPM_NWA : -1;
+            if constexpr (SPLIT) {
+                const __bf16* const imgs[3] = {Ia, Ib, Ic};
+                ggpm_wave_gemm_split<3, false, true>(imgs, PLANE, LDH, wps, KC32, tt, tn, lane, acc, sring);
+            } else if constexpr (BF16) ggpm_wave_gemm_bf16<3, RTT>(tiles, LD, wps, Hp, tt, lane, acc);
+            else ggpm_wave_gemm_ring<3, RTT>(tiles, LD, wps, KC, tt, tn, lane, acc, ring);
         }
         const int c = 16 * tt + 4 * (lane >> 4);
 #pragma unroll
@@ -572,28 +675,47 @@ inline int pick_tg(int E1, int NT) {
     return ggpm_tiles_per_group(E1, NT);
 }
 
+// Gate mode of a level call (mpn_gru.hip: gate_mode): fp32 calls run their gate products on split operands (mode 2) where
+// one 16-row tile per workgroup applies and the backward's two fp32 tiles + the dqf image fit the LDS.
+inline int gate_mode(int dtype, int Hp, bool rt2, bool single_group, bool sparse) {
+    if (dtype == 1) return 1;
+    if (dtype == 2) return 0;
+    static const bool on = [] { const char* e = getenv("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
+    if (!on || rt2) return 0;
+    if (dtype != 3 && (!single_group || sparse)) return 0;
+    // kernel A of the backward: two fp32 tiles + the dqf image; kernel B of the backward: three gate-gradient images
+    const size_t img = ggpm_split_image_bytes(16, Hp);
+    return (lds_tiles(2, Hp) + img <= 160 * 1024 && 3 * img <= 160 * 1024) ? 2 : 0;
+}
+
 void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     const bool rt2 = use_rt2(Hp, a.frozen != nullptr, a.bf16);
     const int rows = rt2 ? 32 : 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
-    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && lds_tiles(3, Hp) <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
+    const bool split = a.bf16 == 2;
+    const size_t img_b = ggpm_split_image_bytes(rows, Hp);
+    const size_t l_fused = split ? lds_tiles(1, Hp) + 2 * img_b : lds_tiles(3, Hp);
+    a.fuse_b = (!rt2 && with_b && grid_a.y == 1 && l_fused <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
-    const size_t la = lds_tiles(a.fuse_b ? 3 : 2, Hp, rows), lb = lds_tiles(1, Hp, rows);
+    const size_t la = a.fuse_b ? l_fused : split ? lds_tiles(1, Hp) + img_b : lds_tiles(2, Hp, rows);
+    const size_t lb = split ? img_b : lds_tiles(1, Hp, rows);
     ggpm_timing_begin(2, s, ((a.fuse_b ? 1 : 0) + (a.h0_zero ? 0 : 3)) * flops1);     // the first depth has no gate products
     auto go = [&](auto kernel) {
         set_lds(kernel, la);
         kernel<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
     };
-    if (rt2) { if (stash) go(lstm_fwd_a<true, false, 2>); else go(lstm_fwd_a<false, false, 2>); }
-    else if (a.bf16) { if (stash) go(lstm_fwd_a<true, true, 1>); else go(lstm_fwd_a<false, true, 1>); }
-    else { if (stash) go(lstm_fwd_a<true, false, 1>); else go(lstm_fwd_a<false, false, 1>); }
+    if (rt2) { if (stash) go(lstm_fwd_a<true, 0, 2>); else go(lstm_fwd_a<false, 0, 2>); }
+    else if (a.bf16 == 2) { if (stash) go(lstm_fwd_a<true, 2, 1>); else go(lstm_fwd_a<false, 2, 1>); }
+    else if (a.bf16 == 1) { if (stash) go(lstm_fwd_a<true, 1, 1>); else go(lstm_fwd_a<false, 1, 1>); }
+    else { if (stash) go(lstm_fwd_a<true, 0, 1>); else go(lstm_fwd_a<false, 0, 1>); }
     ggpm_timing_end(2, s);
     if (with_b) {
         ggpm_timing_begin(6, s, 1 * flops1);
-        if (rt2) { set_lds(lstm_fwd_b<false, 2>, lb); lstm_fwd_b<false, 2><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
-        else if (a.bf16) { set_lds(lstm_fwd_b<true, 1>, lb); lstm_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
-        else { set_lds(lstm_fwd_b<false, 1>, lb); lstm_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        if (rt2) { set_lds(lstm_fwd_b<0, 2>, lb); lstm_fwd_b<0, 2><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else if (a.bf16 == 2) { set_lds(lstm_fwd_b<2, 1>, lb); lstm_fwd_b<2, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else if (a.bf16 == 1) { set_lds(lstm_fwd_b<1, 1>, lb); lstm_fwd_b<1, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else { set_lds(lstm_fwd_b<0, 1>, lb); lstm_fwd_b<0, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         ggpm_timing_end(6, s);
     }
 }
@@ -603,21 +725,25 @@ void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     const bool rt2 = use_rt2(Hp, a.frozen != nullptr, a.bf16);
     const int rows = rt2 ? 32 : 16;
     dim3 grid_a(ggpm_ceil_div(a.E1, rows), ggpm_ceil_div(NT, a.tg));
-    const size_t l3 = lds_tiles(3, Hp, rows);
-    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && lds_tiles(6, Hp) <= 160 * 1024 &&
-                !env_no_fuse_b()) ? 1 : 0;
+    const bool split = a.bf16 == 2;
+    const size_t img_b = ggpm_split_image_bytes(rows, Hp);
+    const size_t l3 = split ? 3 * img_b : lds_tiles(3, Hp, rows);                  // kernel B: the three gate-gradient row sets
+    const size_t l_fused = split ? lds_tiles(2, Hp) + 4 * img_b : lds_tiles(6, Hp);
+    a.fuse_b = (!rt2 && with_b && !a.final_pass && grid_a.y == 1 && l_fused <= 160 * 1024 && !env_no_fuse_b()) ? 1 : 0;
     if (a.fuse_b) with_b = false;
-    const size_t la = a.fuse_b ? lds_tiles(6, Hp) : l3;
+    const size_t la = a.fuse_b ? l_fused : split ? lds_tiles(2, Hp) + img_b : lds_tiles(3, Hp, rows);
     ggpm_timing_begin(3, s, (a.fuse_b ? 4 : 1) * flops1);
-    if (rt2) { set_lds(lstm_bwd_a<false, 2>, la); lstm_bwd_a<false, 2><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
-    else if (a.bf16) { set_lds(lstm_bwd_a<true, 1>, la); lstm_bwd_a<true, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
-    else { set_lds(lstm_bwd_a<false, 1>, la); lstm_bwd_a<false, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    if (rt2) { set_lds(lstm_bwd_a<0, 2>, la); lstm_bwd_a<0, 2><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else if (a.bf16 == 2) { set_lds(lstm_bwd_a<2, 1>, la); lstm_bwd_a<2, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else if (a.bf16 == 1) { set_lds(lstm_bwd_a<1, 1>, la); lstm_bwd_a<1, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else { set_lds(lstm_bwd_a<0, 1>, la); lstm_bwd_a<0, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     ggpm_timing_end(3, s);
     if (with_b) {
         ggpm_timing_begin(7, s, 3 * flops1);
-        if (rt2) { set_lds(lstm_bwd_b<false, 2>, l3); lstm_bwd_b<false, 2><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
-        else if (a.bf16) { set_lds(lstm_bwd_b<true, 1>, l3); lstm_bwd_b<true, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
-        else { set_lds(lstm_bwd_b<false, 1>, l3); lstm_bwd_b<false, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        if (rt2) { set_lds(lstm_bwd_b<0, 2>, l3); lstm_bwd_b<0, 2><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else if (a.bf16 == 2) { set_lds(lstm_bwd_b<2, 1>, l3); lstm_bwd_b<2, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else if (a.bf16 == 1) { set_lds(lstm_bwd_b<1, 1>, l3); lstm_bwd_b<1, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else { set_lds(lstm_bwd_b<0, 1>, l3); lstm_bwd_b<0, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         ggpm_timing_end(7, s);
     }
 }
@@ -625,8 +751,7 @@ void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t ggpm_lstm_pack_floats(int H) {
-    const size_t Hp = (size_t)ggpm_padded_hidden(H);
-    return 4 * Hp * Hp;
+    return 4 * ggpm_packed_matrix_slot(ggpm_padded_hidden(H));
 }
 
 static int lstm_shape_ok(int Hp) { return lds_tiles(3, Hp) <= 160 * 1024; }
@@ -658,11 +783,12 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         return GGPM_ERR_ARG;
     if (save_for_backward && (!Ss || !Is || !Os || !Us || !Fs)) return GGPM_ERR_ARG;
     const int Hp = ggpm_padded_hidden(H);
-    if (!lstm_shape_ok(Hp)) return GGPM_ERR_UNSUPPORTED;
+    if (!lstm_shape_ok(Hp) || (size_t)E1 * Hp >= ((size_t)1 << 30)) return GGPM_ERR_UNSUPPORTED;      // (32-bit byte offsets inside a slot)
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
+    const int bf16 = gate_mode(ggpm_gate_dtype(), Hp, use_rt2(Hp, frozen != nullptr, ggpm_gate_dtype() == 1),
+                               pick_tg(E1, Hp / 16) >= Hp / 16, frozen != nullptr);      // gate mode 0 / 1 / 2
+    const size_t mstep = ggpm_packed_matrix_floats(Hp, bf16);
     float* pWi = wpack; float* pWo = wpack + mstep; float* pWu = wpack + 2 * mstep; float* pWf = wpack + 3 * mstep;
     {
         GgpmPackArgs pk = {};
@@ -683,10 +809,11 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
         LstmFwdArgs a0 = {};
         a0.E1 = E1; a0.Hp = Hp; a0.tg = tg; a0.Hnew = Hs; a0.Qnew = Qs; a0.Wf = pWf; a0.bf16 = bf16;
         if (gathered) { a0.src_h = gs_h; a0.src_c = gs_c; a0.src_idx = gs_idx; a0.Cnew = Cs; }
-        const size_t lb = lds_tiles(1, Hp);
+        const size_t lb = bf16 == 2 ? ggpm_split_image_bytes(ROWS, Hp) : lds_tiles(1, Hp);
         dim3 grid_a(ggpm_ceil_div(E1, ROWS), ggpm_ceil_div(Hp / 16, tg));
-        if (bf16) { set_lds(lstm_fwd_b<true, 1>, lb); lstm_fwd_b<true, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
-        else { set_lds(lstm_fwd_b<false, 1>, lb); lstm_fwd_b<false, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        if (bf16 == 2) { set_lds(lstm_fwd_b<2, 1>, lb); lstm_fwd_b<2, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        else if (bf16 == 1) { set_lds(lstm_fwd_b<1, 1>, lb); lstm_fwd_b<1, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
+        else { set_lds(lstm_fwd_b<0, 1>, lb); lstm_fwd_b<0, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a0); }
     } else {
         (void)hipMemsetAsync(Hs, 0, slot * sizeof(float), s);
         (void)hipMemsetAsync(Cs, 0, slot * sizeof(float), s);
@@ -754,7 +881,7 @@ extern "C" size_t ggpm_lstm_backward_workspace_bytes(int E1, int H, int depth) {
     f += 3 * (size_t)depth * slot;                     // DI, DO, DU
     f += (size_t)depth * slot;                         // DQ (slot t = dqf^t; slot 0 only used by sparse_forward)
     f += 6 * slot;                                     // dS / dFC double buffers + dh / dc carries
-    f += 4 * Hp * Hp;                                  // packed transposes
+    f += 4 * ggpm_packed_matrix_slot((int)Hp);         // packed transposes (the largest gate mode's)
     size_t bytes = f * sizeof(float);
     bytes += ggpm_gemm_workspace_bytes(H, H, depth * E1);
     return bytes + 256;
@@ -786,16 +913,18 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
         return GGPM_ERR_ARG;
     if (work_bytes < ggpm_lstm_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
-    if (!lstm_shape_ok(Hp)) return GGPM_ERR_UNSUPPORTED;
+    if (!lstm_shape_ok(Hp) || (size_t)E1 * Hp >= ((size_t)1 << 30)) return GGPM_ERR_UNSUPPORTED;      // (32-bit byte offsets inside a slot)
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
 
     const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen;
     // (the packed transposes come first: their place does not depend on E1 -- ggpm_weights_packed)
     float* w = work;
-    const int bf16 = ggpm_gate_dtype();
-    const size_t mstep = bf16 ? (size_t)Hp * 32 * ggpm_kc32(Hp) / 2 : HH;      // floats per packed matrix
-    float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep; w += 4 * HH;
+    const int bf16 = gate_mode(ggpm_gate_dtype(), Hp, use_rt2(Hp, frozen != nullptr, ggpm_gate_dtype() == 1),
+                               pick_tg(E1, Hp / 16) >= Hp / 16, frozen != nullptr);      // gate mode 0 / 1 / 2
+    const size_t mstep = ggpm_packed_matrix_floats(Hp, bf16);
+    float* pWiT = w; float* pWoT = w + mstep; float* pWuT = w + 2 * mstep; float* pWfT = w + 3 * mstep;
+    w += 4 * ggpm_packed_matrix_slot(Hp);
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
@@ -872,7 +1001,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
 extern "C" int ggpm_lstm_backward_stashes(float* work, int E1, int H, int depth, float** DI, float** DO, float** DU) {
     if (!work || !DI || !DO || !DU || E1 <= 0 || H <= 0 || depth <= 0) return GGPM_ERR_ARG;
     const size_t Hp = (size_t)ggpm_padded_hidden(H), slot = (size_t)E1 * Hp;
-    *DI = work + 4 * Hp * Hp;
+    *DI = work + 4 * ggpm_packed_matrix_slot((int)Hp);
     *DO = *DI + (size_t)depth * slot;
     *DU = *DO + (size_t)depth * slot;
     return GGPM_OK;
@@ -924,7 +1053,7 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
     const int Hp = ggpm_padded_hidden(H);
     hipStream_t s = (hipStream_t)stream;
     const size_t HH = (size_t)Hp * Hp, slot = (size_t)E1 * Hp;
-    float* w = work + 4 * HH;             // (layout of lstm_backward_impl)
+    float* w = work + 4 * ggpm_packed_matrix_slot(Hp);             // (layout of lstm_backward_impl)
     float* DI = w; w += (size_t)depth * slot;
     float* DO = w; w += (size_t)depth * slot;
     float* DU = w; w += (size_t)depth * slot;
@@ -946,10 +1075,10 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
         gp[3].A = DQ + (size_t)first_slot * slot;
         gp[3].B = Hs + (size_t)first_slot * slot;
         Ks[3] = (depth - first_slot) * E1;
-        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
+        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype());
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }

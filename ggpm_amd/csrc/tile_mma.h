@@ -240,6 +240,208 @@ __device__ __forceinline__ void ggpm_wave_gemm_bf16(const float* const (&tiles)[
     }
 }
 
+// ---- fp32-accurate gate products on the bf16 matrix pipe ("split" operands; gate mode 2) -----------------------------------
+// Every fp32 value is the EXACT sum of three bf16 values (x1 = rne(x), x2 = the upper 8 significant bits of x - x1, x3 = the
+// rest; gemm.hip: gemm_tn_tall_split), a product a*b the sum of nine bf16 x bf16 products that are exact in the fp32
+// accumulator; the three below 2^-24 |a||b| are dropped, the other six are six v_mfma_f32_16x16x32_bf16 (16 cycles each)
+// per 16 x 16 x 32 fragment pair instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each): 2.7x less matrix-pipe time for
+// the same sum to within fp32 rounding.
+//   weights     packed ONCE per call as three bf16 planes in fragment order [out tile][k chunk of 32][plane][lane][8]
+//               (3 KiB contiguous per tile and chunk; zero padded to 32 * kc32 columns);
+//   activations split where they are PRODUCED (gather / epilogue: once per element, not once per reading wave) into an LDS
+//               image of three row-major bf16 planes [rows][LDH], LDH = Hp + 8 halves: the row pitch in dwords is
+//               4 * (Hp / 8 + 1) -- an odd multiple of four, Hp being a multiple of 16 -- so the 16 rows a ds_read_b128
+//               group reads land on 16 distinct bank quads (conflict free).  When Hp is not a multiple of 32 the last k
+//               chunk's upper lanes (k = Hp .. Hp + 15) read the row's 8 pad halves and the first 8 halves of what follows
+//               -- the next row, the next plane, or the 8-half gap that ends every image.  Their weights are zero; what
+//               must not reach the pipe is a stale NaN bit pattern, so pads and gaps are zeroed once per launch
+//               (ggpm_split_init) and everything else a fragment can touch is data of the same image.
+// Summation: the five small products go into one accumulator, a1*b1 into another (added at the end): the small terms are not
+// rounded against the large partial sums, and the two chains are independent for the pipe.
+__device__ __forceinline__ int ggpm_split_ldh(int Hp) { return Hp + 8; }
+static inline int ggpm_split_ldh_host(int Hp) { return Hp + 8; }
+// one image = three planes + an 8-half gap; bytes / halves
+static inline size_t ggpm_split_image_bytes(int rows, int Hp) { return ((size_t)3 * rows * ggpm_split_ldh_host(Hp) + 8) * 2; }
+__device__ __forceinline__ int ggpm_split_image_halves(int rows, int Hp) { return 3 * rows * (Hp + 8) + 8; }
+// floats per packed matrix, by gate mode (0 fp32 fragments, 1 bf16, 2 three bf16 planes); the largest is what callers reserve
+__host__ __device__ static inline size_t ggpm_packed_matrix_floats(int Hp, int mode) {
+    const size_t kc32 = (size_t)((Hp + 31) >> 5);
+    return mode == 2 ? 48 * Hp * kc32 : mode == 1 ? 16 * Hp * kc32 : (size_t)Hp * Hp;
+}
+static inline size_t ggpm_packed_matrix_slot(int Hp) { return ggpm_packed_matrix_floats(Hp, 2); }      // >= every mode's
+struct GgpmNoRing {};
+
+__device__ __forceinline__ size_t ggpm_pack_index_split(int t, int kc, int KC32, int plane, int lane) {
+    return ((((size_t)t * KC32 + kc) * 3 + plane) * 64 + lane) * 8;      // in bf16 elements
+}
+
+// x -> (x1, x2, x3) for four values; each plane as two dwords of packed bf16 (element 0 in the low half)
+__device__ __forceinline__ void ggpm_split3(float4 x, uint2& p1, uint2& p2, uint2& p3) {
+    const float xv[4] = {x.x, x.y, x.z, x.w};
+    unsigned b1[4], r1b[4], r2b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)xv[e];                                   // RNE (v_cvt_pk_bf16_f32)
+        b1[e] = (unsigned)__builtin_bit_cast(unsigned short, h);
+        const float r1 = xv[e] - __builtin_bit_cast(float, b1[e] << 16);  // exact
+        r1b[e] = __builtin_bit_cast(unsigned, r1);
+        const float x2 = __builtin_bit_cast(float, r1b[e] & 0xffff0000u);
+        r2b[e] = __builtin_bit_cast(unsigned, r1 - x2);                   // exact, <= 8 significant bits
+    }
+    p1 = make_uint2(b1[0] | (b1[1] << 16), b1[2] | (b1[3] << 16));
+    p2 = make_uint2(__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u));
+    p3 = make_uint2(__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u));
+}
+
+// store four consecutive columns [c, c+4) of local row lr into the three planes of an LDS image (plane stride PLANE halves)
+__device__ __forceinline__ void ggpm_split_store(__bf16* img, int PLANE, int LDH, int lr, int c, float4 x) {
+    uint2 p1, p2, p3;
+    ggpm_split3(x, p1, p2, p3);
+    __bf16* d = img + lr * LDH + c;
+    *reinterpret_cast<uint2*>(d) = p1;
+    *reinterpret_cast<uint2*>(d + PLANE) = p2;
+    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+}
+
+// zero the row pads and the closing gaps of `nimg` consecutive images of `rows` rows (all threads of the workgroup take part;
+// the data columns are written by the producers, the barrier that publishes them publishes these too)
+__device__ __forceinline__ void ggpm_split_init(__bf16* img0, int nimg, int rows, int Hp) {
+    const int LDH = Hp + 8, IMG = 3 * rows * LDH + 8;
+    for (int it = threadIdx.x; it < nimg * (3 * rows + 1); it += blockDim.x) {
+        const int im = it / (3 * rows + 1), r = it - im * (3 * rows + 1);
+        __bf16* d = img0 + (size_t)im * IMG + (r < 3 * rows ? r * LDH + Hp : 3 * rows * LDH);
+        *reinterpret_cast<uint4*>(d) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// Rows [r0, r0 + ROWS) of a [rows][Hp] fp32 matrix -> the three planes of an LDS image (B kernels); rows past the end: zeros.
+template <int ROWS>
+__device__ __forceinline__ void ggpm_load_rows_to_lds_split(const float* __restrict__ src, int r0, int rows, int Hp,
+                                                            __bf16* img, int PLANE, int LDH) {
+    const int q = Hp >> 2;
+    for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
+        const int lr = it / q, c = (it - lr * q) * 4;
+        const int row = r0 + lr;
+        const float4 v = row < rows ? ggpm_ld4(src + (size_t)row * Hp + c) : ggpm_zero4();
+        ggpm_split_store(img, PLANE, LDH, lr, c, v);
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void ggpm_gather_rows_to_lds_split(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                              int r0, int rows, int Hp, __bf16* img, int PLANE, int LDH,
+                                                              float* __restrict__ copy) {
+    const int q = Hp >> 2;
+    for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
+        const int lr = it / q, c = (it - lr * q) * 4;
+        const int row = r0 + lr;
+        float4 v = ggpm_zero4();
+        if (row < rows) {
+            const int id = idx[row];
+            if (id >= 0) v = ggpm_ld4(src + (size_t)id * Hp + c);
+            if (copy) ggpm_st4(copy + (size_t)row * Hp + c, v);
+        }
+        ggpm_split_store(img, PLANE, LDH, lr, c, v);
+    }
+}
+
+#ifndef GGPM_SPLIT_PF
+#define GGPM_SPLIT_PF 2           // weight-plane ring depth in k chunks of 32 for the two-product loops (3 x 16 B per lane,
+#endif                            // product and chunk); the one-product loops take twice as many chunks (same bytes in flight)
+#ifndef GGPM_SPLIT_PF1
+#define GGPM_SPLIT_PF1 2          // (3 deep spilled 9 registers in lstm_bwd_a, 4 deep 7 in gru_bwd_a)
+#endif
+#ifndef GGPM_SPLIT_PF3
+#define GGPM_SPLIT_PF3 1          // three-product loops: 9 x 16 B per lane and chunk; 2 deep spilled 16-56 registers (the
+#endif                            // load of the next chunk then lands under the other three waves of the SIMD)
+template <int NOPS> struct GgpmSplitPf { static constexpr int value = NOPS == 1 ? GGPM_SPLIT_PF1 : NOPS >= 3 ? GGPM_SPLIT_PF3 : GGPM_SPLIT_PF; };
+template <int NOPS>
+struct GgpmSplitRing {
+    bf16x8 r[GgpmSplitPf<NOPS>::value][NOPS][3];
+};
+
+template <int NOPS>
+__device__ __forceinline__ void ggpm_split_ring_prefetch(const float* const (&wps_f32)[NOPS], int KC32, int t, int lane,
+                                                         GgpmSplitRing<NOPS>& ring) {
+    constexpr int PF = GgpmSplitPf<NOPS>::value;
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int kk = min(d, KC32 - 1);
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                ring.r[d][o][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(wps_f32[o]) +
+                                                                   ggpm_pack_index_split(t, kk, KC32, p, lane));
+    }
+}
+
+// acc[op] += W[op](tile t) x image[op]^T over the full K.  `ring` holds the first PF chunks of tile t.  The MFMAs read the
+// ring's registers themselves and the slot is refilled (chunk kc + PF) right behind them -- no second copy of the fragments
+// in registers; the load then has PF - 1 chunk times to land.  Refills past the end of the tile fetch the head of tile
+// t_next (>= 0, and only when KC32 is a multiple of PF: the ring then arrives loaded at the next call) or re-read the last
+// chunk.  SHARED: every product reads the SAME image (the LSTM's three gates over s): its fragments are fetched once per
+// chunk.  SUM: the products are summed (dS = sum_g dg_pre . W_g): one accumulator pair, acc[0], for all of them.
+template <int NOPS, bool SHARED = false, bool SUM = false>
+__device__ __forceinline__ void ggpm_wave_gemm_split(const __bf16* const (&imgs)[NOPS], int PLANE, int LDH,
+                                                     const float* const (&wps_f32)[NOPS], int KC32, int t, int t_next,
+                                                     int lane, f32x4 (&acc)[NOPS][1], GgpmSplitRing<NOPS>& ring) {
+    constexpr int PF = GgpmSplitPf<NOPS>::value;
+    constexpr int NACC = SUM ? 1 : NOPS;
+    const int boff = (lane & 15) * LDH + 8 * (lane >> 4);
+    const bool chain = t_next >= 0 && (KC32 % PF) == 0;
+    const __bf16* wp[NOPS];
+    const __bf16* wn[NOPS];
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+        wp[o] = reinterpret_cast<const __bf16*>(wps_f32[o]) + ggpm_pack_index_split(t, 0, KC32, 0, lane);
+        wn[o] = reinterpret_cast<const __bf16*>(wps_f32[o]) + ggpm_pack_index_split(chain ? t_next : t, 0, KC32, 0, lane);
+    }
+    f32x4 lo[NACC];
+#pragma unroll
+    for (int o = 0; o < NACC; ++o) lo[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < KC32; kc += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            if (kc + d < KC32) {
+                const int kq = kc + d + PF;
+                const bool over = kq >= KC32;
+                const int kn = over ? (chain ? kq - KC32 : KC32 - 1) : kq;
+                bf16x8 b[3];
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o) {
+                    if (o == 0 || !SHARED) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            b[p] = *reinterpret_cast<const bf16x8*>(imgs[o] + p * PLANE + boff + 32 * (kc + d));
+                    }
+                    constexpr int Z = 0;
+                    f32x4& hi_ = acc[SUM ? Z : o][0];
+                    f32x4& lo_ = lo[SUM ? Z : o];
+                    // smallest terms first: a3*b1, a1*b3, a2*b2, a2*b1, a1*b2 into `lo`; a1*b1 into the main accumulator
+                    lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][2], b[0], lo_, 0, 0, 0);
+                    lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][0], b[2], lo_, 0, 0, 0);
+                    hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][0], b[0], hi_, 0, 0, 0);
+                    lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][1], b[1], lo_, 0, 0, 0);
+                    lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][1], b[0], lo_, 0, 0, 0);
+                    lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][0], b[1], lo_, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot
+#pragma unroll
+                for (int o = 0; o < NOPS; ++o)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        ring.r[d][o][p] = *reinterpret_cast<const bf16x8*>((over && chain ? wn[o] : wp[o]) +
+                                                                           ((size_t)kn * 3 + p) * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NACC; ++o) acc[o][0] = acc[o][0] + lo[o];
+    if (t_next >= 0 && !chain) ggpm_split_ring_prefetch<NOPS>(wps_f32, KC32, t_next, lane, ring);
+}
+
 template <int NOPS, int RT>
 __device__ __forceinline__ void ggpm_zero_acc(f32x4 (&acc)[NOPS][RT]) {
 #pragma unroll

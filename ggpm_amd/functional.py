@@ -830,7 +830,7 @@ class _GruLevel(torch.autograd.Function):
         return dx, dW_z, db_z, dW_r, dU_r, db_u, dW_h, db_h, None, None, None, None, None
 
 
-GATE_DTYPES = {"f32": 0, "fp32": 0, "bf16": 1, None: 0, 0: 0, 1: 1}
+GATE_DTYPES = {"f32": 0, "fp32": 0, "bf16": 1, "f32_mfma": 2, "f32_split": 3, None: 0, 0: 0, 1: 1, 2: 2, 3: 3}
 
 
 class _gate_dtype:

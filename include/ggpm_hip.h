@@ -170,9 +170,14 @@ int ggpm_gru_backward_stashes(float* work, int E1, int H, int depth, float** DMP
 int ggpm_lstm_backward_stashes(float* work, int E1, int H, int depth, float** DI, float** DO, float** DU);
 int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, float* out, ggpm_stream_t stream);
 /* Gate-product dtype of the level calls (ggpm_gru_/ggpm_lstm_ forward, backward, weight_grads) issued by the CALLING
- * THREAD from now on: 0 = fp32 operands (default, the 1e-4 parity mode), 1 = bf16 operands with fp32 accumulate for
- * the hidden x hidden products of the depth loops and the tall weight-gradient contractions (BASELINE configs[4]; the
- * reference's cells are ggpm/rnn.py:27-36, 88-91).  Returns the previous value; any other argument only queries.  The
+ * THREAD from now on: 0 = fp32 operands (default, the 1e-4 parity mode: on dense levels large enough for one column group
+ * the H x H products run at fp32 accuracy on the bf16 matrix pipe, every operand split exactly into three bf16 values
+ * and six of the nine partial products kept; on v_mfma_f32_16x16x4_f32 otherwise),
+ * 1 = bf16 operands with fp32 accumulate for the hidden x hidden products of the depth loops and the tall
+ * weight-gradient contractions (BASELINE configs[4]; the reference's cells are ggpm/rnn.py:27-36, 88-91), 2 = fp32 on
+ * v_mfma_f32_16x16x4_f32 only, 3 = fp32 on split operands wherever their images fit the LDS (0 chooses between 2 and 3
+ * per level: split operands for dense levels of one column group).  Returns the previous value; any other argument only
+ * queries.  The
  * whole-encoder drivers set it from ggpm_enc_dims.gate_dtype for the duration of their call. */
 int ggpm_level_gate_dtype(int dtype);
 /* ------------------------------------------------------------------ GRU message function
@@ -445,7 +450,8 @@ typedef struct ggpm_enc_dims {
                                             (ggpm/rnn.py:41-50 iterates a fixed depth regardless). */
     float dropout;                       /* drop probability of the training forward (0: none / eval) */
     unsigned int seed_lo, seed_hi;       /* mask stream of this forward/backward pair */
-    int gate_dtype;                      /* 0: fp32 gate products (v_mfma_f32_16x16x4_f32; the 1e-4 parity configurations);
+    int gate_dtype;                      /* as ggpm_level_gate_dtype.  0: fp32 gate products (the 1e-4 parity configurations);
+                                            2: fp32 on v_mfma_f32_16x16x4_f32 only;
                                             1: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) for the H x H gate
                                             products of the depth loops -- BASELINE configs[4].  State, stashes, gate math,
                                             input projections and weight-gradient contractions stay fp32. */

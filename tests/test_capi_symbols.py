@@ -26,7 +26,8 @@ def test_library_builds_and_exports_every_symbol():
     assert lib.ggpm_version() >= 100
     assert lib.ggpm_padded_hidden(300) == 304 and lib.ggpm_padded_hidden(16) == 16
     assert lib.ggpm_error_string(1).decode().startswith("invalid")
-    assert lib.ggpm_gru_pack_floats(300) == 3 * 304 * 304 + 304
+    # three matrices in the largest packed form (three bf16 planes, 320 padded columns: 48 * Hp * ceil(Hp / 32) floats) + bias
+    assert lib.ggpm_gru_pack_floats(300) == 3 * 48 * 304 * 10 + 304
     assert lib.ggpm_gemm_workspace_bytes(300, 300, 100) == 0
 
 
