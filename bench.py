@@ -42,6 +42,7 @@ import numpy as np       # noqa: E402
 import torch             # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 (never the 2:1 sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 # BASELINE.json configs[i] -> concrete synthetic workload (C1..C5).  `gen`: motifs-per-molecule
@@ -216,7 +217,7 @@ class Workload:
         from ggpm_amd.nnutils import make_cuda
         from ggpm_amd.parallel import FlatGradSync, broadcast_parameters
         from ggpm_amd.property_vae import HierEncoderVAE
-        self.cfg, self.rnn, self.a, self.world, self.dev = cfg, rnn, a, world, dev
+        self.cfg, self.rnn, self.a, self.world, self.dev, self.gate_dtype = cfg, rnn, a, world, dev, gate_dtype
         n_motif, n_attach = cfg["vocab"]
         # rank r draws the batches r, r+W, ... of the seed-indexed synthetic set (10 000 molecules = 313 batches)
         self.pool = make_batches(a.pool, cfg["batch"], seed0=1000 + rank * 313, gen=cfg["gen"], n_motif=n_motif,
@@ -236,15 +237,10 @@ class Workload:
                 torch.nn.init.xavier_normal_(p)
         self.model.encoder.gate_dtype = gate_dtype
         broadcast_parameters(self.model)
-        # Adam (vae_train.py:60) on one flat view of the parameters; gradients in the flat buffer the all-reduce uses
-        # anyway (GGPM_FLAT_ADAM=0: torch.optim.Adam over the parameter list)
-        if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
-            from ggpm_amd.optim import FlatAdam
-            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
-            self.opt = FlatAdam(self.sync, lr=1e-3)
-        else:
-            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder)
-            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        # Adam (vae_train.py:60) on one flat view of the parameters; gradients in the flat buffer the all-reduce uses anyway
+        from ggpm_amd.optim import FlatAdam
+        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
+        self.opt = FlatAdam(self.sync, lr=1e-3)
         self.host_iter = None
         if a.host_input:
             import itertools
@@ -363,6 +359,7 @@ class Workload:
         torch.cuda.synchronize()
         lib.ggpm_timing_enable(0)
         per = {}
+        peak_tf = PEAK_MFMA_BF16_TFLOPS if self.gate_dtype == "bf16" else PEAK_MFMA_F32_TFLOPS      # (per-kernel "frac")
         for tag, lname in LEVEL_TAGS.items():
             for which, kname in enumerate(KERNELS):
                 n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
@@ -372,7 +369,7 @@ class Workload:
                         "launches": n.value, "avg_launch_us": round(1e3 * ms.value / n.value, 3),
                         "gflop_per_launch": round(fl.value / n.value / 1e9, 4),
                         "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 3),
-                        "frac": round(fl.value / (ms.value * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                        "frac": round(fl.value / (ms.value * 1e-3) / 1e12 / peak_tf, 4),
                         "total_ms": round(ms.value, 3)}
         if "atom" not in per:
             return None
@@ -387,11 +384,28 @@ class Workload:
         except Exception:
             pass
         tree = {lv: per[lv][kname] for lv in ("attachment", "motif") if kname in per.get(lv, {})}
-        return {"kernel": kname, "level": "atom (one 16-wave workgroup per 16 messages, all gate columns)",
-                "bound": "mfma", "achieved": k["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": k["frac"], "traffic": traffic, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
-                "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "tree_levels": tree,
-                "all_depth_kernels": per}
+        out = {"kernel": kname, "level": "atom (one 16-wave workgroup per 16 messages, all gate columns)",
+               "bound": "mfma", "achieved": k["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
+               "frac": k["frac"], "traffic": traffic, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
+               "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "tree_levels": tree,
+               "all_depth_kernels": per}
+        if self.gate_dtype == "bf16":
+            # with bf16 gate products the depth kernels are HBM bound.  Algorithmic bytes of one depth step of the
+            # atom level: s H E (2 + G + g dbar) forwards (X reads, gathered state rows, h' / q' written) and twice that
+            # backwards, plus S = 4 stash arrays written (forward) / read (backward); the A launch is charged with all of it.
+            from ggpm_amd import synth
+            st = [synth.batch_stats(t, g)["atom"] for t, g in self.pool]
+            E, dbar = float(np.mean([x["E"] for x in st])), float(np.mean([x["dbar"] for x in st]))
+            G, g_rows, S, H = (3, 2, 4, self.cfg["hidden"]) if self.rnn == "GRU" else (4, 3, 4, self.cfg["hidden"])
+            per_depth = 4.0 * H * E * (2 + G + g_rows * dbar)
+            nbytes = (2.0 * per_depth if "bwd" in kname else per_depth) + 4.0 * H * E * S
+            gbs = nbytes / (k["avg_launch_us"] * 1e-6) / 1e9
+            out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": round(nbytes, 1),
+                        "mfma": {"achieved": k["tflops"], "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(k["tflops"] / PEAK_MFMA_BF16_TFLOPS, 4),
+                                 "note": "the gate products' flops against the dense bf16 MFMA peak"}})
+        return out
 
 
 class VaeWorkload:
@@ -441,14 +455,10 @@ class VaeWorkload:
             self.items.append((tensors, make_cuda(tensors), sch.to_device(dev), batch6))
         broadcast_parameters(self.model)
         # Adam (vae_train.py:60) on one flat view of the parameters, gradients in the flat buffer the all-reduce uses anyway
-        # and the encoder's backward writes into directly (GGPM_FLAT_ADAM=0: torch.optim.Adam over the parameter list)
-        if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
-            from ggpm_amd.optim import FlatAdam
-            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
-            self.opt = FlatAdam(self.sync, lr=1e-3)
-        else:
-            self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder) if world > 1 else None
-            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)
+        # and the encoder's backward writes into directly
+        from ggpm_amd.optim import FlatAdam
+        self.sync = FlatGradSync(self.model.parameters(), encoder=self.model.encoder, keep_flat=True)
+        self.opt = FlatAdam(self.sync, lr=1e-3)
         self.orders = [None] * cfg["batch"]
 
     def _finish(self, loss, metrics):
@@ -678,6 +688,38 @@ class VaeWorkload:
                           "%.3f s, %d threads" % (cfg["batch"], len(times), med, cores)}
 
 
+def configs4_leg(a, lib, dev, budget_s=90.0):
+    """BASELINE configs[4] as a leg of the default line: {"fp32": ..., "bf16": ...}, <= 6 timed steps each."""
+    import copy
+    import gc
+    if time.time() - _T0 > budget_s:
+        return {"skipped": "the run was %.0f s old when this leg came up (budget %.0f s); `bench.py --config 4` measures it"
+                           % (time.time() - _T0, budget_s)}
+    cfg = dict(CONFIGS[4])
+    b = copy.copy(a)
+    b.pool, b.steps, b.warmup, b.no_full_depth, b.host_input = 2, min(a.steps, 6), 3, True, False
+    out = {"workload": "BASELINE %s: hidden=%d depth=%d batch=%d, %s cell, %d timed steps on a pool of %d batches"
+                       % (cfg["tag"], cfg["hidden"], cfg["depth"], cfg["batch"], cfg["rnn"], b.steps, b.pool)}
+    try:
+        for key, dt in (("fp32", "f32"), ("bf16", "bf16")):
+            gc.unfreeze()
+            gc.collect()
+            torch.cuda.empty_cache()
+            wl = Workload(cfg, cfg["rnn"], b, 0, 1, dev, gate_dtype=dt)
+            m = wl.measure(lib, 0)
+            leg = {k: m[k] for k in ("ms_per_step", "value", "unit", "step_tflops_executed", "atoms_per_molecule") if k in m}
+            r = m.get("roofline")
+            if r:
+                leg["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                     "algorithmic_bytes_per_launch", "mfma") if k in r}
+                leg["roofline"]["all_depth_kernels"] = {"atom": r.get("all_depth_kernels", {}).get("atom")}
+            out[key] = leg
+            del wl
+    except Exception as exc:          # (a leg is a reported number, never a reason to lose the line)
+        out["error"] = repr(exc)
+    return out
+
+
 _REAL_STDOUT = None
 
 
@@ -686,9 +728,8 @@ def _settle_gc():
     schedules' thousands of small index tables) to the permanent generation, so that a full collection falling into the
     timed steps does not walk them again (one such pass cost 90 ms of a 30-step VAE measurement)."""
     import gc
-    if os.environ.get("GGPM_BENCH_GC_FREEZE", "1") != "0":
-        gc.collect()
-        gc.freeze()
+    gc.collect()
+    gc.freeze()
 
 
 def _claim_stdout():
@@ -739,6 +780,7 @@ def parse_args(argv=None):
     ap.add_argument("--vae-profile", default=None, choices=["resident", "in_loop"],
                     help="with --only-vae under rocprofv3: stop after the resident steps / after the vae_train.py-shaped steps, so "
                          "that the trace ends with the steps to be cut out (tools/prof_summary.py --steps)")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] leg of the default line (\"configs4\": fp32 + bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args(argv)
@@ -824,10 +866,13 @@ def main():
                                   " + %s all-reduce (rehearsal backend, not RCCL)" % a.backend),
                    "baseline_config_index": a.config, "rnn_type": rnn, "global_batch": cfg["batch"] * world,
                    "parallelism": "dp%d" % world,
-                   "arithmetic": "fp32 state, stashes, gate math and accumulation; gate products of the depth loops on "
-                                 "v_mfma_f32_16x16x4_f32%s; tall weight-gradient contractions %s" % (
+                   "arithmetic": "fp32 state, stashes, gate math and accumulation; gate products of the depth loops: the atom "
+                                 "level (one column group) on split operands -- every fp32 operand the exact sum of three "
+                                 "bf16 values, six of the nine partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate, "
+                                 "within fp32 rounding of the fp32 product (tests: test_gate_products_on_split_operands_keep_"
+                                 "fp32_accuracy) -- the tree-side levels and two-row-tile launches on v_mfma_f32_16x16x4_f32%s; "
+                                 "tall weight-gradient contractions %s" % (
                                      " (bf16 operands under --dtype bf16 / the \"bf16\" leg)" if a.config == 4 else "",
-                                     "on fp32 MFMA (GGPM_TALL_SPLIT=0)" if os.environ.get("GGPM_TALL_SPLIT") == "0" else
                                      "with every fp32 operand split exactly into three bf16 terms, six of the nine partial "
                                      "products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (fp32 accuracy: 3e-6 from fp64)"),
                    "algorithmic_gflop_per_step_per_gpu": m["algorithmic_gflop_per_step_per_gpu"],
@@ -864,8 +909,6 @@ def main():
         result["bf16"]["dtype"] = ("bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16) for the H x H gate products of "
                                    "the depth loops; state, stashes, gate math, input projections and weight-gradient "
                                    "contractions fp32; tolerance: tests/test_gpu_parity.py::test_bf16_gate_products")
-        if "roofline" in result["bf16"]:
-            result["bf16"]["roofline"]["note"] = "fractions are quoted against the fp32 MFMA peak for comparability"
 
     # the reported row: full VAE training step (never allowed to cost the line)
     vae = None
@@ -890,6 +933,12 @@ def main():
                 raise                            # (ranks must not diverge around collectives)
             result["vae_step"] = {"error": repr(exc)}
             vae = None
+
+    # configs[4] (polymers, H = 600, depth 30) next to the headline row, so that its numbers are timed by whoever runs the
+    # default command: fp32 and the bf16 leg, a few steps each on a pool of two batches; skipped, with the reason in the
+    # line, once the run is past its time budget
+    if a.config == 1 and world == 1 and not a.no_configs4 and not a.host_input and a.rnn is None:
+        result["configs4"] = configs4_leg(a, lib, dev)
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if vae is not None:

@@ -48,8 +48,6 @@ SIGNATURES = {
     "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_gru_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               P, I, P, I, P, P, I, P, c_size_t, I, P]),
-    "ggpm_gru_backward_overlapped": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                         P, I, P, I, P, P, I, P, c_size_t, P, P]),
     "ggpm_csr_table4": (I, [P, P, I, P, P]),
     "ggpm_gru_forward_tab": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_backward_tab": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,

@@ -33,7 +33,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import _lib
+from . import _dev, _lib
 from . import functional as F_
 
 
@@ -419,13 +419,13 @@ def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
     return d, keep
 
 
-_DRIVER = os.environ.get("GGPM_DECODE_DRIVER", "1") != "0"    # (0: the step loops are issued from Python; dev A/B, tests)
-# The two step loops are ~280 launches = 1.5-1.8 ms of host time each, inside one C call.  GGPM_ATOM_ASYNC=1 (default)
+_DRIVER = _dev.DECODE_DRIVER    # (False: the step loops are issued from Python; dev A/B, tests)
+# The two step loops are ~280 launches = 1.5-1.8 ms of host time each, inside one C call.  _dev.ATOM_ASYNC (default)
 # hands them to a worker thread of the library (ggpm_decode_steps_*_async): the forward loop is then issued beside the
 # encoder's forward, the backward loop beside the encoder's backward -- the autograd engine reaches the two nodes at about
 # the same time and would otherwise issue one chain only after the other, although they do not depend on each other.
 # What follows a loop on its stream (read-out / parameter gradients) is enqueued after ggpm_decode_join.
-_ASYNC = os.environ.get("GGPM_ATOM_ASYNC", "1") != "0"
+_ASYNC = _dev.ATOM_ASYNC
 _INFLIGHT: list = []         # buffers named by loops the worker may still be issuing (released by the next join)
 _PENDING: dict = {}          # id(plan) -> the forward's `finish` closure, taken by atom_decode()
 
@@ -433,11 +433,11 @@ _PENDING: dict = {}          # id(plan) -> the forward's `finish` closure, taken
 def _join_worker(what: str) -> None:
     _lib.check(_lib.load().ggpm_decode_join(), what)
     del _INFLIGHT[:]
-_PACK_ONCE = os.environ.get("GGPM_PACK_ONCE", "1") != "0"      # (0: every decode step packs its weights again; dev A/B)
+_PACK_ONCE = _dev.PACK_ONCE      # (False: every decode step packs its weights again; dev A/B)
 
 
 def compact_enabled() -> bool:
-    return os.environ.get("GGPM_ATOM_COMPACT", "1") != "0"
+    return _dev.ATOM_COMPACT
 
 
 def _vp(addr: int) -> ctypes.c_void_p:
@@ -733,7 +733,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
         # host time: with the step loop handed to the worker thread they are issued AFTER the loop has been posted (below),
         # so that the longest chain of the pass starts first; without the worker, here.
         F_.mark("bwd: atom level's node reached")
-        flush_after_post = _DRIVER and _ASYNC and os.environ.get("GGPM_DEFER_EARLY_AT", "post") == "post"
+        flush_after_post = _DRIVER and _ASYNC
         if not flush_after_post:
             F_.flush_deferred_early()
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "../../include/ggpm_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,6 +21,38 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // leaves benign errors behind, e.g. from capability probes); clear it on entry so that the check after our
 // launches reports OUR launches only.
 #define GGPM_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
+// Tuning / ablation switches (tile splits, kernel selections, phases switched off for timing, ...) are read from the
+// environment only in the DEV variant of the library -- `python -m ggpm_amd.build --variant dev -DGGPM_DEV_SWITCHES`, selected
+// at run time with GGPM_LIB_PATH.  The product build compiles every one of them to its default: it has no environment
+// switches of its own.  tools/README.md lists the names.
+#ifdef GGPM_DEV_SWITCHES
+inline const char* ggpm_dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* ggpm_dev_env(const char*) { return nullptr; }
+#endif
+
+// Raise a kernel's dynamic-LDS limit to at least `bytes`: once per (kernel instantiation, device, size) instead of once per
+// launch (the attribute call costs host microseconds; a level issues ~40 launches per direction).  Launches come from several
+// host threads at once (autograd's, the library's decode and side workers): the limit is only ever RAISED, under a lock, and
+// the size on record is stored after the call succeeded -- a thread can therefore never see a size on record that is larger
+// than the attribute in force.
+template <typename K>
+inline void ggpm_set_lds(K kernel, size_t bytes) {
+    constexpr int MAXDEV = 16;
+    static std::atomic<size_t> have[MAXDEV];      // (one set per kernel instantiation; zero-initialised)
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
+    if (bytes <= have[dev].load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bytes <= have[dev].load(std::memory_order_relaxed)) return;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
+        hipSuccess)
+        have[dev].store(bytes, std::memory_order_release);
+    else
+        (void)hipGetLastError();                   // (the launch that follows reports the failure)
+}
 
 static inline int ggpm_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int ggpm_round_up(int a, int b) { return ggpm_ceil_div(a, b) * b; }

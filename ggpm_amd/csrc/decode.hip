@@ -19,7 +19,7 @@ namespace {
 
 // GGPM_DECODE_FOLD=0 (dev A/B, tests): the start-state gather and the incoming-gradient scatter of every decode step as
 // launches of their own instead of inside the step's first / last launch
-inline bool decode_fold() { static const bool v = [] { const char* e = getenv("GGPM_DECODE_FOLD"); return !e || atoi(e) != 0; }(); return v; }
+inline bool decode_fold() { static const bool v = [] { const char* e = ggpm_dev_env("GGPM_DECODE_FOLD"); return !e || atoi(e) != 0; }(); return v; }
 
 struct Offs {
     size_t f0, f1, r0, q0;      // F-id range of the step, first row of its [depth][n] and [depth + 1][n] blocks

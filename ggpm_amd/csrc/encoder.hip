@@ -166,14 +166,9 @@ inline int lwo(bool lstm, int level) { return lstm ? lq(level, Q_WO) : lp(level,
 inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level, L_BO); }
 
 // GGPM_SPLIT_TAIL=0: the input-half gradients of the last level behind its tall contractions on the second stream again
-inline bool split_tail_enabled() { static const bool v = !(getenv("GGPM_SPLIT_TAIL") && atoi(getenv("GGPM_SPLIT_TAIL")) == 0); return v; }
-inline int wgrad_overlap_mode() {
-    static const int v = getenv("GGPM_WGRAD_OVERLAP") ? atoi(getenv("GGPM_WGRAD_OVERLAP")) : 0;
-    return v;
-}
-
+inline bool split_tail_enabled() { static const bool v = !(ggpm_dev_env("GGPM_SPLIT_TAIL") && atoi(ggpm_dev_env("GGPM_SPLIT_TAIL")) == 0); return v; }
 inline bool use_tables() {
-    static const bool on = getenv("GGPM_TABLES") != nullptr && atoi(getenv("GGPM_TABLES")) != 0;   // opt-in: measured slower
+    static const bool on = ggpm_dev_env("GGPM_TABLES") != nullptr && atoi(ggpm_dev_env("GGPM_TABLES")) != 0;   // opt-in: measured slower
     return on;
 }
 
@@ -187,7 +182,7 @@ inline bool use_tables() {
 class SideWorker {
 public:
     static SideWorker* get() {
-        static const bool on = !(getenv("GGPM_SIDE_WORKER") && atoi(getenv("GGPM_SIDE_WORKER")) == 0);
+        static const bool on = !(ggpm_dev_env("GGPM_SIDE_WORKER") && atoi(ggpm_dev_env("GGPM_SIDE_WORKER")) == 0);
         if (!on) return nullptr;
         static SideWorker w;
         return &w;
@@ -295,7 +290,7 @@ __global__ void __launch_bounds__(256) replicate_slots_k(ReplicateArgs r) {
 
 // steps a tree-side level really has to run: chain + 1 (the step after the last change also fixes the stash)
 inline int run_steps(const Dims& d, int level, int depth) {
-    static const bool off = getenv("GGPM_TREE_FIXED_POINT") && atoi(getenv("GGPM_TREE_FIXED_POINT")) == 0;
+    static const bool off = ggpm_dev_env("GGPM_TREE_FIXED_POINT") && atoi(ggpm_dev_env("GGPM_TREE_FIXED_POINT")) == 0;
     if (off || level == 2 || d.tree_chain <= 0 || d.tree_chain + 1 >= depth) return depth;
     return d.tree_chain + 1;
 }
@@ -303,7 +298,7 @@ inline int run_steps(const Dims& d, int level, int depth) {
 // first step the backward of a tree-side level has to run: lo = max(1, D - chain + 1) (common.h: below it d(h^t) is
 // exactly zero); 1 = all steps
 inline int backward_lo(const Dims& d, int level, int depth) {
-    static const bool off = getenv("GGPM_TREE_FIXED_POINT") && atoi(getenv("GGPM_TREE_FIXED_POINT")) == 0;
+    static const bool off = ggpm_dev_env("GGPM_TREE_FIXED_POINT") && atoi(ggpm_dev_env("GGPM_TREE_FIXED_POINT")) == 0;
     if (off || level == 2 || d.tree_chain <= 0) return 1;
     const int lo = depth - d.tree_chain + 1;
     return lo < 1 ? 1 : lo;
@@ -610,7 +605,7 @@ int linear2_wgrad(int M, int N, const float* dpre, int ldp, const float* x1, int
 // backward of one level given dHD = d(h_D); dx (the gradient of the level's message inputs) is optional
 int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int ldx, float* const* P, float* const* G,
                    int level, const Csr& pred, const LevelSaved& L, const float* dHD, float* dX, float* level_work,
-                   float* dx, int lddx, BwdWork& w, Streams& st, int overlap_wgrads = 0) {
+                   float* dx, int lddx, BwdWork& w, Streams& st) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
     const int blo = backward_lo(d, level, depth);
@@ -619,8 +614,8 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     // no input gradient wanted (the atom level: one-hot inputs): the summed gate-input gradients are not needed on this
     // stream at all -- the depth launches skip their read-modify-write and the second stream sums the stashed gate
     // gradients before it contracts them (GGPM_SKIP_XSUM=0: per-depth accumulation everywhere)
-    static const bool xsum_env = !(getenv("GGPM_SKIP_XSUM") && atoi(getenv("GGPM_SKIP_XSUM")) == 0);
-    const bool skip_xsum = xsum_env && overlap_wgrads == 0 && dx == nullptr && depth > 1;
+    static const bool xsum_env = !(ggpm_dev_env("GGPM_SKIP_XSUM") && atoi(ggpm_dev_env("GGPM_SKIP_XSUM")) == 0);
+    const bool skip_xsum = xsum_env && dx == nullptr && depth > 1;
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
         float* dW[4] = {G[lq(level, Q_WI)], G[lq(level, Q_WOG)], G[lq(level, Q_WU)], G[lq(level, Q_WF)]};
@@ -686,45 +681,13 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     }
     const float *Wz = P[lp(level, L_WZ)], *Wr = P[lp(level, L_WR)], *Wh = P[lp(level, L_WH)];
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
-    // The last level of the backward (the atom level) has nothing behind it to hide its weight-gradient contractions:
-    // issue them in chunks of depths on the second stream WHILE its own depth loop still runs.
-    const bool overlap = overlap_wgrads != 0 && st.side != nullptr;
-    if (overlap) {
-        CK(st.side_after_main());
-        ggpm_stream_t chunk_stream = st.side;
-        if (overlap_wgrads == 2) {          // chunks on a LOW-priority stream: they should only fill idle CUs
-            static thread_local hipStream_t lowp = nullptr;
-            if (!lowp) {
-                int least = 0, greatest = 0;
-                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-                if (hipStreamCreateWithPriority(&lowp, hipStreamNonBlocking, least) != hipSuccess) lowp = nullptr;
-            }
-            if (lowp) {
-                hipEvent_t ev = ggpm_wgrad_event(58);
-                (void)hipEventRecord(ev, (hipStream_t)st.side);
-                (void)hipStreamWaitEvent(lowp, ev, 0);
-                chunk_stream = lowp;
-            }
-        }
-        CK(ggpm_gru_backward_overlapped(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
-                                        pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs, L.Qs, L.St, L.St + ds,
-                                        L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot, dX + 2 * slot,
-                                        dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
-                                        w.level_work_bytes, st.main, chunk_stream));
-        if (chunk_stream != st.side) {      // the rest of the second stream's work comes after the chunks
-            hipEvent_t ev = ggpm_wgrad_event(59);
-            (void)hipEventRecord(ev, (hipStream_t)chunk_stream);
-            (void)hipStreamWaitEvent((hipStream_t)st.side, ev, 0);
-        }
-    } else {
-        ggpm_backward_lo_depth(blo);
-        if (skip_xsum) ggpm_backward_skip_x_sums(1);
-        CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
-                                 pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
-                                 L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
-                                 dX + 2 * slot, dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
-                                 w.level_work_bytes, 0, st.main));
-    }
+    ggpm_backward_lo_depth(blo);
+    if (skip_xsum) ggpm_backward_skip_x_sums(1);
+    CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
+                             pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
+                             L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
+                             dX + 2 * slot, dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
+                             w.level_work_bytes, 0, st.main));
     if (dx) {       // needed upstream right away: main stream
         // dx = dX_z W_z[:, :I] + dX_r W_r + dX_h W_h[:, :I]: one launch over three K segments
         const float* A[3] = {dX, dX + slot, dX + 2 * slot};
@@ -763,15 +726,13 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     };
     // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE, beside
     // the tall contractions on the second stream, instead of behind them
-    const bool x_on_main = skip_xsum && st.side != nullptr && !overlap && split_tail_enabled();
+    const bool x_on_main = skip_xsum && st.side != nullptr && split_tail_enabled();
     const int rc_side = st.on_side([=]() -> int {
         if (!x_on_main) CK(x_part(sw));
-        if (!overlap) {
-            ggpm_wgrad_lo_depth(blo);
-            GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)
-            CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
-                                     dbu, dWh + I, I + H, sw));
-        }
+        ggpm_wgrad_lo_depth(blo);
+        GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)
+        CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
+                                 dbu, dWh + I, I + H, sw));
         return GGPM_OK;
     });
     if (rc_side) return rc_side;
@@ -816,8 +777,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
     float* const* P = params;
     float* const* G = grads;
     const int H = d.H, Hp = d.Hp, He = d.He;
-    // (the opt-in overlapped weight gradients interleave both streams from the calling thread: no worker then)
-    Streams st = {stream, side_stream, 0, (side_stream && wgrad_overlap_mode() == 0) ? SideWorker::get() : nullptr};
+    Streams st = {stream, side_stream, 0, side_stream ? SideWorker::get() : nullptr};
     DrainGuard guard = {st.wk};
     if (st.wk) {
         int dev = 0;
@@ -930,7 +890,7 @@ extern "C" int ggpm_encoder_backward(const ggpm_enc_dims* dims, float* const* pa
                      st));
     CK(ggpm_segment_sum(w.d_nei_g, Hp, S.gagr.rowptrT, S.gagr.colT, d.E1g, H, w.d_h, Hp, 0, Hp, stream));
     CK(level_backward(d, d.E1g, d.Ig, d.depthG, S.hmess_a, d.ld_m, P, G, 2, S.gpred, S.lv[2], w.d_h, dXl[2], lwork[2],
-                      nullptr, 0, w, st, wgrad_overlap_mode()));
+                      nullptr, 0, w, st));
 
     CK(st.drain());
     if (side_stream) {      // every gradient buffer is complete once the main stream has passed this point

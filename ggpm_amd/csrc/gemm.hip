@@ -960,15 +960,10 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
 }
 constexpr size_t GGPM_TALL_SPLIT_LDS = (size_t)2 * 3 * BTK * BLD * sizeof(__bf16);
 // 0: fp32 MFMA for the fp32 tall contractions (the round-1 kernel); 1 (default): split operands on the bf16 pipe
-inline int tall_split_mode() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT"); return e ? atoi(e) : 1; }(); return v; }
-inline int tall_split_wgs() { static const int v = [] { const char* e = getenv("GGPM_TALL_SPLIT_WGS"); return e ? atoi(e) : 256; }(); return v; }
+inline int tall_split_mode() { static const int v = [] { const char* e = ggpm_dev_env("GGPM_TALL_SPLIT"); return e ? atoi(e) : 1; }(); return v; }
+inline int tall_split_wgs() { static const int v = [] { const char* e = ggpm_dev_env("GGPM_TALL_SPLIT_WGS"); return e ? atoi(e) : 256; }(); return v; }
 inline void launch_tall_split(const GemmGroupArgs& gg, dim3 grid, int splits, hipStream_t s) {
-    static bool ready = false;
-    if (!ready) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_tall_split), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)GGPM_TALL_SPLIT_LDS);
-        ready = true;
-    }
+    ggpm_set_lds(gemm_tn_tall_split, GGPM_TALL_SPLIT_LDS);
     gemm_tn_tall_split<<<grid, 512, GGPM_TALL_SPLIT_LDS, s>>>(gg, splits);
 }
 
@@ -1019,7 +1014,7 @@ inline size_t tall_slab_bytes(int M, int N) {
 }
 constexpr int GGPM_TALL_BF16_WGS = 768;      // workgroups of a bf16 tall launch (three per CU: it lives on overlapped loads)
 inline int tall_splits(int M, int N, int K, int target_wgs = 0) {
-    static const int target_env = [] { const char* e = getenv("GGPM_GEMM_TALL_WGS"); return e ? atoi(e) : 256; }();
+    static const int target_env = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL_WGS"); return e ? atoi(e) : 256; }();
     const int target = target_wgs > 0 ? target_wgs : target_env;
     const int tiles = ggpm_ceil_div(M, TM) * ggpm_ceil_div(N, TN);
     int s = target / tiles, maxs = K / (8 * TK);
@@ -1129,8 +1124,8 @@ namespace {
 // gemm_small_v3 when the 64 x 64 kernels would launch about one workgroup per CU or fewer (swept: 128 / 300 / 1024
 // tiles -> 4.51 / 4.49 / 4.53 ms per GRU step)
 inline bool small_launch(int M, int N, int count) {
-    static const int use_v3 = [] { const char* e = getenv("GGPM_GEMM_V3"); return e ? atoi(e) : 1; }();
-    static const int max_tiles = [] { const char* e = getenv("GGPM_GEMM_V3_TILES"); return e ? atoi(e) : 300; }();
+    static const int use_v3 = [] { const char* e = ggpm_dev_env("GGPM_GEMM_V3"); return e ? atoi(e) : 1; }();
+    static const int max_tiles = [] { const char* e = ggpm_dev_env("GGPM_GEMM_V3_TILES"); return e ? atoi(e) : 300; }();
     return use_v3 && (size_t)ggpm_ceil_div(M, BM) * ggpm_ceil_div(N, BN) * count <= (size_t)max_tiles;
 }
 inline void launch_small(int trans_a, int trans_b, const GemmGroupArgs& gg, int count, int M, int n_pad_max, hipStream_t s) {
@@ -1164,7 +1159,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     g.n_pad = n_pad; g.bias = bias; g.accumulate = accumulate; g.act = act; g.zero_row0 = zero_row0;
     g.vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
-    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    static const int use_tall = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
     if (use_tall && trans_a && !trans_b && g.vecA && g.vecB && lda >= ggpm_round_up(M, 4) && ldb >= ggpm_round_up(N, 4) &&
         tall_shape(M, N, K) && n_pad <= ggpm_round_up(N, TN) && (size_t)K * lda * 4 < 0xffffff00ull && (size_t)K * ldb * 4 < 0xffffff00ull) {
         const size_t slab = tall_slab_bytes(M, N);
@@ -1195,7 +1190,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
         dim3 grid(tiles_n, tiles_m, splits);
         static unsigned long long* dbg = [] {
             unsigned long long* p = nullptr;
-            if (getenv("GGPM_GEMM_DEBUG")) (void)hipMalloc(&p, 64);
+            if (ggpm_dev_env("GGPM_GEMM_DEBUG")) (void)hipMalloc(&p, 64);
             return p;
         }();
         g.dbg = dbg;
@@ -1226,7 +1221,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
     }
     if (splits <= 1) { splits = 1; g.k_chunk = ggpm_round_up(K, BK); g.ws = nullptr; } else { g.ws = splitk_ws; }
     dim3 grid(ggpm_ceil_div(splits > 1 ? N : n_pad, BN), ggpm_ceil_div(M, BM), splits);
-    static const int use_v2 = [] { const char* e = getenv("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
+    static const int use_v2 = [] { const char* e = ggpm_dev_env("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
     const size_t rows_a = trans_a ? K : M, rows_b = trans_b ? N : K;
     if (use_v2 && splits == 1 && small_launch(M, N, 1) && g.vecA && g.vecB && rows_a * lda * 4 < 0xffffff00ull &&
         rows_b * ldb * 4 < 0xffffff00ull) {
@@ -1258,7 +1253,7 @@ extern "C" int ggpm_gemm(int trans_a, int trans_b, int M, int N, int K, const fl
 
 namespace {
 inline bool v2_operands_ok(const float* A, int lda, size_t rows_a, const float* B, int ldb, size_t rows_b) {
-    static const int use_v2 = [] { const char* e = getenv("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
+    static const int use_v2 = [] { const char* e = ggpm_dev_env("GGPM_GEMM_V2"); return e ? atoi(e) : 1; }();
     return use_v2 && (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
            rows_a * lda * 4 < 0xffffff00ull && rows_b * ldb * 4 < 0xffffff00ull;
 }
@@ -1275,7 +1270,7 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
                            ggpm_stream_t stream, int bf16) {
     GGPM_CLEAR_STALE_ERROR();
     if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || !K || M <= 0 || N <= 0) return GGPM_ERR_ARG;
-    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    static const int use_tall = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
     const size_t slab = tall_slab_bytes(M, N);
     // (bf16 operands exist in the tall kernel only: a group that does not qualify falls back to fp32 products, which is
     // the more accurate side of the stated tolerance)
@@ -1319,7 +1314,7 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
 }
 
 extern "C" int ggpm_gemm_tn_bf16_applies(int M, int N, int K) {
-    static const int use_tall = [] { const char* e = getenv("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    static const int use_tall = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
     return use_tall && M > 0 && N > 0 && K > 0 && tall_shape(M, N, K) ? 1 : 0;
 }
 

@@ -745,33 +745,23 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     }
 }
 
-// Raise the dynamic-LDS limit of a kernel once per (kernel, size) instead of once per launch: the attribute call
-// costs host microseconds and a level issues ~40 launches per direction.  (A benign race between autograd
-// threads at worst repeats the call.)
 template <typename K>
-inline void set_lds(K kernel, size_t bytes) {
-    static size_t have = 0;            // one static per kernel instantiation
-    if (bytes > have) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bytes);
-        have = bytes;
-    }
-}
+inline void set_lds(K kernel, size_t bytes) { ggpm_set_lds(kernel, bytes); }      // (common.h)
 
 // Environment switches are read once: getenv walks the whole environment (~0.5 us) and the launch helpers below run
 // ~120 times per training step.
-inline bool env_no_fuse_b() { static const bool v = getenv("GGPM_NO_FUSE_B") != nullptr; return v; }
-inline bool env_adebug() { static const bool v = getenv("GGPM_ADEBUG") != nullptr; return v; }
+inline bool env_no_fuse_b() { static const bool v = ggpm_dev_env("GGPM_NO_FUSE_B") != nullptr; return v; }
+inline bool env_adebug() { static const bool v = ggpm_dev_env("GGPM_ADEBUG") != nullptr; return v; }
 
 inline int pick_tg(int E1, int NT) {
-    static const char* const tg_env = getenv("GGPM_TG");
+    static const char* const tg_env = ggpm_dev_env("GGPM_TG");
     if (const char* e = tg_env) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
-    static const char* const tg_small_env = getenv("GGPM_TG_SMALL");
+    static const char* const tg_small_env = ggpm_dev_env("GGPM_TG_SMALL");
     if (const char* e = tg_small_env) {      // tuning override for the small (motif / attachment) levels only
         int v = atoi(e);
         if (v >= 1 && v <= 64 && (E1 + 15) / 16 <= 64) return v < NT ? v : NT;
     }
-    static const char* const tg_large_env = getenv("GGPM_TG_LARGE");
+    static const char* const tg_large_env = ggpm_dev_env("GGPM_TG_LARGE");
     if (const char* e = tg_large_env) {      // tuning override for the large (atom) levels only
         int v = atoi(e);
         if (v >= 1 && v <= 64 && (E1 + 15) / 16 > 64) return v < NT ? v : NT;
@@ -782,7 +772,7 @@ inline int pick_tg(int E1, int NT) {
 // two row tiles per workgroup where the level is large enough to be bound by the weight stream (see GGPM_RT2_MIN_ROW_TILES)
 thread_local bool g_prefer_narrow = false;       // ggpm_level_prefer_narrow
 inline bool use_rt2(int E1, int Hp, bool sparse) {
-    static const int mode = [] { const char* e = getenv("GGPM_RT2"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
+    static const int mode = [] { const char* e = ggpm_dev_env("GGPM_RT2"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
     if (mode == 0 || sparse) return false;
     if ((size_t)2 * 32 * (Hp + 4) * sizeof(float) > 160 * 1024) return false;
     return mode == 2 || g_prefer_narrow || ggpm_ceil_div(E1, 16) >= GGPM_RT2_MIN_ROW_TILES;
@@ -800,7 +790,7 @@ inline bool use_rt2(int E1, int Hp, bool sparse) {
 inline int gate_mode(int dtype, int Hp, bool rt2, bool single_group, bool sparse) {
     if (dtype == 1) return 1;
     if (dtype == 2) return 0;
-    static const bool on = [] { const char* e = getenv("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char* e = ggpm_dev_env("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
     if (!on || rt2) return 0;
     if (dtype != 3 && (!single_group || sparse)) return 0;
     const size_t need = (size_t)16 * (Hp + 4) * sizeof(float) + 2 * ggpm_split_image_bytes(16, Hp);
@@ -1024,7 +1014,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
-    static const char* const abl = getenv("GGPM_ABLATE");
+    static const char* const abl = ggpm_dev_env("GGPM_ABLATE");
     int run_depth = ggpm_take_run_depth();
     if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
     for (int t = 1; t <= run_depth; ++t) {
@@ -1103,15 +1093,13 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
                                  float* work, size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
                                  float* dbu, float* dWh_h, int ld_dwh, bool with_slot0, int lo, ggpm_stream_t stream);
 
-// depths per chunk of the overlapped weight-gradient contractions, and a small pool of re-recordable events
-constexpr int GGPM_WGRAD_CHUNK = 5;
+// a small pool of re-recordable events (the encoder drivers' stream ordering, encoder.hip)
 hipEvent_t ggpm_wgrad_event(int i) {
     static thread_local hipEvent_t pool[64] = {};
     i &= 63;
     if (!pool[i] && hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     return pool[i];
 }
-static inline hipEvent_t wgrad_event(int i) { return ggpm_wgrad_event(i); }
 
 static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
                                  const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
@@ -1122,10 +1110,10 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, int weight_grads,
                                  const unsigned char* frozen, float* dHin, ggpm_stream_t stream,
-                                 ggpm_stream_t side_stream = nullptr, const int32_t* succ_tab = nullptr) {
+                                 const int32_t* succ_tab = nullptr) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
-    const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen && !side_stream;
+    const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen;
     float *ss_h = nullptr, *ss_c = nullptr;
     const int32_t* ss_idx = nullptr;
     const bool scattered = ggpm_take_scatter_state(&ss_h, &ss_c, &ss_idx) && frozen;      // (consumed on every path)
@@ -1175,11 +1163,9 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
-    int chunk_hi = depth, n_ev = 0;
-    bool first_chunk = true, dur_started = false;
-    // tree-side levels: d(h^t) vanishes below step `lo` (nilpotent Jacobian, common.h); sparse / overlapped runs go all the way
+    // tree-side levels: d(h^t) vanishes below step `lo` (nilpotent Jacobian, common.h); sparse runs go all the way
     int lo = ggpm_take_backward_lo();
-    if (lo < 1 || lo > depth || frozen || side_stream) lo = 1;
+    if (lo < 1 || lo > depth || frozen) lo = 1;
     for (int t = depth; t >= lo; --t) {
         GruBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
@@ -1199,53 +1185,8 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
         a.skip_xsum = skip_xsum ? 1 : 0;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);     // (the dS/dG launch of step lo > 1 still forms dXr)
-        if (side_stream && !frozen) {
-            // Overlapped weight gradients: the stash slots of the depths finished so far are final, so their share of
-            // the three tall contractions runs on the second stream beside the rest of this (latency-bound) loop.
-            const int done = depth - t + 1;
-            const bool last = (t == 1);
-            if (done % GGPM_WGRAD_CHUNK == 0 || last) {
-                const int t_hi = chunk_hi;                 // depths (t_hi .. t] finished since the last chunk
-                chunk_hi = t - 1;
-                hipEvent_t ev = wgrad_event(n_ev++);
-                if (!ev) return GGPM_ERR_LAUNCH;
-                (void)hipEventRecord(ev, s);
-                (void)hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
-                const int acc = first_chunk ? 0 : 1;
-                const int nsl = t_hi - t + 1;              // slots t-1 .. t_hi-1 of DMP/DZP/S/G
-                const int K1 = nsl * E1;
-                int rc = ggpm_gemm(1, 0, H, H, K1, DMP + (size_t)(t - 1) * slot, Hp, Gs + (size_t)(t - 1) * slot, Hp, dWh_h,
-                                   ld_dwh, H, nullptr, acc, GGPM_ACT_NONE, 0, skws, skbytes, side_stream);
-                if (rc) return rc;
-                rc = ggpm_gemm(1, 0, H, H, K1, DZP + (size_t)(t - 1) * slot, Hp, Ss + (size_t)(t - 1) * slot, Hp, dWz_h,
-                               ld_dwz, H, nullptr, acc, GGPM_ACT_NONE, 0, skws, skbytes, side_stream);
-                if (rc) return rc;
-                // dq^u pairs with h^u for u in [max(t,1), min(t_hi, depth-1)]
-                const int u_lo = t, u_hi = t_hi < depth ? t_hi : depth - 1;
-                if (u_hi >= u_lo) {
-                    rc = ggpm_gemm(1, 0, H, H, (u_hi - u_lo + 1) * E1, DQ + (size_t)u_lo * slot, Hp, Hs + (size_t)u_lo * slot,
-                                   Hp, dUr, ld_dur, H, nullptr, dur_started ? 1 : 0, GGPM_ACT_NONE, 0, skws, skbytes,
-                                   side_stream);
-                    if (rc) return rc;
-                    dur_started = true;
-                }
-                first_chunk = false;
-            }
-        }
     }
     GGPM_CHECK_LAUNCH();
-    if (side_stream && !frozen) {
-        hipStream_t ss = (hipStream_t)side_stream;
-        if (depth > 1) {
-            int rc = ggpm_colsum(DQ + slot, Hp, (depth - 1) * E1, H, dbu, csws, side_stream);
-            if (rc) return rc;
-        } else {
-            for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), ss);
-            (void)hipMemsetAsync(dbu, 0, H * sizeof(float), ss);
-        }
-        GGPM_CHECK_LAUNCH();
-        return GGPM_OK;
-    }
 
     if (frozen) {      // gradient of the incoming state: one more gather + dq.U_r launch at t = 0
         GruBwdArgs a = {};
@@ -1288,24 +1229,7 @@ extern "C" int ggpm_gru_backward_tab(int E1, int H, int depth, const float* Xr, 
                                      ggpm_stream_t stream) {
     return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
                              succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
-                             dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream, nullptr, succ_tab);
-}
-
-// As ggpm_gru_backward with weight_grads = 0, but the h-half weight gradients (dWz_h, dUr, dbu, dWh_h) are issued on
-// `side_stream` in chunks of depths WHILE the depth loop still runs on `stream` (event-ordered), instead of after it.
-extern "C" int ggpm_gru_backward_overlapped(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
-                                            const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
-                                            const int32_t* pred_rowptr, const int32_t* pred_col,
-                                            const int32_t* succ_rowptr, const int32_t* succ_col, const float* Hs,
-                                            const float* Qs, const float* Ss, const float* Gs, const float* Zs,
-                                            const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr,
-                                            float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
-                                            float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
-                                            ggpm_stream_t stream, ggpm_stream_t side_stream) {
-    if (!side_stream) return GGPM_ERR_ARG;
-    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
-                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
-                             dWh_h, ld_dwh, work, work_bytes, 0, nullptr, nullptr, stream, side_stream);
+                             dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream, succ_tab);
 }
 
 // sparse_forward backward: additionally returns dHin (gradient of the incoming state; zero on the recomputed rows)

@@ -640,18 +640,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     }
 }
 
-// Raise the dynamic-LDS limit of a kernel once per (kernel, size) instead of once per launch: the attribute call
-// costs host microseconds and a level issues ~40 launches per direction.  (A benign race between autograd
-// threads at worst repeats the call.)
 template <typename K>
-inline void set_lds(K kernel, size_t bytes) {
-    static size_t have = 0;            // one static per kernel instantiation
-    if (bytes > have) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bytes);
-        have = bytes;
-    }
-}
+inline void set_lds(K kernel, size_t bytes) { ggpm_set_lds(kernel, bytes); }      // (common.h)
 
 inline size_t lds_tiles(int n, int Hp, int rows = ROWS) { return (size_t)n * rows * (Hp + 4) * sizeof(float); }
 // ggpm_level_prefer_narrow (mpn_gru.hip, common.h): two row tiles per workgroup for the dense fp32 level calls of this thread
@@ -661,13 +651,13 @@ inline bool use_rt2(int Hp, bool sparse, int bf16) {
 
 // Environment switches are read once: getenv walks the whole environment (~0.5 us) and the launch helpers below run
 // ~120 times per training step.
-inline bool env_no_fuse_b() { static const bool v = getenv("GGPM_NO_FUSE_B") != nullptr; return v; }
-inline bool env_adebug() { static const bool v = getenv("GGPM_ADEBUG") != nullptr; return v; }
+inline bool env_no_fuse_b() { static const bool v = ggpm_dev_env("GGPM_NO_FUSE_B") != nullptr; return v; }
+inline bool env_adebug() { static const bool v = ggpm_dev_env("GGPM_ADEBUG") != nullptr; return v; }
 
 inline int pick_tg(int E1, int NT) {
-    static const char* const tg_env = getenv("GGPM_TG");
+    static const char* const tg_env = ggpm_dev_env("GGPM_TG");
     if (const char* e = tg_env) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning override
-    static const char* const tg_large_env = getenv("GGPM_TG_LARGE");
+    static const char* const tg_large_env = ggpm_dev_env("GGPM_TG_LARGE");
     if (const char* e = tg_large_env) {      // tuning override for the large (atom) levels only
         int v = atoi(e);
         if (v >= 1 && v <= 64 && (E1 + 15) / 16 > 64) return v < NT ? v : NT;
@@ -680,7 +670,7 @@ inline int pick_tg(int E1, int NT) {
 inline int gate_mode(int dtype, int Hp, bool rt2, bool single_group, bool sparse) {
     if (dtype == 1) return 1;
     if (dtype == 2) return 0;
-    static const bool on = [] { const char* e = getenv("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char* e = ggpm_dev_env("GGPM_GATE_SPLIT"); return !e || atoi(e) != 0; }();
     if (!on || rt2) return 0;
     if (dtype != 3 && (!single_group || sparse)) return 0;
     // kernel A of the backward: two fp32 tiles + the dqf image; kernel B of the backward: three gate-gradient images

@@ -24,6 +24,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include "../../include/ggpm_hip.h"
+#ifdef GGPM_DEV_SWITCHES      // (host-only file: no common.h)
+static inline const char* ggpm_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* ggpm_dev_env(const char*) { return nullptr; }
+#endif
 
 namespace {
 
@@ -124,7 +129,7 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         if (!ok) return nullptr;
     }
     Sched* S = new Sched();
-    static const bool dbg = getenv("GGPM_SCHED_DEBUG") != nullptr;
+    static const bool dbg = ggpm_dev_env("GGPM_SCHED_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_begin = now();
     auto lap = [&](const char* what) {

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from . import _dev
 from . import functional as F_
 from . import inc_encoder as IE
 from .decoder_heads import ScoreHeads, bce_with_logits_sum, cross_entropy_sum
@@ -128,8 +129,7 @@ class DecodeSchedule:
         prepare the tables that depend on them as well; ``native=False`` forces the numpy builder (the checker)."""
         from . import schedule_native as SN
         if native is None:
-            native = SN.enabled() and all(os.environ.get(k, "1") != "0" for k in
-                                          ("GGPM_DECODER_BATCHED", "GGPM_ATOM_DECODE", "GGPM_ATOM_COMPACT"))
+            native = SN.enabled() and _dev.DECODER_BATCHED and _dev.ATOM_DECODE and _dev.ATOM_COMPACT
         if native:
             nt = SN.build_tables(tensors, orders, inter_icls, assm_cands, depth or 0, gates or 0)
             if nt is not None:
@@ -506,7 +506,7 @@ class HierMPNDecoder(ScoreHeads):
             init_vecs = src_root_vecs
         else:
             init_vecs = F_.linear([src_root_vecs.contiguous()], [L], self.W_root.weight, self.W_root.bias)[:, :H]
-        if os.environ.get("GGPM_DECODER_BATCHED", "1") != "0" and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
+        if _dev.DECODER_BATCHED and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_batched(schedule, D, tree_tensors, graph_tensors,
                                                                             init_vecs)
         else:
@@ -571,13 +571,12 @@ class HierMPNDecoder(ScoreHeads):
     # molecule's own bonds and the decoder's parameters only.  ``start_atom_level`` therefore issues it on its own stream
     # BEFORE the encoder runs (HierPropertyVAE.forward), so that two chains of small latency-bound launches share the GPU
     # instead of queueing behind each other; autograd runs a node's backward on the stream of its forward, so the backward
-    # overlaps the encoder's backward the same way.  GGPM_ATOM_AHEAD=0 switches it off.
+    # overlaps the encoder's backward the same way.  _dev.ATOM_AHEAD = False switches it off.
     _ATOM_STREAMS = {}
 
     def start_atom_level(self, schedule, tensors) -> bool:
         self._atom_ahead = None
-        if (schedule is None or os.environ.get("GGPM_ATOM_AHEAD", "1") == "0" or os.environ.get("GGPM_ATOM_DECODE", "1") == "0"
-                or os.environ.get("GGPM_DECODER_BATCHED", "1") == "0"):
+        if schedule is None or not (_dev.ATOM_AHEAD and _dev.ATOM_DECODE and _dev.DECODER_BATCHED):
             return False
         tree_tensors, graph_tensors = tensors
         dev = tree_tensors[0].device
@@ -591,8 +590,8 @@ class HierMPNDecoder(ScoreHeads):
         side = self._ATOM_STREAMS.get(dev.index)
         if side is None:
             # high priority: this chain of small dependent launches is the step's critical path, the encoder beside it
-            # has slack -- where both have a kernel waiting for CUs, this one goes first (GGPM_ATOM_PRIORITY=0: default)
-            prio = -1 if os.environ.get("GGPM_ATOM_PRIORITY", "1") != "0" else 0
+            # has slack -- where both have a kernel waiting for CUs, this one goes first (_dev.ATOM_PRIORITY = False: default priority)
+            prio = -1 if _dev.ATOM_PRIORITY else 0
             side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=prio)
         side.wait_stream(main)
         from .atom_decode import compact_enabled
@@ -633,7 +632,7 @@ class HierMPNDecoder(ScoreHeads):
         pooled, assm_vecs, assm_dest = [], [], []
         off, aoff, boff = P["inst_off"], P["atom_off"], P["bond_off"]
         ahead, self._atom_ahead = getattr(self, "_atom_ahead", None), None
-        ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if os.environ.get("GGPM_ATOM_DECODE", "1") != "0" else None
+        ap = schedule.atom_plan(n_gnodes, graph_tensors[1].size(0)) if _dev.ATOM_DECODE else None
         if ap is not None and ap.ok:                        # ---- atom level as ONE autograd node (atom_decode.py)
             if ahead is not None and ahead[0] is schedule:  # issued before the encoder on its own stream: join it here
                 _, pooled_all, cand, side, finish, pre = ahead

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _dev, _lib
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -152,7 +152,7 @@ def upload(a, device) -> torch.Tensor:
     return _STAGING.upload(a, device)
 
 
-_MEMO_ON = os.environ.get("GGPM_INDEX_MEMO", "1") != "0"
+_MEMO_ON = _dev.INDEX_MEMO
 
 
 def _memo_get(t: torch.Tensor, slot: str, key):
@@ -483,12 +483,6 @@ def embed_graph(fnode: torch.Tensor, fmess: torch.Tensor, atom_size: int, bond_t
 _SIDE = {}
 
 
-def wgrad_overlap_enabled() -> bool:
-    """GGPM_WGRAD_OVERLAP=1 (opt-in): weight-gradient contractions start while the level's backward depth loop still
-    runs.  Off by default: the contractions already hide behind the NEXT level's loop and the extra events cost host time."""
-    return os.environ.get("GGPM_WGRAD_OVERLAP", "0") != "0"
-
-
 def side_stream_enabled() -> bool:
     import os
     return os.environ.get("GGPM_SIDE_STREAM", "1") != "0"
@@ -508,8 +502,8 @@ def _side_stream(device) -> torch.cuda.Stream:
 # tools/probe/free_stall_probe.py).  The mark is not needed here: a published gradient stays referenced by ``param.grad``
 # until the optimizer side releases it, i.e. after everything that reads it has been ENQUEUED on the main stream, and every
 # helper stream of this package waits for the main stream (``wait_stream(main)``) before the first allocation of its next use
-# -- the block cannot be handed out again in front of its readers.  GGPM_RECORD_GRADS=1 restores the marks.
-_RECORD_GRADS = os.environ.get("GGPM_RECORD_GRADS", "0") == "1"
+# -- the block cannot be handed out again in front of its readers.  _dev.RECORD_GRADS restores the marks.
+_RECORD_GRADS = _dev.RECORD_GRADS
 
 
 def hand_to(g: torch.Tensor, main: torch.cuda.Stream) -> None:
@@ -562,12 +556,31 @@ def _has_hooks(p) -> bool:
     return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
 
+_PUBLISH = [True]
+
+
+def publish_gradients(enabled: bool) -> bool:
+    """Process-wide switch for gradients written to ``.grad`` by this package itself (deferred contractions, second
+    stream, flat gradient buffer) instead of being returned through autograd.  -> the previous setting.
+
+    Switch it OFF before wrapping a model in ``torch.nn.parallel.DistributedDataParallel`` or anything else that hooks the
+    AccumulateGrad NODE of a parameter: such hooks live in the C++ node and cannot be seen from Python (``can_publish``
+    only sees ``Tensor.register_hook`` and ``register_post_accumulate_grad_hook``), and a reducer whose hook never fires
+    waits for a gradient that was written around it.  The data-parallel path this package supports and measures is
+    ``ggpm_amd.parallel.FlatGradSync`` (one all-reduce of one flat buffer), which needs no hooks."""
+    prev, _PUBLISH[0] = _PUBLISH[0], bool(enabled)
+    return prev
+
+
 def can_publish(*params) -> bool:
     """True when the gradients of these parameters may be written to ``.grad`` by this module itself (deferred
-    contraction / second stream) instead of being returned through autograd: leaves that require grad and carry NO
-    hooks.  A parameter with a tensor hook or a post-accumulate-grad hook (stock DDP, hook-based clippers / reducers)
-    gets its gradient the ordinary way, through AccumulateGrad, so that the hooks fire."""
-    return all(p is None or (getattr(p, "is_leaf", False) and p.requires_grad and not _has_hooks(p)) for p in params)
+    contraction / second stream) instead of being returned through autograd: publishing is on (``publish_gradients``)
+    and every parameter is a leaf that requires grad and carries NO Python-visible hook.  A parameter with a tensor hook
+    or a post-accumulate-grad hook (hook-based clippers / reducers) gets its gradient the ordinary way, through
+    AccumulateGrad, so that the hooks fire.  Hooks on the AccumulateGrad node itself (stock DDP's reducer) are not visible
+    here: see ``publish_gradients``."""
+    return _PUBLISH[0] and all(p is None or (getattr(p, "is_leaf", False) and p.requires_grad and not _has_hooks(p))
+                               for p in params)
 
 
 def _defer_register() -> None:
@@ -687,8 +700,8 @@ def flush_deferred_early() -> None:
     """Called from inside a backward pass at a point after which only nodes WITHOUT deferred gradients have much left to
     do (the decoder's atom level and the encoder, once the heads and the tree-side levels have run): the queued
     contractions start now on the second stream, beside that work, instead of behind it.  Whatever is queued later still
-    goes through the end-of-backward flush.  GGPM_DEFER_EARLY=0 switches it off."""
-    if os.environ.get("GGPM_DEFER_EARLY", "1") == "0" or not side_stream_enabled():
+    goes through the end-of-backward flush.  _dev.DEFER_EARLY = False switches it off."""
+    if not _dev.DEFER_EARLY or not side_stream_enabled():
         return
     main = _DEFER["stream"]
     if main is None or _DEFER["task"] is None or _DEFER["task"] != torch._C._current_graph_task_id():
@@ -768,29 +781,13 @@ class _GruLevel(torch.autograd.Function):
         wb = int(lib.ggpm_gru_backward_workspace_bytes(E1, H, depth))
         work = torch.empty((wb + 3) // 4, **f32)
         use_side = side_stream_enabled() and can_publish(*ctx.params)
-        overlapped = use_side and wgrad_overlap_enabled()
-        if overlapped:
-            # the h-half weight gradients run on the second stream in chunks of depths WHILE this level's depth
-            # loop is still going (the loop is latency bound and leaves most of the chip idle)
-            main = torch.cuda.current_stream()
-            side = _side_stream(x.device)
-            side.wait_stream(main)
-            for tns in (work, Hs, Ss, dW_z, dU_r, dW_h, db_u):
-                tns.record_stream(side)
-            _lib.check(lib.ggpm_gru_backward_overlapped(
-                E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0), _p(Wh_h), W_h.stride(0),
-                _p(pred.rowptr), _p(pred.col), _p(succ.rowptr), _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs),
-                _p(Ms), _p(Rs), _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0), _p(dU_r), H,
-                _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work), work.numel() * 4, _stream(),
-                ctypes.c_void_p(side.cuda_stream)), "gru_backward_overlapped")
-        else:
-            with _gate_dtype(ctx.gate_dtype):
-                _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
-                                                 _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
-                                                 _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
-                                                 _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0),
-                                                 _p(dU_r), H, _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work),
-                                                 work.numel() * 4, 0 if use_side else 1, _stream()), "gru_backward")
+        with _gate_dtype(ctx.gate_dtype):
+            _lib.check(lib.ggpm_gru_backward(E1, H, depth, _p(Xr), _p(Wz_h), W_z.stride(0), _p(U_r), U_r.stride(0),
+                                             _p(Wh_h), W_h.stride(0), _p(pred.rowptr), _p(pred.col), _p(succ.rowptr),
+                                             _p(succ.col), _p(Hs), _p(Qs), _p(Ss), _p(Gs), _p(Zs), _p(Ms), _p(Rs),
+                                             _p(dHD), _p(dX[0]), _p(dX[1]), _p(dX[2]), _p(dWz_h), dW_z.stride(0),
+                                             _p(dU_r), H, _p(db_u), _p(dWh_h), dW_h.stride(0), _p(work),
+                                             work.numel() * 4, 0 if use_side else 1, _stream()), "gru_backward")
         ctx.stash = None
         ldx = _ld(x)
         dx = None
@@ -801,7 +798,7 @@ class _GruLevel(torch.autograd.Function):
             gemm(0, 0, E1, I, H, dX[2], Hp, Wh_x, W_h.stride(0), dx, ldx, I, accumulate=True)
 
         def weight_grads():
-            if use_side and not overlapped:
+            if use_side:
                 with _gate_dtype(ctx.gate_dtype):
                     _lib.check(lib.ggpm_gru_weight_grads(E1, H, depth, _p(Hs), _p(Ss), _p(Gs), _p(work), work.numel() * 4,
                                                          _p(dWz_h), dW_z.stride(0), _p(dU_r), H, _p(db_u), _p(dWh_h),

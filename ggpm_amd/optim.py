@@ -13,6 +13,8 @@ import os
 
 import torch
 
+from . import _dev
+
 
 class FlatAdam:
     def __init__(self, sync, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
@@ -30,7 +32,7 @@ class FlatAdam:
         self.opt = torch.optim.Adam([self.flat], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=flat.is_cuda)
         # on the GPU the step is ONE launch of ggpm_adam_step over the flat buffer (torch's fused Adam issues three
         # multi-tensor launches for it); learning-rate schedulers keep working through ``param_groups``
-        self._hip = flat.is_cuda and os.environ.get("GGPM_HIP_ADAM", "1") != "0"
+        self._hip = flat.is_cuda and _dev.HIP_ADAM
         if self._hip:
             self._m, self._v, self._t = torch.zeros_like(flat), torch.zeros_like(flat), 0
 

@@ -17,6 +17,8 @@ from typing import Iterable, List, Sequence
 import torch
 import torch.distributed as dist
 
+from . import _dev
+
 
 def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     """Round-robin shard of item (batch) indices: rank r takes r, r+W, r+2W, ..."""
@@ -49,7 +51,7 @@ class FlatGradSync:
                 uniq.append(p)
         self.encoder_params, self.early_numel = [], 0
         self.bucketed = os.environ.get("GGPM_BUCKETED_ALLREDUCE", "0") != "0"
-        if encoder is not None and os.environ.get("GGPM_GRAD_SINK", "1") != "0":
+        if encoder is not None and _dev.GRAD_SINK:
             from . import fused
             from .rnn import LSTM
             named = dict(encoder.named_parameters())

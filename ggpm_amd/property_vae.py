@@ -11,6 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import _dev
 from . import functional as F_
 from .encoder import HierMPNEncoder
 from .nnutils import make_cuda
@@ -161,7 +162,7 @@ class StepMetrics(dict):
         self._dev = torch.stack([v if v is not None else torch.zeros((), device=dev) for v in vals]) if dev is not None else None
         self._ready = False
         self._host = self._event = None
-        if self._dev is not None and self._dev.is_cuda and os.environ.get("GGPM_METRICS_ASYNC", "1") != "0":
+        if self._dev is not None and self._dev.is_cuda and _dev.METRICS_ASYNC:
             # the copy to the host is ENQUEUED here, behind the forward; a reader waits for this event only -- not for
             # whatever the stream has been given since (backward, optimizer), so the loop can go on to the next batch
             # while the step's tail still runs, as it does around the reference's .item() calls
@@ -255,7 +256,7 @@ class HierPropertyVAE(nn.Module):
         # beside the atom level's chain of small launches the encoder's levels take half as many (twice as large)
         # workgroups: the chain's launches then find free compute units instead of waiting for the encoder's to drain
         from . import fused
-        beside = getattr(self.decoder, "_atom_ahead", None) is not None and os.environ.get("GGPM_ENC_NARROW", "1") != "0"
+        beside = getattr(self.decoder, "_atom_ahead", None) is not None and _dev.ENC_NARROW
         fused.NARROW[0] = beside
         try:
             root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]

@@ -27,14 +27,14 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _dev, _lib
 from . import functional as F_
 
 MAX_POS = 20
 
 
 def enabled() -> bool:
-    return os.environ.get("GGPM_TREE_COMPOSITE", "1") != "0"
+    return _dev.TREE_COMPOSITE
 
 
 class LevelSpec:

@@ -214,16 +214,6 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
                       int weight_grads, ggpm_stream_t stream);
 /* The weight-gradient tail of ggpm_gru_backward (called with weight_grads = 0) as its own entry point, so the
  * host may enqueue it on a second stream beside the next level's depth loop. Same `work` buffer. */
-/* ggpm_gru_backward (weight_grads = 0) with the h-half weight gradients issued on `side_stream` in chunks of depths
- * while the depth loop still runs on `stream` (event-ordered); afterwards `side_stream` holds dWz_h, dUr, dbu, dWh_h. */
-int ggpm_gru_backward_overlapped(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
-                                 const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
-                                 const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* succ_rowptr,
-                                 const int32_t* succ_col, const float* Hs, const float* Qs, const float* Ss,
-                                 const float* Gs, const float* Zs, const float* Ms, const float* Rs, const float* dHD,
-                                 float* dXz, float* dXr, float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur,
-                                 float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
-                                 ggpm_stream_t stream, ggpm_stream_t side_stream);
 /* ggpm_gru_forward / ggpm_gru_backward with optional neighbour tables (ggpm_csr_table4 of the predecessor resp.
  * successor CSR; null = walk the CSR as the plain entry points do). */
 int ggpm_gru_forward_tab(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh, const float* Wz_h,

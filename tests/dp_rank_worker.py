@@ -153,8 +153,9 @@ def main():
         # ---- two backwards per step: sink path vs the path without the sink
         os.environ["GGPM_BUCKETED_ALLREDUCE"] = "0"
         grads = {}
+        from ggpm_amd import _dev as dev_settings
         for sink in ("1", "0"):
-            os.environ["GGPM_GRAD_SINK"] = sink
+            dev_settings.GRAD_SINK = sink == "1"
             torch.manual_seed(0)
             model = HierEncoderVAE(bench.make_args(rnn, 100, 5, 16, 50, 150)).cuda()
             broadcast_parameters(model)
@@ -165,7 +166,7 @@ def main():
             loss_of(model, batches[1]).backward()
             sync.all_reduce()
             grads[sink] = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
-        os.environ.pop("GGPM_GRAD_SINK")
+        dev_settings.GRAD_SINK = True
         scale = float(grads["0"].abs().max())
         d = float((grads["1"] - grads["0"]).abs().max())
         assert d <= 2e-6 * scale, (d, scale)

@@ -1149,8 +1149,16 @@ def _vae_names():
     return vae_case_names()
 
 
-@pytest.mark.parametrize("mode", ["batched", "batched_inline", "batched_pyloop", "batched_full", "levels", "stepwise"])
-@pytest.mark.parametrize("name", _vae_names())
+def _vae_mode_cases():
+    """The default form of the device loop on every reference fixture; the alternative forms (ggpm_amd/_dev.py) on the first
+    GRU and the first LSTM fixture."""
+    names = _vae_names()
+    picked = [next((n for n in names if cell in n), None) for cell in ("gru", "lstm")]
+    others = ["batched_inline", "batched_pyloop", "batched_full", "levels", "stepwise"]
+    return [(n, "batched") for n in names] + [(n, m) for n in picked if n for m in others]
+
+
+@pytest.mark.parametrize("name,mode", _vae_mode_cases())
 def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     """The full VAE training step -- HierPropertyVAE.forward (ggpm/property_vae.py:47-62): encoder, rsample, the
     teacher-forced HierMPNDecoder.forward with enum_attach and the four losses (ggpm/decoder.py:166-301) -- and its
@@ -1162,10 +1170,11 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     issued on its own stream ahead of the encoder; ``batched_inline`` keeps it in program order, ``batched_pyloop``
     additionally issues the step loops from Python instead of through ggpm_decode_steps_*, ``batched_full`` runs
     its steps over all rows of the level instead of compact row sets)."""
-    monkeypatch.setenv("GGPM_DECODER_BATCHED", "0" if mode == "stepwise" else "1")
-    monkeypatch.setenv("GGPM_ATOM_DECODE", "1" if mode.startswith("batched") else "0")
-    monkeypatch.setenv("GGPM_ATOM_COMPACT", "0" if mode == "batched_full" else "1")     # compact row sets per decode step
-    monkeypatch.setenv("GGPM_ATOM_AHEAD", "1" if mode == "batched" else "0")
+    from ggpm_amd import _dev as dev_settings
+    monkeypatch.setattr(dev_settings, "DECODER_BATCHED", mode != "stepwise")
+    monkeypatch.setattr(dev_settings, "ATOM_DECODE", mode.startswith("batched"))
+    monkeypatch.setattr(dev_settings, "ATOM_COMPACT", mode != "batched_full")     # compact row sets per decode step
+    monkeypatch.setattr(dev_settings, "ATOM_AHEAD", mode == "batched")
     if mode == "batched_pyloop":        # the decode step loops issued from Python instead of csrc/decode.hip
         import ggpm_amd.atom_decode as _ad
         monkeypatch.setattr(_ad, "_DRIVER", False)

@@ -178,9 +178,10 @@ def test_metrics_read_through_the_event_equal_the_blocking_read(monkeypatch):
     _init_like_vae_train(model)
     batch = synth.train_batch(synth.random_batch(21, 6, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120))
     got = []
-    for lazy, asyn in (("1", "1"), ("1", "0"), ("0", "0")):
+    from ggpm_amd import _dev as dev_settings
+    for lazy, asyn in (("1", True), ("1", False), ("0", False)):
         monkeypatch.setenv("GGPM_LAZY_METRICS", lazy)
-        monkeypatch.setenv("GGPM_METRICS_ASYNC", asyn)
+        monkeypatch.setattr(dev_settings, "METRICS_ASYNC", asyn)
         loss, m = model(*batch, beta=0.3, perturb_z=False)
         loss.backward()
         model.zero_grad()

@@ -112,8 +112,9 @@ def test_deferred_gradients_survive_a_failed_backward(fake_streams):
 
 
 def test_parameters_with_hooks_are_not_published_behind_autograd():
-    """a parameter with a tensor hook / post-accumulate-grad hook (stock DDP, hook-based clippers) must get
-    its gradient through AccumulateGrad so that the hooks fire."""
+    """A parameter with a tensor hook / post-accumulate-grad hook (hook-based clippers, reducers) must get its gradient
+    through AccumulateGrad so that the hooks fire.  Hooks on the AccumulateGrad NODE (stock DDP's reducer) cannot be seen
+    from Python: for those the whole mechanism is switched off with ``publish_gradients(False)``."""
     p = torch.nn.Parameter(torch.ones(2))
     q = torch.nn.Parameter(torch.ones(2))
     assert F_.can_publish(p, q, None)
@@ -127,6 +128,18 @@ def test_parameters_with_hooks_are_not_published_behind_autograd():
     frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
     assert not F_.can_publish(frozen)
     assert not F_.can_publish(p * 2)                               # not a leaf
+    # a hook on the accumulate node (what stock DDP registers) is invisible ...
+    acc = p.expand_as(p).grad_fn.next_functions[0][0]
+    h = acc.register_hook(lambda *a: None)
+    assert F_.can_publish(p)
+    # ... hence the process-wide switch
+    assert F_.publish_gradients(False) is True
+    try:
+        assert not F_.can_publish(p) and not F_.can_publish(p, q, None)
+    finally:
+        assert F_.publish_gradients(True) is False
+    assert F_.can_publish(p)
+    h.remove()
 
 
 def test_deferred_linear_is_keyed_by_its_column_split(fake_streams):
