@@ -288,13 +288,18 @@ class Workload:
         a, cfg = self.a, self.cfg
         H, depth, batch = cfg["hidden"], cfg["depth"], cfg["batch"]
         log("%s: model + %d batches resident; warm-up" % (self.rnn, len(self.dev_batches)))
-        for i in range(a.warmup):
+        # W untimed steps, and at least one pass over the pool: every batch shape has then been seen by the caching allocator,
+        # on each of the package's streams -- a shape met for the first time inside the timed region costs a device allocation
+        # there (measured with tools/step_jitter.py: 5 ms at configs[1] sizes, 250-300 ms at configs[4] sizes, in ONE step)
+        warm = max(a.warmup, len(self.dev_batches))
+        self.warmup_run = warm
+        for i in range(warm):
             self.step(i)
             if i == 0:
                 torch.cuda.synchronize()
                 log("first step done")
-        log("warm-up done; timing %d steps" % a.steps)
-        elapsed, host_enqueue = self.timed(a.steps, a.warmup)
+        log("warm-up done (%d steps); timing %d steps" % (warm, a.steps))
+        elapsed, host_enqueue = self.timed(a.steps, warm)
         log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,
                                                                              1e3 * host_enqueue / a.steps))
         chains = [int(getattr(t[0][3], "ggpm_chain", 0)) for t in self.dev_batches]
@@ -305,16 +310,16 @@ class Workload:
         if self.host_iter is None and not a.no_full_depth and any(chains):
             hinted = self.dev_batches
             self.dev_batches = [(list(tree[:3]) + [tree[3].view_as(tree[3])] + list(tree[4:]), graph) for tree, graph in hinted]
-            for i in range(min(a.warmup, 4)):
+            for i in range(max(min(a.warmup, 4), min(len(self.dev_batches), 4))):
                 self.step(i)
-            full_elapsed, _ = self.timed(a.steps, a.warmup)
+            full_elapsed, _ = self.timed(a.steps, warm)
             self.dev_batches = hinted
             log("without the tree fixed-point hint: %.3f ms/step" % (1e3 * full_elapsed / a.steps))
         gates = 3 if self.rnn == "GRU" else 4
         fl_full, fl_exec, atoms = algorithmic_work(self.pool, H, depth, gates, chains)
         mols = a.steps * batch * self.world
         res = {"ms_per_step": round(1e3 * elapsed / a.steps, 4), "value": round(mols / elapsed, 2),
-               "unit": "molecules/s", "rnn_type": self.rnn,
+               "unit": "molecules/s", "rnn_type": self.rnn, "warmup_steps_run": warm,
                "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 4),
                "algorithmic_gflop_per_step_per_gpu": round(fl_full / 1e9, 2),
                "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
@@ -697,14 +702,13 @@ def configs4_leg(a, lib, dev, budget_s=90.0):
                            % (time.time() - _T0, budget_s)}
     cfg = dict(CONFIGS[4])
     b = copy.copy(a)
-    b.pool, b.steps, b.warmup, b.no_full_depth, b.host_input = 2, min(a.steps, 6), 3, True, False
+    b.pool, b.steps, b.warmup, b.no_full_depth, b.host_input = 2, min(a.steps, 6), 8, True, False
     out = {"workload": "BASELINE %s: hidden=%d depth=%d batch=%d, %s cell, %d timed steps on a pool of %d batches"
                        % (cfg["tag"], cfg["hidden"], cfg["depth"], cfg["batch"], cfg["rnn"], b.steps, b.pool)}
     try:
         for key, dt in (("fp32", "f32"), ("bf16", "bf16")):
             gc.unfreeze()
             gc.collect()
-            torch.cuda.empty_cache()
             wl = Workload(cfg, cfg["rnn"], b, 0, 1, dev, gate_dtype=dt)
             m = wl.measure(lib, 0)
             leg = {k: m[k] for k in ("ms_per_step", "value", "unit", "step_tflops_executed", "atoms_per_molecule") if k in m}
@@ -855,7 +859,8 @@ def main():
         "metric": "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32) -- HierMPNEncoder fwd+bwd target row "
                   "(encoder + KL heads + optimizer)",
         "value": m["value"], "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
+        "warmup": a.warmup, "warmup_steps_run": m.get("warmup_steps_run", a.warmup), "ms_per_step": m["ms_per_step"],
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic" + (" (host-resident batches, PCIe-inclusive diagnostic)" if a.host_input else ""),
         "config": {"workload": "BASELINE %s: %.1f atoms/molecule, motif vocab %d/%d, hidden=%d depth=%d latent=%d "
@@ -889,8 +894,7 @@ def main():
     cpu_runs = [(rnn, main_wl.pool)]
     # the other message function on the same workload, in the same line (all 32 shipped model configs use LSTM)
     if a.config == 1 and a.rnn is None and not a.no_second_cell and not a.host_input:
-        del main_wl
-        torch.cuda.empty_cache()
+        del main_wl      # (no empty_cache(): 288 GB of HBM leave nothing to make room for, and cached blocks spare device allocations)
         other = Workload(cfg, "LSTM", a, rank, world, dev)
         mo = other.measure(lib, rank)
         result["lstm"] = {k: mo[k] for k in ("ms_per_step", "value", "unit", "host_enqueue_ms_per_step",
@@ -901,7 +905,6 @@ def main():
     # configs[4] names bf16: the same workload with bf16 gate products, in the same line
     if a.config == 4 and a.dtype == "f32" and not a.no_second_cell and not a.host_input:
         del main_wl
-        torch.cuda.empty_cache()
         other = Workload(cfg, rnn, a, rank, world, dev, gate_dtype="bf16")
         mo = other.measure(lib, rank)
         result["bf16"] = {k: mo[k] for k in ("ms_per_step", "value", "unit", "host_enqueue_ms_per_step",
@@ -918,7 +921,6 @@ def main():
             import gc
             gc.unfreeze()
             gc.collect()
-            torch.cuda.empty_cache()
             vae = VaeWorkload(cfg, rnn, a, dev, rank, world)
             result["vae_step"] = vae.measure()
             if a.rnn is None and not a.no_second_cell:          # the LSTM leg of the same row

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ggpm_onehot": (I, [P, I, I, P, I, I, I, P]),
     "ggpm_embed_graph": (I, [P, I, P, I, I, I, I, P, I, P, I, P]),
     "ggpm_level_gate_dtype": (I, [I]),
+    "ggpm_level_bf16_storage": (I, [I, I]),
     "ggpm_backward_skip_x_sums": (None, [I]),
     "ggpm_gru_backward_stashes": (I, [P, I, I, I, POINTER(c_void_p), POINTER(c_void_p)]),
     "ggpm_lstm_backward_stashes": (I, [P, I, I, I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),

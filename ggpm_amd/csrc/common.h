@@ -106,7 +106,8 @@ __device__ __forceinline__ void ggpm_lds_barrier() {
 bool ggpm_gemm_prefers_grouped(int M, int N, int K, int count);
 // `count` (<= 4) tall contractions C_i = A_i^T B_i of one output shape (K_i may differ) in one launch + one reduce;
 // falls back to sequential ggpm_gemm calls when a member does not qualify for the tall kernel
-// bf16 != 0: operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate (gemm_tn_tall_bf16)
+// bf16 == 1: operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate (gemm_tn_tall_bf16); bf16 == 2: the
+// operands ARE bf16 in memory (lda / ldb in elements; the group must qualify for the tall kernel: GGPM_ERR_UNSUPPORTED if not)
 int ggpm_gemm_tall_grouped(int M, int N, int count, const ggpm_gemm_problem* p, const int* K, float* ws, size_t ws_bytes,
                            ggpm_stream_t stream, int bf16 = 0);
 #define GGPM_GEMM_MAX_GROUP 4          // members of ggpm_gemm_grouped / segments of ggpm_gemm_ksegments
@@ -144,6 +145,15 @@ bool ggpm_take_scatter_state(float** dst_h, float** dst_c, const int32_t** idx);
 // drivers from ggpm_enc_dims.gate_dtype for the duration of their call (mpn_gru.hip).
 void ggpm_set_gate_dtype(int dtype);
 int ggpm_gate_dtype();
+
+// Levels whose depth-loop arrays are kept in bf16 under gate mode 1 (tile_mma.h: "bf16 STORAGE"): dense training levels large
+// enough that every weight-gradient contraction over their stashes runs on the bf16 tall kernel, which then reads the
+// stashes as they are.  (GRU levels; exported as ggpm_level_bf16_storage for the tests' choice of oracle mode.)
+bool ggpm_bf16_storage_applies(int E1, int H);       // (gemm.hip: one stash slot alone must qualify for the bf16 tall kernel)
+// out[i] = sum_t src[t][i] over `slots` slots of `slot_floats` elements, src fp32 or bf16 (first half of its buffer); fixed order
+int ggpm_sum_slots_any(const float* src, int slots, size_t slot_floats, float* out, bool src_bf16, ggpm_stream_t stream);
+// column sums of a [rows, ld] fp32 or bf16 matrix (losses.hip / gemm.hip: ggpm_colsum is the fp32 entry point)
+int ggpm_colsum_any(const float* A, int lda, int rows, int cols, float* out, float* scratch, bool a_bf16, ggpm_stream_t stream);
 
 // Optional per-launch timing (bench.py roofline): implemented in capi.hip.
 void ggpm_timing_tag(int tag);       // 1 atom, 2 attachment, 3 motif level, 0 untagged; collected as which + 8 * tag

@@ -289,17 +289,20 @@ __global__ void __launch_bounds__(256) replicate_slots_k(ReplicateArgs r) {
 }
 
 // steps a tree-side level really has to run: chain + 1 (the step after the last change also fixes the stash)
-inline int run_steps(const Dims& d, int level, int depth) {
+// (a level whose depth-loop arrays are kept in bf16 -- gate mode 1 on >= 6144 messages, tile_mma.h -- runs all its steps: the
+// replication below copies fp32 slots)
+inline bool bf16_stored(const Dims& d, int E1) { return d.gate_dtype == 1 && !d.lstm && ggpm_bf16_storage_applies(E1, d.H); }
+inline int run_steps(const Dims& d, int level, int depth, int E1) {
     static const bool off = ggpm_dev_env("GGPM_TREE_FIXED_POINT") && atoi(ggpm_dev_env("GGPM_TREE_FIXED_POINT")) == 0;
-    if (off || level == 2 || d.tree_chain <= 0 || d.tree_chain + 1 >= depth) return depth;
+    if (off || level == 2 || bf16_stored(d, E1) || d.tree_chain <= 0 || d.tree_chain + 1 >= depth) return depth;
     return d.tree_chain + 1;
 }
 
 // first step the backward of a tree-side level has to run: lo = max(1, D - chain + 1) (common.h: below it d(h^t) is
 // exactly zero); 1 = all steps
-inline int backward_lo(const Dims& d, int level, int depth) {
+inline int backward_lo(const Dims& d, int level, int depth, int E1) {
     static const bool off = ggpm_dev_env("GGPM_TREE_FIXED_POINT") && atoi(ggpm_dev_env("GGPM_TREE_FIXED_POINT")) == 0;
-    if (off || level == 2 || d.tree_chain <= 0) return 1;
+    if (off || level == 2 || bf16_stored(d, E1) || d.tree_chain <= 0) return 1;
     const int lo = depth - d.tree_chain + 1;
     return lo < 1 ? 1 : lo;
 }
@@ -307,7 +310,7 @@ inline int backward_lo(const Dims& d, int level, int depth) {
 int replicate_tail(const Dims& d, int E1, int depth, int run, int level, const LevelSaved& L, ggpm_stream_t s) {
     if (run >= depth) return GGPM_OK;
     const size_t slot = (size_t)E1 * d.Hp, ds = (size_t)depth * slot;
-    const int blo = backward_lo(d, level, depth);         // the backward only reads state slots >= blo, stash slots >= blo - 1
+    const int blo = backward_lo(d, level, depth, E1);     // the backward only reads state slots >= blo, stash slots >= blo - 1
     ReplicateArgs r = {};
     int n = 0;
     auto add = [&](float* base, int src, int lo, int hi) {
@@ -327,7 +330,7 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
                   const Csr& pred, const Csr& agr, LevelSaved& L, ggpm_stream_t s) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp;
-    const int run = run_steps(d, level, depth);
+    const int run = run_steps(d, level, depth, E1);
     struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
     if (d.lstm) {
         const float* W[4] = {P[lq(level, Q_WI)], P[lq(level, Q_WOG)], P[lq(level, Q_WU)], P[lq(level, Q_WF)]};
@@ -608,7 +611,7 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                    float* dx, int lddx, BwdWork& w, Streams& st) {
     const int H = d.H, Hp = d.Hp;
     const size_t slot = (size_t)E1 * Hp, ds = (size_t)depth * slot;
-    const int blo = backward_lo(d, level, depth);
+    const int blo = backward_lo(d, level, depth, E1);
     const int gate_dtype = d.gate_dtype;
     struct Tag { Tag(int level) { ggpm_timing_tag(3 - level); } ~Tag() { ggpm_timing_tag(0); } } tag(level);
     // no input gradient wanted (the atom level: one-hot inputs): the summed gate-input gradients are not needed on this
@@ -705,8 +708,9 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             float *DMP = nullptr, *DZP = nullptr;
             CK(ggpm_gru_backward_stashes(level_work, E1, H, depth, &DMP, &DZP));
             const int lo_ = blo < 1 ? 1 : blo;          // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
-            CK(ggpm_sum_slots(DZP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX, sx));
-            CK(ggpm_sum_slots(DMP + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + 2 * slot, sx));
+            const bool b16 = bf16_stored(d, E1);        // (then lo_ == 1 and the stashes are bf16 in the first half of their buffers)
+            CK(ggpm_sum_slots_any(DZP + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX, b16, sx));
+            CK(ggpm_sum_slots_any(DMP + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX + 2 * slot, b16, sx));
         }
         if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
             const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},

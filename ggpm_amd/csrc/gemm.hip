@@ -710,6 +710,7 @@ typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
 typedef short gs16x4 __attribute__((ext_vector_type(4)));
 constexpr int BTK = 32, BLD = 336;      // k rows per step; bf16 elements per LDS row (672 B = 168 dwords)
 
+template <bool IN16>      // IN16: the operands are bf16 in memory (bf16 storage of the depth loops' stashes): no conversion
 __global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, int splits) {
     __shared__ __attribute__((aligned(16))) __bf16 Ls[2][BTK * BLD];
     const unsigned T = gridDim.x * gridDim.y * gridDim.z;
@@ -729,8 +730,9 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, in
     const int isb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const float* P = isb ? g.B : g.A;
     const int ld = isb ? g.ldb : g.lda, c0 = isb ? n0 : m0, climit = isb ? g.N : g.M;
+    constexpr unsigned ES = IN16 ? 2 : 4;       // bytes per operand element in memory
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * 4) : 0u, 0x00020000);
+        const_cast<float*>(P), 0, kend > kbeg ? (unsigned)(((size_t)(kend - 1) * ld + climit) * ES) : 0u, 0x00020000);
     unsigned voff[10];
     int loff[10];
 #pragma unroll
@@ -738,22 +740,28 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_tall_bf16(GemmGroupArgs gg, in
         const int f = (threadIdx.x & 127) + 128 * i;
         const int k = f / (TM / 4), c = (f % (TM / 4)) * 4;
         loff[i] = k * BLD + isb * TM + c;
-        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * 4) : 0xffffff00u;
+        voff[i] = c0 + c < climit ? (unsigned)(((size_t)(kbeg + k) * ld + c0 + c) * ES) : 0xffffff00u;
     }
-    const unsigned vstep = (unsigned)BTK * ld * 4;
-    f32x4 r[10];
+    const unsigned vstep = (unsigned)BTK * ld * ES;
+    f32x4 r[IN16 ? 1 : 10];
+    uint2 r16[IN16 ? 10 : 1];
     auto fetch = [&]() {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+            if constexpr (IN16) r16[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff[i], 0, 0));
+            else r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
             if (voff[i] != 0xffffff00u) voff[i] += vstep;
         }
     };
     auto put = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            const gbf16x4 w = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
-            *reinterpret_cast<gbf16x4*>(&Ls[buf][loff[i]]) = w;
+            if constexpr (IN16) {
+                *reinterpret_cast<uint2*>(&Ls[buf][loff[i]]) = r16[i];
+            } else {
+                const gbf16x4 w = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
+                *reinterpret_cast<gbf16x4*>(&Ls[buf][loff[i]]) = w;
+            }
         }
     };
 
@@ -1050,6 +1058,7 @@ inline int choose_splits(int M, int N, int K) {
 constexpr int CS_ROWS = 256;   // max row chunks of the column-sum first stage (workspace = 256*N floats)
 
 // stage 1: block = 64 columns x 4 row lanes; grid (ceil(N/64), CS_ROWS); chunk c sums rows [c*per, (c+1)*per)
+template <bool IN16>
 __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A, int lda, int M, int N,
                                                      float* __restrict__ ws) {
     __shared__ float red[4][64];
@@ -1060,7 +1069,10 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ A
     const int lo = chunk * per, hi = min(M, lo + per);
     float v = 0.f;
     if (n < N)
-        for (int m = lo + rl; m < hi; m += 4) v += A[(size_t)m * lda + n];
+        for (int m = lo + rl; m < hi; m += 4) {
+            if constexpr (IN16) v += (float)reinterpret_cast<const __bf16*>(A)[(size_t)m * lda + n];
+            else v += A[(size_t)m * lda + n];
+        }
     red[rl][threadIdx.x & 63] = v;
     __syncthreads();
     if (rl == 0 && n < N) ws[(size_t)chunk * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -1274,6 +1286,8 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     const size_t slab = tall_slab_bytes(M, N);
     // (bf16 operands exist in the tall kernel only: a group that does not qualify falls back to fp32 products, which is
     // the more accurate side of the stated tolerance)
+    const bool in16 = bf16 == 2;
+    const size_t es = in16 ? 2 : 4;
     bool ok = use_tall && (count > 1 || bf16) && ws != nullptr;
     const bool split = !bf16 && tall_split_mode() != 0;      // fp32 accuracy on the bf16 pipe (gemm_tn_tall_split)
     int splits = 1 << 30;
@@ -1281,12 +1295,13 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
         ok = (p[i].lda & 3) == 0 && (p[i].ldb & 3) == 0 && ((uintptr_t)p[i].A & 15) == 0 && ((uintptr_t)p[i].B & 15) == 0 &&
              p[i].lda >= ggpm_round_up(M, 4) && p[i].ldb >= ggpm_round_up(N, 4) && tall_shape(M, N, K[i]) &&
              p[i].n_pad <= ggpm_round_up(N, TN) && p[i].n_pad >= N && p[i].n_pad <= p[i].ldc &&
-             (size_t)K[i] * p[i].lda * 4 < 0xffffff00ull && (size_t)K[i] * p[i].ldb * 4 < 0xffffff00ull;
+             (size_t)K[i] * p[i].lda * es < 0xffffff00ull && (size_t)K[i] * p[i].ldb * es < 0xffffff00ull;
         splits = min(splits, tall_splits(M, N, K[i], bf16 ? GGPM_TALL_BF16_WGS / count : (split ? tall_split_wgs() / count : 0)));
     }
     const int slabs_per_chunk = 1;
     if (ok) splits = min(splits, (int)(ws_bytes / (count * slab * slabs_per_chunk)));      // the group shares the workspace
     if (!ok || splits < ((bf16 || split) ? 1 : 2)) {
+        if (in16) return GGPM_ERR_UNSUPPORTED;      // (bf16 operands in memory exist for the tall kernel only)
         for (int i = 0; i < count; ++i) {
             const int rc = ggpm_gemm(1, 0, M, N, K[i], p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].n_pad,
                                      p[i].bias, p[i].accumulate, p[i].act, p[i].zero_row0, ws, ws_bytes, stream);
@@ -1305,13 +1320,20 @@ int ggpm_gemm_tall_grouped(int M, int N, int count, const GgpmGemmProblem* p, co
     for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = ggpm_ceil_div(N, TN), tiles_m = ggpm_ceil_div(M, TM);
-    if (bf16) gemm_tn_tall_bf16<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    if (in16) gemm_tn_tall_bf16<true><<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
+    else if (bf16) gemm_tn_tall_bf16<false><<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
     else if (split) launch_tall_split(gg, dim3(tiles_n, tiles_m, splits * count), splits, s);
     else gemm_tn_tall<<<dim3(tiles_n, tiles_m, splits * count), 256, 0, s>>>(gg, splits);
     tall_reduce<<<dim3(tiles_n * tiles_m * 100, count), 256, 0, s>>>(gg, splits * slabs_per_chunk, tiles_n, tiles_n * tiles_m);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
+
+bool ggpm_bf16_storage_applies(int E1, int H) {
+    static const int use_tall = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
+    return use_tall && E1 >= 6144 && tall_shape(H, H, E1);
+}
+extern "C" int ggpm_level_bf16_storage(int E1, int H) { return ggpm_bf16_storage_applies(E1, H) ? 1 : 0; }
 
 extern "C" int ggpm_gemm_tn_bf16_applies(int M, int N, int K) {
     static const int use_tall = [] { const char* e = ggpm_dev_env("GGPM_GEMM_TALL"); return e ? atoi(e) : 1; }();
@@ -1410,9 +1432,21 @@ extern "C" int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const fl
 }
 
 extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream) {
+    return ggpm_colsum_any(A, lda, M, N, out, ws, false, stream);
+}
+
+int ggpm_colsum_any(const float* A, int lda, int M, int N, float* out, float* ws, bool a_bf16, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (!A || !out || !ws || M <= 0 || N <= 0) return GGPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (a_bf16) {                                // (large stashes only: always the two-stage form)
+        int chunks = ggpm_ceil_div(M, 128);
+        if (chunks > CS_ROWS) chunks = CS_ROWS;
+        colsum_stage1<true><<<dim3(ggpm_ceil_div(N, 64), chunks), 256, 0, s>>>(A, lda, M, N, ws);
+        colsum_stage2<<<ggpm_ceil_div(N, 64), 256, 0, s>>>(ws, N, chunks, out);
+        GGPM_CHECK_LAUNCH();
+        return GGPM_OK;
+    }
     if (M <= CS_ONE_MAX) {
         colsum_one<<<ggpm_ceil_div(N, 64), 1024, 0, s>>>(A, lda, M, N, out);
         GGPM_CHECK_LAUNCH();
@@ -1421,7 +1455,7 @@ extern "C" int ggpm_colsum(const float* A, int lda, int M, int N, float* out, fl
     int chunks = ggpm_ceil_div(M, 128);          // >= 128 rows per chunk, at most CS_ROWS chunks
     if (chunks > CS_ROWS) chunks = CS_ROWS;
     dim3 g1(ggpm_ceil_div(N, 64), chunks);
-    colsum_stage1<<<g1, 256, 0, s>>>(A, lda, M, N, ws);
+    colsum_stage1<false><<<g1, 256, 0, s>>>(A, lda, M, N, ws);
     colsum_stage2<<<ggpm_ceil_div(N, 64), 256, 0, s>>>(ws, N, chunks, out);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;

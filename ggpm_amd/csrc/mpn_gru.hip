@@ -132,8 +132,10 @@ struct GruFwdArgs {
     const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
     int bf16;                      // gate mode: 0 fp32 MFMA, 1 bf16 operands (packed weights are bf16 fragments), 2 fp32 on
                                    // split operands (three bf16 planes per operand, tile_mma.h)
+    int st16;                      // bf16 storage of Hs / Qs / S / G / Z / M (gate mode 1, large dense training levels; tile_mma.h)
     int h0_zero;                   // first depth of a dense level: h^0 = 0, so s = g = 0 without a gather and the gate
                                    // products vanish (h^1 = sigmoid(x_z) tanh(x_h)); H^0 / Q^0 are neither built nor read
+    float* Hout;                   // bf16 storage only: where the LAST depth also writes h' in fp32 (the level's result)
     const float* src_h;            // kernel B of a sparse forward's q^0 launch (ggpm_forward_gather_state): row r of the
     const int32_t* src_idx;        // start state is src_h[src_idx[r]] (zero when < 0); the launch writes it to Hnew itself
 };
@@ -149,11 +151,12 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time (full Hp width: two 256-column sweeps
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
-template <bool STASH, int GM, int RTT>
+template <bool STASH, int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
+    static_assert(!ST16 || GM == 1, "bf16 storage goes with bf16 gate products");      // Hs, Qs, S, G, Z, M in bf16 (tile_mma.h)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
     float* Ts = lds;
@@ -207,8 +210,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                         const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp;
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            h[u][k] = ggpm_ld4(a.Hprev + p + cs[k]);
-                            q[u][k] = ggpm_ld4(a.Qprev + p + cs[k]);
+                            h[u][k] = ggpm_ldx<ST16>(a.Hprev, p + cs[k]);
+                            q[u][k] = ggpm_ldx<ST16>(a.Qprev, p + cs[k]);
                         }
                     }
 #pragma unroll
@@ -226,6 +229,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (!on[k]) continue;
+                if constexpr (ST16) s[k] = ggpm_rne4(s[k]);      // what the stash holds is what the epilogue below uses
                 ggpm_st4(Ts + lr * LD + c[k], s[k]);
                 if constexpr (SPLIT) {
                     ggpm_split_store(Is, PLANE, LDH, lr, c[k], s[k]);
@@ -235,8 +239,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                 }
                 if (STASH && row < a.E1 && (c[k] >> 4) / a.tg == grp) {
                     const size_t o = (size_t)row * Hp + c[k];
-                    ggpm_st4(a.S + o, s[k]);
-                    ggpm_st4(a.G + o, g[k]);
+                    ggpm_stx<ST16>(a.S, o, s[k]);
+                    ggpm_stx<ST16>(a.G, o, g[k]);
                     ggpm_st4(a.R + o, rc[k]);     // sum_p h_p r(1-r): lets the backward form dXr without a gather
                 }
             }
@@ -306,14 +310,17 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                 const float4 pz = ggpm_f4(acc[0][r]) + xz[r], pm = ggpm_f4(acc[1][r]) + xh[r];
                 z = ggpm_sigmoid4(pz);
                 m = make_float4(tanhf(pm.x), tanhf(pm.y), tanhf(pm.z), tanhf(pm.w));
+                if constexpr (ST16) { z = ggpm_rne4(z); m = ggpm_rne4(m); }
                 h = make_float4((1.f - z.x) * s.x + z.x * m.x, (1.f - z.y) * s.y + z.y * m.y,
                                 (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
+                if constexpr (ST16) h = ggpm_rne4(h);
             }
-            ggpm_st4(a.Hnew + o, h);
+            ggpm_stx<ST16>(a.Hnew, o, h);
+            if constexpr (ST16) if (a.Hout) ggpm_st4(a.Hout + o, h);      // the level's result (last depth) also in fp32
             if (a.fuse_b) keep_h(h);
             if (STASH) {
-                ggpm_st4(a.Z + o, z);
-                ggpm_st4(a.M + o, m);
+                ggpm_stx<ST16>(a.Z, o, z);
+                ggpm_stx<ST16>(a.M, o, m);
             }
         }
     }
@@ -344,13 +351,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                 ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
             } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
             else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
-            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
+            if (row < a.E1) ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
         }
     }
 }
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
@@ -377,7 +384,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
         else ggpm_load_rows_to_lds_split<ROWS>(a.Hnew, r0, a.E1, Hp, Ih, PLANE, LDH);
     } else {
         if (a.src_idx) ggpm_gather_rows_to_lds<ROWS>(a.src_h, a.src_idx, r0, a.E1, Hp, LD, Th, grp == 0 ? a.Hnew : nullptr);
-        else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+        else ggpm_load_rows_to_lds<ROWS, ST16>(a.Hnew, r0, a.E1, Hp, LD, Th);
     }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -397,7 +404,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < RTT; ++r) {
             const int row = r0 + 16 * r + (lane & 15);
-            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][r]) + b);
+            if (row < a.E1) ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][r]) + b);
         }
     }
 }
@@ -430,13 +437,14 @@ struct GruBwdArgs {
     unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
     int bf16;                      // gate products on bf16 operands
     int skip_xsum;                 // dXz / dXh are NOT accumulated here: the caller sums the DZP / DMP stash slots afterwards
+    int st16;                      // bf16 storage of Hs / Qs / S / Z / M / dS / dG / DQ / DZP / DMP (see GruFwdArgs)
 };
 
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
 // gate derivatives for this workgroup's column group.
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
-    constexpr int ROWS = RTT * 16;
+    constexpr int ROWS = RTT * 16;      // ST16: Hs, Qs, S, Z, M, dS / dG, DQ, DZP, DMP in bf16 (tile_mma.h)
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -478,8 +486,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                     on[k] = c[k] < Hp;
                     cs[k] = on[k] ? c[k] : 0;
                     dh[k] = ggpm_zero4(); dq[k] = ggpm_zero4();
-                    hp[k] = ggpm_ld4(a.Hcur + po + cs[k]);
-                    qp[k] = ggpm_ld4(a.Qcur + po + cs[k]);
+                    hp[k] = ggpm_ldx<ST16>(a.Hcur, po + cs[k]);
+                    qp[k] = ggpm_ldx<ST16>(a.Qcur, po + cs[k]);
                 }
                 for (int base = 0; base < rl.n; base += 64) {
                     const int chunk = fast ? tchunk : ggpm_list_chunk(a.scol, rl, base, lane);
@@ -492,8 +500,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 xr[u][k] = ggpm_ld4(a.Xr + e + cs[k]);
-                                dg[u][k] = ggpm_ld4(a.dGin + e + cs[k]);
-                                ds[u][k] = ggpm_ld4(a.dSin + e + cs[k]);
+                                dg[u][k] = ggpm_ldx<ST16>(a.dGin, e + cs[k]);
+                                ds[u][k] = ggpm_ldx<ST16>(a.dSin, e + cs[k]);
                             }
                         }
 #pragma unroll
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                     ggpm_st4(T0 + lr * LD + c[k], dh[k]);
                     if constexpr (SPLIT) ggpm_split_store(I1, PLANE, LDH, lr, c[k], dq[k]);
                     else ggpm_st4(T1 + lr * LD + c[k], dq[k]);
-                    if (p < a.E1 && (c[k] >> 4) / a.tg == grp) ggpm_st4(a.DQ + (size_t)p * Hp + c[k], dq[k]);
+                    if (p < a.E1 && (c[k] >> 4) / a.tg == grp) ggpm_stx<ST16>(a.DQ, (size_t)p * Hp + c[k], dq[k]);
                 }
             }
         }
@@ -545,7 +553,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 const size_t o = (size_t)(row < a.E1 ? row : 0) * Hp + c;
                 s[r] = z[r] = m[r] = oxz[r] = oxh[r] = ggpm_zero4();
                 if (!a.final_pass) {
-                    s[r] = ggpm_ld4(a.S + o); z[r] = ggpm_ld4(a.Z + o); m[r] = ggpm_ld4(a.M + o);
+                    s[r] = ggpm_ldx<ST16>(a.S, o); z[r] = ggpm_ldx<ST16>(a.Z, o); m[r] = ggpm_ldx<ST16>(a.M, o);
                     if (!a.first && !a.skip_xsum) { oxz[r] = ggpm_ld4(a.dXz + o); oxh[r] = ggpm_ld4(a.dXh + o); }    // depth D starts the sums
                 }
                 dhd[r] = a.first ? ggpm_ld4(a.dHD + o) : ggpm_zero4();
@@ -617,9 +625,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 dsdir = make_float4(o_ds[0], o_ds[1], o_ds[2], o_ds[3]);
                 dzp = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
                 dmp = make_float4(o_dm[0], o_dm[1], o_dm[2], o_dm[3]);
+                if constexpr (ST16) { dzp = ggpm_rne4(dzp); dmp = ggpm_rne4(dmp); }      // (the stored values: every user sees them)
             }
-            ggpm_st4(a.DZP + o, dzp);
-            ggpm_st4(a.DMP + o, dmp);
+            ggpm_stx<ST16>(a.DZP, o, dzp);
+            ggpm_stx<ST16>(a.DMP, o, dmp);
             if (!a.skip_xsum) {
                 ggpm_st4(a.dXz + o, oxz[r] + dzp);
                 ggpm_st4(a.dXh + o, oxh[r] + dmp);
@@ -665,9 +674,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                 else ggpm_wave_gemm_ring<2, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             }
             if (row >= a.E1) continue;
-            const float4 dg = ggpm_f4(acc[0][0]);
-            ggpm_st4(a.dGout + o, dg);
-            ggpm_st4(a.dSout + o, ggpm_f4(acc[1][0]) + dsd);
+            float4 dg = ggpm_f4(acc[0][0]);
+            if constexpr (ST16) dg = ggpm_rne4(dg);
+            ggpm_stx<ST16>(a.dGout, o, dg);
+            ggpm_stx<ST16>(a.dSout, o, ggpm_f4(acc[1][0]) + dsd);
             ggpm_st4(a.dXr + o, oxr + dg * rco);
         }
     }
@@ -675,7 +685,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 
 // Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
@@ -703,8 +713,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
         ggpm_load_rows_to_lds_split<ROWS>(a.DZP, r0, a.E1, Hp, Iz, PLANE, LDH);
         ggpm_load_rows_to_lds_split<ROWS>(a.DMP, r0, a.E1, Hp, Im, PLANE, LDH);
     } else {
-        ggpm_load_rows_to_lds<ROWS>(a.DZP, r0, a.E1, Hp, LD, T1);
-        ggpm_load_rows_to_lds<ROWS>(a.DMP, r0, a.E1, Hp, LD, T2);
+        ggpm_load_rows_to_lds<ROWS, ST16>(a.DZP, r0, a.E1, Hp, LD, T1);
+        ggpm_load_rows_to_lds<ROWS, ST16>(a.DMP, r0, a.E1, Hp, LD, T2);
     }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -737,9 +747,10 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
             const int e = r0 + 16 * r + (lane & 15);
             if (e >= a.E1) continue;
             const size_t o = (size_t)e * Hp + c;
-            const float4 dg = ggpm_f4(acc[0][r]);
-            ggpm_st4(a.dGout + o, dg);
-            ggpm_st4(a.dSout + o, ggpm_f4(acc[1][r]) + dsd[r]);
+            float4 dg = ggpm_f4(acc[0][r]);
+            if constexpr (ST16) dg = ggpm_rne4(dg);
+            ggpm_stx<ST16>(a.dGout, o, dg);
+            ggpm_stx<ST16>(a.dSout, o, ggpm_f4(acc[1][r]) + dsd[r]);
             ggpm_st4(a.dXr + o, oxr[r] + dg * rco[r]);
         }
     }
@@ -822,7 +833,9 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
         set_lds(kernel, lds_a);
         kernel<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     };
-    if (rt2) {
+    if (a.st16) {      // (training levels only: always with stashes)
+        if (rt2) go(gru_fwd_a<true, 1, 2, true>); else go(gru_fwd_a<true, 1, 1, true>);
+    } else if (rt2) {
         if (a.bf16 == 1) { if (stash) go(gru_fwd_a<true, 1, 2>); else go(gru_fwd_a<false, 1, 2>); }
         else { if (stash) go(gru_fwd_a<true, 0, 2>); else go(gru_fwd_a<false, 0, 2>); }
     } else {
@@ -845,7 +858,8 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
             kernel<<<grid_a, GGPM_NWA * 64, lds_b, s>>>(a);
         };
         ggpm_timing_begin(4, s, 1 * flops1);
-        if (rt2) { if (a.bf16 == 1) gob(gru_fwd_b<1, 2>); else gob(gru_fwd_b<0, 2>); }
+        if (a.st16) { if (rt2) gob(gru_fwd_b<1, 2, true>); else gob(gru_fwd_b<1, 1, true>); }
+        else if (rt2) { if (a.bf16 == 1) gob(gru_fwd_b<1, 2>); else gob(gru_fwd_b<0, 2>); }
         else { if (a.bf16 == 2) gob(gru_fwd_b<2, 1>); else if (a.bf16 == 1) gob(gru_fwd_b<1, 1>); else gob(gru_fwd_b<0, 1>); }
         ggpm_timing_end(4, s);
     }
@@ -876,7 +890,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
         kernel<<<grid_a, GGPM_NWA * 64, bytes, s>>>(a);
     };
     ggpm_timing_begin(1, s, (a.fuse_b ? 3 : 1) * flops1);
-    if (rt2) { if (a.bf16 == 1) go(gru_bwd_a<1, 2>, lds_a); else go(gru_bwd_a<0, 2>, lds_a); }
+    if (a.st16) { if (rt2) go(gru_bwd_a<1, 2, true>, lds_a); else go(gru_bwd_a<1, 1, true>, lds_a); }
+    else if (rt2) { if (a.bf16 == 1) go(gru_bwd_a<1, 2>, lds_a); else go(gru_bwd_a<0, 2>, lds_a); }
     else { if (a.bf16 == 2) go(gru_bwd_a<2, 1>, lds_a); else if (a.bf16 == 1) go(gru_bwd_a<1, 1>, lds_a); else go(gru_bwd_a<0, 1>, lds_a); }
     ggpm_timing_end(1, s);
     if (a.dbg && !a.first && (++dbg_count % 89) == 0) {
@@ -889,7 +904,8 @@ void launch_bwd(GruBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     }
     if (with_b) {
         ggpm_timing_begin(5, s, 2 * flops1);
-        if (rt2) { if (a.bf16 == 1) go(gru_bwd_b<1, 2>, lds); else go(gru_bwd_b<0, 2>, lds); }
+        if (a.st16) { if (rt2) go(gru_bwd_b<1, 2, true>, lds); else go(gru_bwd_b<1, 1, true>, lds); }
+        else if (rt2) { if (a.bf16 == 1) go(gru_bwd_b<1, 2>, lds); else go(gru_bwd_b<0, 2>, lds); }
         else { if (a.bf16 == 2) go(gru_bwd_b<2, 1>, lds); else if (a.bf16 == 1) go(gru_bwd_b<1, 1>, lds); else go(gru_bwd_b<0, 1>, lds); }
         ggpm_timing_end(5, s);
     }
@@ -1015,6 +1031,8 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     static const char* const abl = ggpm_dev_env("GGPM_ABLATE");
+    // bf16 storage (tile_mma.h): bf16 gate products, dense, training, every stash contraction on the bf16 tall kernel
+    const bool st16 = bf16 == 1 && !frozen && save_for_backward && ggpm_bf16_storage_applies(E1, H);
     int run_depth = ggpm_take_run_depth();
     if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
     for (int t = 1; t <= run_depth; ++t) {
@@ -1025,13 +1043,15 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         a.frozen = frozen;
         a.ptab = pred_tab;
         a.bf16 = bf16;
+        a.st16 = st16 ? 1 : 0;
         a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
-            a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
-            a.Qprev = Qs + (size_t)(t - 1) * slot;
-            a.Qnew = (t < depth) ? Qs + (size_t)t * slot : nullptr;   // q^depth is never consumed
-            a.S = Ss + (size_t)(t - 1) * slot; a.G = Gs + (size_t)(t - 1) * slot;
-            a.Z = Zs + (size_t)(t - 1) * slot; a.M = Ms + (size_t)(t - 1) * slot;
+            a.Hprev = ggpm_slot_ptr(Hs, t - 1, slot, st16); a.Hnew = ggpm_slot_ptr(Hs, t, slot, st16);
+            a.Hout = (st16 && t == depth) ? Hs + (size_t)depth * slot : nullptr;      // the level's result stays fp32, at its usual place
+            a.Qprev = ggpm_slot_ptr(Qs, t - 1, slot, st16);
+            a.Qnew = (t < depth) ? ggpm_slot_ptr(Qs, t, slot, st16) : nullptr;   // q^depth is never consumed
+            a.S = ggpm_slot_ptr(Ss, t - 1, slot, st16); a.G = ggpm_slot_ptr(Gs, t - 1, slot, st16);
+            a.Z = ggpm_slot_ptr(Zs, t - 1, slot, st16); a.M = ggpm_slot_ptr(Ms, t - 1, slot, st16);
             a.R = Rs + (size_t)(t - 1) * slot;
         } else {
             a.Hprev = Hs + (size_t)((t - 1) & 1) * slot; a.Hnew = Hs + (size_t)(t & 1) * slot;
@@ -1163,6 +1183,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
 
     const int tg = pick_tg(E1, Hp / 16);
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
+    const bool st16 = bf16 == 1 && !frozen && ggpm_bf16_storage_applies(E1, H);      // (as the forward decided)
     // tree-side levels: d(h^t) vanishes below step `lo` (nilpotent Jacobian, common.h); sparse runs go all the way
     int lo = ggpm_take_backward_lo();
     if (lo < 1 || lo > depth || frozen) lo = 1;
@@ -1170,16 +1191,18 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         GruBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
         a.Xr = Xr;
-        a.Hcur = Hs + (size_t)t * slot;
-        a.Qcur = (t < depth) ? Qs + (size_t)t * slot : nullptr;
-        a.S = Ss + (size_t)(t - 1) * slot; a.Z = Zs + (size_t)(t - 1) * slot; a.M = Ms + (size_t)(t - 1) * slot;
+        a.st16 = st16 ? 1 : 0;
+        a.Hcur = ggpm_slot_ptr(Hs, t, slot, st16);
+        a.Qcur = (t < depth) ? ggpm_slot_ptr(Qs, t, slot, st16) : nullptr;
+        a.S = ggpm_slot_ptr(Ss, t - 1, slot, st16); a.Z = ggpm_slot_ptr(Zs, t - 1, slot, st16);
+        a.M = ggpm_slot_ptr(Ms, t - 1, slot, st16);
         a.R = Rs + (size_t)(t - 1) * slot;
         a.dHD = dHD;
-        a.dSin = dSb[(t + 1) & 1]; a.dGin = dGb[(t + 1) & 1];
+        a.dSin = dSb[(t + 1) & 1]; a.dGin = dGb[(t + 1) & 1];      // (bf16 storage: bf16 in the first half of each buffer)
         a.dSout = dSb[t & 1]; a.dGout = dGb[t & 1];
-        a.DQ = (t < depth) ? DQ + (size_t)t * slot : nullptr;
+        a.DQ = (t < depth) ? ggpm_slot_ptr(DQ, t, slot, st16) : nullptr;
         a.frozen = frozen; a.carry = carry; a.final_pass = 0; a.dHin = nullptr;
-        a.DMP = DMP + (size_t)(t - 1) * slot; a.DZP = DZP + (size_t)(t - 1) * slot; a.DSD = DSD;
+        a.DMP = ggpm_slot_ptr(DMP, t - 1, slot, st16); a.DZP = ggpm_slot_ptr(DZP, t - 1, slot, st16); a.DSD = DSD;
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
@@ -1271,27 +1294,32 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = (depth - lo + 1) * E1;
-    const size_t o1 = (size_t)(lo - 1) * slot;
+    // bf16 storage (as gru_forward_impl / gru_backward_impl decided): the stashes are bf16 in the first half of their buffers
+    // and the bf16 tall kernel reads them as they are
+    const bool st16 = ggpm_gate_dtype() == 1 && !with_slot0 && ggpm_bf16_storage_applies(E1, H);
+    const int tall_mode = st16 ? 2 : (ggpm_gate_dtype() == 1 ? 1 : 0);
     int rc;
     // the two or three contractions in ONE launch and one reduce (they share the split-K workspace)
-    ggpm_gemm_problem gp[3] = {{DMP + o1, Hp, Gs + o1, Hp, dWh_h, ld_dwh, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DZP + o1, Hp, Ss + o1, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
+    ggpm_gemm_problem gp[3] = {{ggpm_slot_ptr(DMP, lo - 1, slot, st16), Hp, ggpm_slot_ptr(Gs, lo - 1, slot, st16), Hp, dWh_h, ld_dwh, H,
+                                nullptr, 0, GGPM_ACT_NONE, 0},
+                               {ggpm_slot_ptr(DZP, lo - 1, slot, st16), Hp, ggpm_slot_ptr(Ss, lo - 1, slot, st16), Hp, dWz_h, ld_dwz, H,
+                                nullptr, 0, GGPM_ACT_NONE, 0},
                                {nullptr, Hp, nullptr, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0}};
     int Ks[3] = {KD, KD, 0};
     if (depth > lo || with_slot0) {
         // dq^t pairs with h^t; the dense level never produces dq^0 (h^0 = 0), sparse_forward does
         const int first_slot = with_slot0 ? 0 : lo;
         const int KQ = (depth - first_slot) * E1;
-        const float* dq0 = DQ + (size_t)first_slot * slot;
+        const float* dq0 = ggpm_slot_ptr(DQ, first_slot, slot, st16);
         gp[2].A = dq0;
-        gp[2].B = Hs + (size_t)first_slot * slot;
+        gp[2].B = ggpm_slot_ptr(Hs, first_slot, slot, st16);
         Ks[2] = KQ;
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
-        rc = ggpm_colsum(dq0, Hp, KQ, H, dbu, csws, stream);
+        rc = ggpm_colsum_any(dq0, Hp, KQ, H, dbu, csws, st16, stream);
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
+        rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
         (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
@@ -1301,21 +1329,26 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
 }
 
 namespace {
+template <bool B16>
 __global__ void __launch_bounds__(256) sum_slots_k(const float* __restrict__ src, int slots, size_t slot4, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= slot4) return;
-    const float4* p = reinterpret_cast<const float4*>(src) + i;
-    float4 acc = p[0];
-    for (int t = 1; t < slots; ++t) acc = acc + p[(size_t)t * slot4];          // fixed order
+    float4 acc = ggpm_ldx<B16>(src, 4 * i);
+    for (int t = 1; t < slots; ++t) acc = acc + ggpm_ldx<B16>(src, 4 * ((size_t)t * slot4 + i));          // fixed order
     reinterpret_cast<float4*>(out)[i] = acc;
 }
 }  // namespace
 
 extern "C" int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, float* out, ggpm_stream_t stream) {
+    return ggpm_sum_slots_any(src, slots, slot_floats, out, false, stream);
+}
+
+int ggpm_sum_slots_any(const float* src, int slots, size_t slot_floats, float* out, bool src_bf16, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     if (!src || !out || slots <= 0 || slot_floats == 0 || (slot_floats & 3)) return GGPM_ERR_ARG;
     const size_t slot4 = slot_floats / 4;
-    sum_slots_k<<<(unsigned)((slot4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, slots, slot4, out);
+    if (src_bf16) sum_slots_k<true><<<(unsigned)((slot4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, slots, slot4, out);
+    else sum_slots_k<false><<<(unsigned)((slot4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, slots, slot4, out);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

@@ -452,6 +452,39 @@ __device__ __forceinline__ void ggpm_zero_acc(f32x4 (&acc)[NOPS][RT]) {
 
 __device__ __forceinline__ float4 ggpm_f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
+// ---- bf16 STORAGE of the depth loop's arrays (gate mode 1 on large dense levels; BASELINE configs[4]) ----------------------
+// An array kept in bf16 lives in the FIRST HALF of the fp32 buffer the caller reserved for it (same slot count, half the
+// bytes), so no allocation, driver or binding changes with the storage type; values are rounded (RNE) where they are written
+// and every reader -- the writing kernel's own epilogue included -- sees the rounded value (oracle/ref_encoder.py: "bf16s").
+__device__ __forceinline__ float4 ggpm_bf16x4_to_f4(uint2 v) {
+    return make_float4(__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                       __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 ggpm_f4_to_bf16x4(float4 v) {      // RNE (v_cvt_pk_bf16_f32)
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    const b4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ float4 ggpm_rne4(float4 v) { return ggpm_bf16x4_to_f4(ggpm_f4_to_bf16x4(v)); }
+// element i (a multiple of 4) of an array that is fp32 or, with B16, bf16 in the first half of the same buffer
+template <bool B16>
+__device__ __forceinline__ float4 ggpm_ldx(const float* base, size_t i) {
+    if constexpr (B16) return ggpm_bf16x4_to_f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(base) + i));
+    else return ggpm_ld4(base + i);
+}
+template <bool B16>
+__device__ __forceinline__ void ggpm_stx(float* base, size_t i, float4 v) {
+    if constexpr (B16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(base) + i) = ggpm_f4_to_bf16x4(v);
+    else ggpm_st4(base + i, v);
+}
+// start of slot t (of `slot` elements) of such an array
+static inline float* ggpm_slot_ptr(float* base, size_t t, size_t slot, bool b16) {
+    return b16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + t * slot) : base + t * slot;
+}
+static inline const float* ggpm_slot_ptr(const float* base, size_t t, size_t slot, bool b16) {
+    return b16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(base) + t * slot) : base + t * slot;
+}
+
 // ---- CSR row walk helpers for the gather phases -------------------------------------------------------
 // One wave walks one destination row.  The row's list is loaded ONCE, coalesced (lane j holds entry j), and
 // entries are then broadcast with v_readlane; slots past the end read index 0, the all-zero pad row of
@@ -489,14 +522,14 @@ __device__ __forceinline__ int ggpm_list_at(int chunk, int j, int m) {
 
 // Copy ROWS full feature rows [r0, r0+ROWS) of a [rows][Hp] matrix into an LDS tile [ROWS][LD]
 // (rows past the end are zero filled).  All NW waves take part; 16 B per lane, coalesced.
-template <int ROWS>
+template <int ROWS, bool B16 = false>
 __device__ __forceinline__ void ggpm_load_rows_to_lds(const float* __restrict__ src, int r0, int rows, int Hp,
                                                       int LD, float* __restrict__ tile) {
     const int q = Hp >> 2;    // float4 per row
     for (int it = threadIdx.x; it < ROWS * q; it += blockDim.x) {
         const int lr = it / q, c = (it - lr * q) * 4;
         const int row = r0 + lr;
-        const float4 v = row < rows ? ggpm_ld4(src + (size_t)row * Hp + c) : ggpm_zero4();
+        const float4 v = row < rows ? ggpm_ldx<B16>(src, (size_t)row * Hp + c) : ggpm_zero4();
         ggpm_st4(tile + lr * LD + c, v);
     }
 }

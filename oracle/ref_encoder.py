@@ -58,6 +58,7 @@ def _row0_mask(n: int, like: Tensor) -> Tensor:
 #   backward  dx = rne(dy) rne(W)            (the products of the backward depth kernels)
 #             dW = dy^T x                    "bf16":  weight gradients contracted from the unrounded stashes
 #             dW = rne(dy)^T rne(x)          "bf16w": bf16 operands in the tall weight-gradient contractions as well
+#                                            "bf16s": ... and bf16 STORAGE of the depth loop's arrays (see _Round below)
 # The per-slot recurrent products of the reference, U_r(h_nei)[e,k] (rnn.py:31) and the hidden half of W_f([x, h_nei])[e,k]
 # (rnn.py:90), are applied once per MESSAGE and gathered, (U_r h)[bgraph[e,k]] -- the same numbers element for
 # element, but the gradient then reaches the product summed over a message's uses, which is where the kernels round it.
@@ -82,39 +83,90 @@ class _Bf16Product(torch.autograd.Function):
 
 
 def bf16_product(x: Tensor, w: Tensor, gate_dtype: str) -> Tensor:
-    return _Bf16Product.apply(x, w, gate_dtype == "bf16w")
+    return _Bf16Product.apply(x, w, gate_dtype in ("bf16w", "bf16s"))
+
+
+# "bf16s": bf16 STORAGE on top of "bf16w" (BASELINE configs[4]: "bf16 storage / MFMA with fp32 accumulate").  Every array of
+# the depth loop that the kernels keep in bf16 is rounded where the kernels write it -- the value is then the same wherever it
+# is read, in the forward and in the backward:
+#   state h' and the per-message recurrent product q (Hs, Qs), s = sum_p h_p, the gates z / m (GRU) and i / o / u (LSTM)
+#       rounded in the FORWARD (what the kernels stash is what their own epilogue uses, and what the backward differentiates
+#       the activations with: _StoredGate);
+#   the gradients the backward stores between its launches -- d(pre-activation) of every gate (DZP / DMP, DI / DO / DU), dq
+#       (DQ) and dS, dG -- rounded in the BACKWARD, once, where autograd has summed them.
+# Kept in fp32 by the kernels and therefore untouched here: the LSTM cell state c and dFC, the reset / forget coefficient
+# sums R / F, the gate inputs X and their gradients.
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return rne_bf16(x) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (rne_bf16(dy) if ctx.bwd else dy), None, None
+
+
+def _stored(t: Tensor, gate_dtype: str, fwd: bool, bwd: bool) -> Tensor:
+    return _Round.apply(t, fwd, bwd) if gate_dtype == "bf16s" else t
+
+
+class _StoredGate(torch.autograd.Function):
+    """A gate activation whose OUTPUT is what the kernels stash in bf16: y = rne(act(x)), and the derivative is formed from
+    that stored y (y (1 - y) resp. 1 - y^2), as the backward kernels form it -- not from the unrounded activation."""
+
+    @staticmethod
+    def forward(ctx, x, tanh):
+        y = rne_bf16(torch.tanh(x) if tanh else torch.sigmoid(x))
+        ctx.save_for_backward(y)
+        ctx.tanh = tanh
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return dy * ((1.0 - y * y) if ctx.tanh else (y * (1.0 - y))), None
+
+
+def _gate(x: Tensor, gate_dtype: str, tanh: bool = False) -> Tensor:
+    if gate_dtype == "bf16s":
+        return _StoredGate.apply(x, tanh)
+    return torch.tanh(x) if tanh else torch.sigmoid(x)
 
 
 def gru_cell_bf16(p: Params, pre: str, x: Tensor, h: Tensor, bgraph: Tensor, gate_dtype: str) -> Tensor:
     """GRU.GRU (ggpm/rnn.py:25-39) on the message state ``h`` [E, H] with bf16 gate products (see above)."""
     I = x.shape[1]
     Wz, Wh = p[pre + "W_z.weight"], p[pre + "W_h.weight"]
+    st = lambda t, fwd, bwd: _stored(t, gate_dtype, fwd, bwd)
     h_nei = gather_rows(h, bgraph)
-    q_nei = gather_rows(bf16_product(h, p[pre + "U_r.weight"], gate_dtype) + p[pre + "U_r.bias"], bgraph)
-    s = h_nei.sum(dim=1)
-    z = torch.sigmoid(x @ Wz[:, :I].t() + bf16_product(s, Wz[:, I:], gate_dtype) + p[pre + "W_z.bias"])
+    q_nei = gather_rows(st(bf16_product(h, p[pre + "U_r.weight"], gate_dtype) + p[pre + "U_r.bias"], True, True), bgraph)
+    s = st(h_nei.sum(dim=1), True, True)
+    z = _gate(st(x @ Wz[:, :I].t() + bf16_product(s, Wz[:, I:], gate_dtype) + p[pre + "W_z.bias"], False, True), gate_dtype)
     r = torch.sigmoid(_affine(p, pre + "W_r", x).unsqueeze(1) + q_nei)
-    g = (r * h_nei).sum(dim=1)
-    cand = torch.tanh(x @ Wh[:, :I].t() + bf16_product(g, Wh[:, I:], gate_dtype) + p[pre + "W_h.bias"])
-    return (1.0 - z) * s + z * cand
+    g = st((r * h_nei).sum(dim=1), False, True)      # (forwards g only feeds the product, which rounds it anyway)
+    cand = _gate(st(x @ Wh[:, :I].t() + bf16_product(g, Wh[:, I:], gate_dtype) + p[pre + "W_h.bias"], False, True), gate_dtype,
+                 tanh=True)
+    return st((1.0 - z) * s + z * cand, True, False)
 
 
 def lstm_cell_bf16(p: Params, pre: str, x: Tensor, h: Tensor, c: Tensor, bgraph: Tensor, gate_dtype: str):
     """LSTM.LSTM (ggpm/rnn.py:85-94) on the message state (h, c) with bf16 gate products (see above)."""
     I = x.shape[1]
+    st = lambda t, fwd, bwd: _stored(t, gate_dtype, fwd, bwd)
     h_nei, c_nei = gather_rows(h, bgraph), gather_rows(c, bgraph)
-    s = h_nei.sum(dim=1)
+    s = st(h_nei.sum(dim=1), True, True)
 
     def gate(name):
         W = p[pre + name + ".0.weight"]
-        return x @ W[:, :I].t() + bf16_product(s, W[:, I:], gate_dtype) + p[pre + name + ".0.bias"]
+        return st(x @ W[:, :I].t() + bf16_product(s, W[:, I:], gate_dtype) + p[pre + name + ".0.bias"], False, True)
 
-    i, o, u = torch.sigmoid(gate("W_i")), torch.sigmoid(gate("W_o")), torch.tanh(gate("W"))
+    i, o, u = _gate(gate("W_i"), gate_dtype), _gate(gate("W_o"), gate_dtype), _gate(gate("W"), gate_dtype, tanh=True)
     Wf = p[pre + "W_f.0.weight"]
     xf = x @ Wf[:, :I].t() + p[pre + "W_f.0.bias"]
-    f = torch.sigmoid(xf.unsqueeze(1) + gather_rows(bf16_product(h, Wf[:, I:], gate_dtype), bgraph))
+    f = torch.sigmoid(xf.unsqueeze(1) + gather_rows(st(bf16_product(h, Wf[:, I:], gate_dtype), True, True), bgraph))
     c_new = i * u + (f * c_nei).sum(dim=1)
-    return o * torch.tanh(c_new), c_new
+    return st(o * torch.tanh(c_new), True, False), c_new
 
 
 # ---------------------------------------------------------------- GRU (ggpm/rnn.py:5-59)
@@ -182,7 +234,7 @@ def lstm_forward(p: Params, pre: str, fmess: Tensor, bgraph: Tensor, depth: int,
 def rnn_forward(p: Params, pre: str, rnn_type: str, fmess: Tensor, bgraph: Tensor, depth: int,
                 trace: list | None = None, gate_dtype: str = "f32") -> Tensor:
     """rnn(...) followed by get_hidden_state -- ggpm/encoder.py:29-30, rnn.py:22-23,82-83."""
-    if gate_dtype not in ("f32", "bf16", "bf16w"):
+    if gate_dtype not in ("f32", "bf16", "bf16w", "bf16s"):
         raise ValueError("gate_dtype " + gate_dtype)
     if rnn_type == "GRU":
         return gru_forward(p, pre, fmess, bgraph, depth, trace, gate_dtype)

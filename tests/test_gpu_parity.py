@@ -896,6 +896,8 @@ def _bf16_hip_vs_oracle(build, tensors, H, rnn, depths, params):
                               ("tree_encoder.", depthT, tensors[0][1].shape[0], chain)):
         lo = max(1, depth - c + 1) if 0 < c else 1
         modes[pre] = "bf16w" if lib.ggpm_gemm_tn_bf16_applies(H, H, (depth - lo) * E1) else "bf16"
+        if rnn == "GRU" and lib.ggpm_level_bf16_storage(E1, H):      # the level's depth-loop arrays are kept in bf16 as well
+            modes[pre] = "bf16s"
     routs = ref.hier_encoder_forward(p, rnn, depthT, depthG, tt, gt, gate_dtype=modes)
     _, rkl = ref.rsample_kl(p, routs[0])
     (rkl + sum((o * o).sum() for o in routs)).backward()
@@ -947,6 +949,8 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
                        dx=xg.grad.cpu().numpy())
     lib = _lib.load(build_if_missing=False)
     mode = "bf16w" if lib.ggpm_gemm_tn_bf16_applies(H, H, (depth - 1) * (E + 1)) else "bf16"
+    if rnn == "GRU" and lib.ggpm_level_bf16_storage(E + 1, H):      # bf16 storage of the depth loop's arrays (tile_mma.h)
+        mode = "bf16s"
     p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
     xr = torch.from_numpy(x).requires_grad_(True)
     href = ref.rnn_forward(p, "", rnn, xr, torch.from_numpy(bgraph), depth, gate_dtype=mode)
@@ -961,7 +965,11 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
         med, frac, worst = float(np.median(row)), float((row <= 2e-5).mean()), float(row.max())
         report.append("%s rows: median %.1e, %.1f%% within 2e-5, worst %.1e" % (k, med, 100 * frac, worst))
         # (a flipped row reaches its predecessors through the backward gather: more dx rows than h rows are touched)
-        assert med <= 2e-6 and frac >= (0.9 if k == "h" else 0.7) and worst <= 2e-3, (k, med, frac, worst)
+        # (bf16 storage: what a flip moves is a STORED value, by one bf16 ulp of itself, i.e. up to 2^-8 of the tensor's scale)
+        # and every stored array is one more rounding point per element and depth step: more rows meet a flip)
+        worst_tol = 6e-3 if mode == "bf16s" else 2e-3
+        frac_min = {"h": 0.9, "dx": 0.7} if mode != "bf16s" else {"h": 0.75, "dx": 0.5}
+        assert med <= 2e-6 and frac >= frac_min[k] and worst <= worst_tol, (k, med, frac, worst)
     errs = {k: rel_err(got["bf16"][k], want[k]) for k in sd}
     worst_k = max(errs, key=errs.get)
     print("bf16 level %s E=%d H=%d depth=%d (weight-gradient operands %s): %s; parameter gradients worst %.2e (%s) at a "

@@ -475,12 +475,17 @@ def test_bf16_cells_of_the_oracle_are_the_reference_cells_up_to_the_rounding(nam
         return outs, p
 
     monkeypatch.setattr(ref, "rne_bf16", lambda t: t)
-    outs, p = run("bf16w")
-    for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
-        assert rel_err(o.detach().numpy(), g.z[k]) <= 2e-5, k
-    for k, v in p.items():
-        g.check_grad(k, (v.grad if v.grad is not None else torch.zeros_like(v)).numpy(), rel=1e-4)
+    for mode in ("bf16w", "bf16s"):       # ("bf16s": the storage roundings of ref._Round are identities too)
+        outs, p = run(mode)
+        for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs):
+            assert rel_err(o.detach().numpy(), g.z[k]) <= 2e-5, (mode, k)
+        for k, v in p.items():
+            g.check_grad(k, (v.grad if v.grad is not None else torch.zeros_like(v)).numpy(), rel=1e-4)
     monkeypatch.undo()
     outs_b, _ = run("bf16")
     shift = max(rel_err(o.detach().numpy(), g.z[k]) for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs_b))
     assert 1e-6 < shift < 0.3, shift      # (GRU at depth 20 amplifies a 2^-9 operand error to ~0.1: sum aggregation)
+    outs_s, _ = run("bf16s")
+    shift_s = max(rel_err(o.detach().numpy(), g.z[k]) for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs_s))
+    assert 1e-6 < shift_s < 0.5, shift_s
+
