@@ -49,10 +49,6 @@ SIGNATURES = {
     "ggpm_gru_backward_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_gru_backward": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                               P, I, P, I, P, P, I, P, c_size_t, I, P]),
-    "ggpm_csr_table4": (I, [P, P, I, P, P]),
-    "ggpm_gru_forward_tab": (I, [I, I, I, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, P]),
-    "ggpm_gru_backward_tab": (I, [I, I, I, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                  P, I, P, I, P, P, I, P, c_size_t, I, P]),
     "ggpm_gru_weight_grads": (I, [I, I, I, P, P, P, P, c_size_t, P, I, P, I, P, P, I, P]),
     "ggpm_gru_sparse_forward": (I, [I, I, I, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "ggpm_gru_sparse_backward": (I, [I, I, I, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,

@@ -40,7 +40,6 @@ struct Csr {
     int32_t *rowptr, *col;
     int rows, ncols, cap;
     int32_t *rowptrT, *colT, *cursor;
-    int32_t *tab, *tabT;          // 4-entry neighbour tables of the CSR / its transpose (pred levels only)
 };
 
 struct LevelSaved {
@@ -103,8 +102,6 @@ void take_csr(Arena& A, Csr& c, int rows, int ncols, int cap) {
     c.rowptrT = A.take<int32_t>(ncols + 1);
     c.colT = A.take<int32_t>(c.cap);
     c.cursor = A.take<int32_t>(ncols);
-    c.tab = A.take<int32_t>((size_t)rows * 4);
-    c.tabT = A.take<int32_t>((size_t)ncols * 4);
 }
 
 void take_level(Arena& A, LevelSaved& L, int E1, int N1, int Hp, int H, int depth, bool lstm) {
@@ -133,7 +130,6 @@ void layout_saved(Arena& A, const Dims& d, Saved& s) {
         c.rows = rows; c.ncols = ncols; c.cap = rows;
         c.rowptr = s.iota; c.col = nullptr;
         c.rowptrT = A.take<int32_t>(ncols + 1); c.colT = A.take<int32_t>(rows); c.cursor = A.take<int32_t>(ncols);
-        c.tab = c.tabT = nullptr;
     };
     take_index(s.tsrc, d.E1t, d.N1t);
     take_index(s.root, d.B, d.N1t);
@@ -167,11 +163,6 @@ inline int lbo(bool lstm, int level) { return lstm ? lq(level, Q_BO) : lp(level,
 
 // GGPM_SPLIT_TAIL=0: the input-half gradients of the last level behind its tall contractions on the second stream again
 inline bool split_tail_enabled() { static const bool v = !(ggpm_dev_env("GGPM_SPLIT_TAIL") && atoi(ggpm_dev_env("GGPM_SPLIT_TAIL")) == 0); return v; }
-inline bool use_tables() {
-    static const bool on = ggpm_dev_env("GGPM_TABLES") != nullptr && atoi(ggpm_dev_env("GGPM_TABLES")) != 0;   // opt-in: measured slower
-    return on;
-}
-
 // ---- launch worker of the second stream -----------------------------------------------------------------------------------
 // A step issues ~285 launches, ~90 of them on the second stream (index transposes beside the forward, every weight-gradient
 // contraction of the backward).  They are independent of what the calling thread issues next, so a worker thread issues
@@ -354,8 +345,8 @@ int level_forward(const Dims& d, int E1, int N1, int I, int depth, const float* 
     CK(ggpm_gemm_grouped(0, 1, E1, H, I, 3, gp, s));          // the three input projections in one launch
     const size_t ds = (size_t)depth * slot;
     ggpm_forward_run_depth(run);
-    CK(ggpm_gru_forward_tab(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
-                            P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col, use_tables() ? pred.tab : nullptr,
+    CK(ggpm_gru_forward(E1, H, depth, L.X, L.X + slot, L.X + 2 * slot, Wz + I, I + H, P[lp(level, L_UR)], H,
+                            P[lp(level, L_BU)], Wh + I, I + H, pred.rowptr, pred.col,
                             L.Hs, L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, L.wpack, 1, s));
     CK(replicate_tail(d, E1, depth, run, level, L, s));
     CK(ggpm_segment_sum(L.Hs + (size_t)depth * slot, Hp, agr.rowptr, agr.col, N1, H, L.nei, Hp, 0, Hp, s));
@@ -411,7 +402,6 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
     }
     CK(ggpm_padded_to_csr(gbgraph, d.E1g, d.Kgb, S.gpred.rowptr, S.gpred.col, stream));
     CK(ggpm_padded_to_csr(gagraph, d.N1g, d.Kga, S.gagr.rowptr, S.gagr.col, stream));
-    if (use_tables()) CK(ggpm_csr_table4(S.gpred.rowptr, S.gpred.col, d.E1g, S.gpred.tab, stream));
     hipEvent_t ev_atom = nullptr, ev_tree = nullptr;
     if (side_stream) {
         ev_atom = ggpm_wgrad_event(54);
@@ -425,7 +415,6 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
         CK(ggpm_padded_to_csr(tbgraph, d.E1t, d.Ktb, S.tpred.rowptr, S.tpred.col, ts));
         CK(ggpm_padded_to_csr(tagraph, d.N1t, d.Kta, S.tagr.rowptr, S.tagr.col, ts));
         CK(ggpm_padded_to_csr(tcgraph, d.N1t, d.Ktc, S.tcgr.rowptr, S.tcgr.col, ts));
-        if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptr, S.tpred.col, d.E1t, S.tpred.tab, ts));
         CK(ggpm_extract_column(tfmess, d.E1t, 4, 0, S.src, ts));
         CK(ggpm_extract_column(tfmess, d.E1t, 4, 2, S.attr0, ts));
         CK(ggpm_extract_column(tfnode, d.N1t, 2, 0, S.motif_id, ts));
@@ -447,10 +436,8 @@ extern "C" int ggpm_encoder_forward(const ggpm_enc_dims* dims, float* const* par
             (void)hipStreamWaitEvent((hipStream_t)side_stream, ev_atom, 0);     // the atom CSRs, for their transposes
         }
         CK(transpose(S.gpred, nullptr, ts));
-        if (use_tables()) CK(ggpm_csr_table4(S.gpred.rowptrT, S.gpred.colT, d.E1g, S.gpred.tabT, ts));
         CK(transpose(S.gagr, nullptr, ts));
         CK(transpose(S.tpred, nullptr, ts));
-        if (use_tables()) CK(ggpm_csr_table4(S.tpred.rowptrT, S.tpred.colT, d.E1t, S.tpred.tabT, ts));
         CK(transpose(S.tagr, nullptr, ts));
         CK(transpose(S.tcgr, nullptr, ts));
         CK(transpose(S.tsrc, S.src, ts));
@@ -686,8 +673,8 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     float *dWz = G[lp(level, L_WZ)], *dWr = G[lp(level, L_WR)], *dWh = G[lp(level, L_WH)], *dUr = G[lp(level, L_UR)];
     ggpm_backward_lo_depth(blo);
     if (skip_xsum) ggpm_backward_skip_x_sums(1);
-    CK(ggpm_gru_backward_tab(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
-                             pred.rowptr, pred.col, pred.rowptrT, pred.colT, use_tables() ? pred.tabT : nullptr, L.Hs,
+    CK(ggpm_gru_backward(E1, H, depth, L.X + slot, Wz + I, I + H, P[lp(level, L_UR)], H, Wh + I, I + H,
+                             pred.rowptr, pred.col, pred.rowptrT, pred.colT, L.Hs,
                              L.Qs, L.St, L.St + ds, L.St + 2 * ds, L.St + 3 * ds, L.St + 4 * ds, dHD, dX, dX + slot,
                              dX + 2 * slot, dWz + I, I + H, dUr, H, G[lp(level, L_BU)], dWh + I, I + H, level_work,
                              w.level_work_bytes, 0, st.main));

@@ -228,31 +228,6 @@ extern "C" int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int
     return GGPM_OK;
 }
 
-namespace {
-// table[r] = the first four entries of CSR row r (0 = none); rows with more than four get table[r][3] = -1 and are
-// walked through the CSR instead.  One 16-byte load then replaces the rowptr -> col -> data chain of the gathers.
-__global__ void csr_table4_k(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int rows,
-                             int32_t* __restrict__ table) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const int lo = rowptr[r], n = rowptr[r + 1] - lo;
-    int v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = k < n ? col[lo + k] : 0;
-    if (n > 4) v[3] = -1;
-    *reinterpret_cast<int4*>(table + (size_t)r * 4) = make_int4(v[0], v[1], v[2], v[3]);
-}
-}  // namespace
-
-extern "C" int ggpm_csr_table4(const int32_t* rowptr, const int32_t* col, int rows, int32_t* table,
-                               ggpm_stream_t stream) {
-    GGPM_CLEAR_STALE_ERROR();
-    if (!rowptr || !col || !table || rows <= 0) return GGPM_ERR_ARG;
-    csr_table4_k<<<ggpm_ceil_div(rows, 256), 256, 0, (hipStream_t)stream>>>(rowptr, col, rows, table);
-    GGPM_CHECK_LAUNCH();
-    return GGPM_OK;
-}
-
 extern "C" int ggpm_extract_column(const int64_t* mat, int rows, int width, int column, int32_t* out,
                                    ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();

@@ -129,7 +129,6 @@ struct GruFwdArgs {
     const unsigned char* frozen;   // sparse_forward only: rows with frozen[row] != 0 keep their state (h' = h)
     int fuse_b;                    // single column group: kernel A also forms q' = U_r h' + b_u (no B launch)
     unsigned long long* dbg;       // optional phase stamps of workgroup (0,0) (GGPM_ADEBUG; dev only)
-    const int32_t* ptab;           // optional 4-entry predecessor table (ggpm_csr_table4)
     int bf16;                      // gate mode: 0 fp32 MFMA, 1 bf16 operands (packed weights are bf16 fragments), 2 fp32 on
                                    // split operands (three bf16 planes per operand, tile_mma.h)
     int st16;                      // bf16 storage of Hs / Qs / S / G / Z / M (gate mode 1, large dense training levels; tile_mma.h)
@@ -181,11 +180,8 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
     // ---- P1: gather
     for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
         const int row = r0 + lr;
-        bool fast;
-        const int tchunk = ggpm_table_chunk(a.ptab, row, a.E1, lane, fast);
         GgpmRowList rl;
-        if (a.h0_zero) { rl.lo = 0; rl.n = 0; }
-        else if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
+        if (a.h0_zero) { rl.lo = 0; rl.n = 0; } else rl = ggpm_row_list(a.rowptr, row, a.E1);
         if (a.ablate & 1) rl.n = 0;
         const size_t rowo = (size_t)(row < a.E1 ? row : 0) * Hp;
         for (int c0 = 0; c0 < Hp; c0 += 512) {
@@ -201,7 +197,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
                 xr[k] = ggpm_ld4(a.Xr + rowo + cs[k]);
             }
             for (int base = 0; base < rl.n; base += 64) {
-                const int chunk = fast ? tchunk : ggpm_list_chunk(a.col, rl, base, lane);
+                const int chunk = ggpm_list_chunk(a.col, rl, base, lane);
                 const int m = min(64, rl.n - base);
                 for (int j = 0; j < m; j += GGPM_GATHER_U) {
                     float4 h[GGPM_GATHER_U][2], q[GGPM_GATHER_U][2];
@@ -433,7 +429,6 @@ struct GruBwdArgs {
     float* scat_h;                 // ggpm_backward_scatter_state: the final pass ADDS row r's result to
     const int32_t* scat_idx;       // scat_h[scat_idx[r]] (unique ids; < 0: dropped) instead of writing dHin
     int fuse_b;                    // single column group: kernel A also forms dS, dG for depth t-1 (no B launch)
-    const int32_t* stab;           // optional 4-entry successor table (ggpm_csr_table4)
     unsigned long long* dbg;       // optional phase stamps (GGPM_ADEBUG; dev only)
     int bf16;                      // gate products on bf16 operands
     int skip_xsum;                 // dXz / dXh are NOT accumulated here: the caller sums the DZP / DMP stash slots afterwards
@@ -471,10 +466,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
     if (!a.first) {
         for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
             const int p = r0 + lr;
-            bool fast;
-            const int tchunk = ggpm_table_chunk(a.stab, p, a.E1, lane, fast);
-            GgpmRowList rl;
-            if (fast) { rl.lo = 0; rl.n = 4; } else rl = ggpm_row_list(a.srowptr, p, a.E1);
+            const GgpmRowList rl = ggpm_row_list(a.srowptr, p, a.E1);
             const size_t po = (size_t)(p < a.E1 ? p : 0) * Hp;
             for (int c0 = 0; c0 < Hp; c0 += 512) {
                 int c[2], cs[2];
@@ -490,7 +482,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
                     qp[k] = ggpm_ldx<ST16>(a.Qcur, po + cs[k]);
                 }
                 for (int base = 0; base < rl.n; base += 64) {
-                    const int chunk = fast ? tchunk : ggpm_list_chunk(a.scol, rl, base, lane);
+                    const int chunk = ggpm_list_chunk(a.scol, rl, base, lane);
                     const int m = min(64, rl.n - base);
                     for (int j = 0; j < m; j += 2) {
                         float4 xr[2][2], dg[2][2], ds[2][2];
@@ -987,7 +979,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
                             const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
                             float* Hs, float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs,
                             float* wpack, int save_for_backward, const float* h_in, const unsigned char* frozen,
-                            ggpm_stream_t stream, const int32_t* pred_tab = nullptr) {
+                            ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Xz || !Xr || !Xh || !Wz_h || !Ur || !bu || !Wh_h || !pred_rowptr ||
@@ -1041,7 +1033,6 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
         a.Wz = pWz; a.Wh = pWh; a.Ur = pUr; a.bu = pbu; a.rowptr = pred_rowptr; a.col = pred_col;
         a.ablate = abl ? atoi(abl) : 0;
         a.frozen = frozen;
-        a.ptab = pred_tab;
         a.bf16 = bf16;
         a.st16 = st16 ? 1 : 0;
         a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
@@ -1072,16 +1063,6 @@ extern "C" int ggpm_gru_forward(int E1, int H, int depth, const float* Xz, const
                                 ggpm_stream_t stream) {
     return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
                             Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, nullptr, nullptr, stream);
-}
-
-// ggpm_gru_forward / ggpm_gru_backward with the optional 4-entry neighbour tables of ggpm_csr_table4 (null = CSR walk)
-extern "C" int ggpm_gru_forward_tab(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
-                                    const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
-                                    const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
-                                    const int32_t* pred_tab, float* Hs, float* Qs, float* Ss, float* Gs, float* Zs,
-                                    float* Ms, float* Rs, float* wpack, int save_for_backward, ggpm_stream_t stream) {
-    return gru_forward_impl(E1, H, depth, Xz, Xr, Xh, Wz_h, ld_wz, Ur, ld_ur, bu, Wh_h, ld_wh, pred_rowptr, pred_col,
-                            Hs, Qs, Ss, Gs, Zs, Ms, Rs, wpack, save_for_backward, nullptr, nullptr, stream, pred_tab);
 }
 
 extern "C" int ggpm_gru_sparse_forward(int E1, int H, int depth, const float* h_in, const unsigned char* frozen,
@@ -1129,8 +1110,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr, float* dXh,
                                  float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
                                  int ld_dwh, float* work, size_t work_bytes, int weight_grads,
-                                 const unsigned char* frozen, float* dHin, ggpm_stream_t stream,
-                                 const int32_t* succ_tab = nullptr) {
+                                 const unsigned char* frozen, float* dHin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen;
@@ -1205,7 +1185,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
         a.DMP = ggpm_slot_ptr(DMP, t - 1, slot, st16); a.DZP = ggpm_slot_ptr(DZP, t - 1, slot, st16); a.DSD = DSD;
         a.dXz = dXz; a.dXr = dXr; a.dXh = dXh;
         a.WzT = pWzT; a.WhT = pWhT; a.UrT = pUrT; a.bf16 = bf16;
-        a.srowptr = succ_rowptr; a.scol = succ_col; a.stab = succ_tab;
+        a.srowptr = succ_rowptr; a.scol = succ_col;
         a.skip_xsum = skip_xsum ? 1 : 0;
         launch_bwd(a, t > 1 || frozen != nullptr, flops1, s);     // (the dS/dG launch of step lo > 1 still forms dXr)
     }
@@ -1239,20 +1219,6 @@ extern "C" int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, cons
     return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
                              succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
                              dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream);
-}
-
-extern "C" int ggpm_gru_backward_tab(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz,
-                                     const float* Ur, int ld_ur, const float* Wh_h, int ld_wh,
-                                     const int32_t* pred_rowptr, const int32_t* pred_col,
-                                     const int32_t* succ_rowptr, const int32_t* succ_col, const int32_t* succ_tab,
-                                     const float* Hs, const float* Qs, const float* Ss, const float* Gs, const float* Zs,
-                                     const float* Ms, const float* Rs, const float* dHD, float* dXz, float* dXr,
-                                     float* dXh, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
-                                     float* dWh_h, int ld_dwh, float* work, size_t work_bytes, int weight_grads,
-                                     ggpm_stream_t stream) {
-    return gru_backward_impl(E1, H, depth, Xr, Wz_h, ld_wz, Ur, ld_ur, Wh_h, ld_wh, pred_rowptr, pred_col, succ_rowptr,
-                             succ_col, Hs, Qs, Ss, Gs, Zs, Ms, Rs, dHD, dXz, dXr, dXh, dWz_h, ld_dwz, dUr, ld_dur, dbu,
-                             dWh_h, ld_dwh, work, work_bytes, weight_grads, nullptr, nullptr, stream, succ_tab);
 }
 
 // sparse_forward backward: additionally returns dHin (gradient of the incoming state; zero on the recomputed rows)

@@ -505,17 +505,6 @@ __device__ __forceinline__ int ggpm_list_chunk(const int32_t* __restrict__ col, 
     return (base + lane < r.n) ? col[r.lo + base + lane] : 0;
 }
 
-// Optional 4-entry neighbour table (ggpm_csr_table4): lanes 0..3 load the row's entries with one 16-byte access that
-// does not depend on rowptr; `fast` (wave uniform) tells whether the row fits the table.
-__device__ __forceinline__ int ggpm_table_chunk(const int32_t* __restrict__ table, int row, int rows, int lane,
-                                                bool& fast) {
-    fast = false;
-    if (!table) return 0;
-    const int v = lane < 4 ? table[(size_t)(row < rows ? row : 0) * 4 + lane] : 0;
-    fast = __builtin_amdgcn_readlane(v, 3) >= 0;
-    return v;
-}
-
 __device__ __forceinline__ int ggpm_list_at(int chunk, int j, int m) {
     return (j < m) ? __builtin_amdgcn_readlane(chunk, j) : 0;
 }

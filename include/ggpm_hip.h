@@ -62,9 +62,6 @@ int ggpm_padded_to_csr(const int64_t* padded, int rows, int width, int32_t* rowp
 int ggpm_csr_transpose(const int32_t* rowptr, const int32_t* col, int rows, int ncols,
                        int32_t* rowptrT, int32_t* colT, int32_t* cursor, ggpm_stream_t stream);
 /* out[r] = (int32) mat[r*width + column]   (e.g. fmess[:,0], fnode[:,1]) */
-/* table[r][0..3] = first four entries of CSR row r (0 = none; table[r][3] = -1 when the row has more than four and must
- * be walked through the CSR): lets the depth kernels fetch a row's neighbours with one 16-byte load. int32[rows*4]. */
-int ggpm_csr_table4(const int32_t* rowptr, const int32_t* col, int rows, int32_t* table, ggpm_stream_t stream);
 int ggpm_extract_column(const int64_t* mat, int rows, int width, int column, int32_t* out,
                         ggpm_stream_t stream);
 
@@ -222,20 +219,6 @@ int ggpm_gru_backward(int E1, int H, int depth, const float* Xr, const float* Wz
                       int weight_grads, ggpm_stream_t stream);
 /* The weight-gradient tail of ggpm_gru_backward (called with weight_grads = 0) as its own entry point, so the
  * host may enqueue it on a second stream beside the next level's depth loop. Same `work` buffer. */
-/* ggpm_gru_forward / ggpm_gru_backward with optional neighbour tables (ggpm_csr_table4 of the predecessor resp.
- * successor CSR; null = walk the CSR as the plain entry points do). */
-int ggpm_gru_forward_tab(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh, const float* Wz_h,
-                         int ld_wz, const float* Ur, int ld_ur, const float* bu, const float* Wh_h, int ld_wh,
-                         const int32_t* pred_rowptr, const int32_t* pred_col, const int32_t* pred_tab, float* Hs,
-                         float* Qs, float* Ss, float* Gs, float* Zs, float* Ms, float* Rs, float* wpack,
-                         int save_for_backward, ggpm_stream_t stream);
-int ggpm_gru_backward_tab(int E1, int H, int depth, const float* Xr, const float* Wz_h, int ld_wz, const float* Ur,
-                          int ld_ur, const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
-                          const int32_t* succ_rowptr, const int32_t* succ_col, const int32_t* succ_tab, const float* Hs,
-                          const float* Qs, const float* Ss, const float* Gs, const float* Zs, const float* Ms,
-                          const float* Rs, const float* dHD, float* dXz, float* dXr, float* dXh, float* dWz_h, int ld_dwz,
-                          float* dUr, int ld_dur, float* dbu, float* dWh_h, int ld_dwh, float* work, size_t work_bytes,
-                          int weight_grads, ggpm_stream_t stream);
 int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs, float* work,
                           size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu,
                           float* dWh_h, int ld_dwh, ggpm_stream_t stream);

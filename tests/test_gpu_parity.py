@@ -860,6 +860,8 @@ def _bf16_case(case):
     if case.startswith(("cfg", "tiny")):
         g = Golden(case)
         return (lambda: _build_encoder(g)), g.numpy_tensors(), g.H, g.rnn, (g.depthT, g.depthG), g.params
+    if case == "storage_gru_h300_d6":      # >= 6144 atom-level messages: that level keeps its depth-loop arrays in bf16 ("bf16s")
+        return _seeded_encoder_case("GRU", 300, 6, synth.random_batch(607, 80, motifs=(8, 12), n_motif_vocab=60, n_attach_vocab=180))
     rnn, depth = ("LSTM", 30) if "lstm" in case else ("GRU", 10)
     return _seeded_encoder_case(rnn, 600, depth, synth.random_batch(606, 3, motifs=(46, 58), n_motif_vocab=60, n_attach_vocab=180))
 
@@ -978,15 +980,18 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
         assert e <= BF16_STEP_TOL and e <= max(shift[k] / 3.0, 2e-5), (k, e, shift[k])
 
 
-@pytest.mark.parametrize("case", ["tiny_gru_s1", "cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10"])
+@pytest.mark.parametrize("case", ["tiny_gru_s1", "cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10",
+                                  "storage_gru_h300_d6"])
 def test_bf16_gate_products_match_the_bf16_oracle(case):
     """BASELINE configs[4] names bf16: ``encoder.gate_dtype = "bf16"`` runs the H x H gate products of the depth loops
     on v_mfma_f32_16x16x32_bf16 -- operands rounded to bf16 (RNE), fp32 accumulate -- and (round 3) the tall
     weight-gradient contractions on bf16 operands as well; state, gate math and input projections stay fp32.
     Checked end to end, at full depth, against oracle/ref_encoder.py with the SAME operands rounded at the SAME points
     (the reference's cells, ggpm/rnn.py:27-36, 88-91): outputs, KL and EVERY parameter gradient within BF16_TOL = 2e-3
-    norm-wise -- or, where the recurrence itself amplifies rounding, within 0.5 x the distance between the bf16 and the
-    fp32 arithmetic of the same tensor class.  Why a second clause: a rounding is a discontinuity.  Two evaluations
+    norm-wise -- or, where the recurrence itself amplifies rounding, within 0.1 x (outputs) / 0.4 x (gradients) the distance
+    between the bf16 and the fp32 arithmetic of the same tensor class (measured, round 4: at most 0.07 x / 0.32 x; round 3
+    allowed 0.5 x for both).  ``storage_gru_h300_d6``: a batch whose atom level (>= 6144 messages) also keeps the arrays of its
+    depth loop in bf16 (oracle mode "bf16s").  Why a second clause: a rounding is a discontinuity.  Two evaluations
     that agree to 1e-7 round a few operands the other way; each such flip is a 2^-9 perturbation like the ones that
     separate bf16 from fp32 arithmetic, and a recurrence that amplifies those (the sum-aggregating GRU over 20-30 depths:
     bf16 -> fp32 distance 0.08-0.16 here, see test_configs4_polymer_shard_matches_oracle) amplifies the flips too and makes
@@ -998,8 +1003,10 @@ def test_bf16_gate_products_match_the_bf16_oracle(case):
           "arithmetic: outputs %.2e, gradients %.2e" % (case, "/".join(modes.values()), err_o, errs_g[worst_k], worst_k,
                                                          shift_o, shift_g))
     assert shift_o > 1e-6                    # the bf16 path really ran
-    assert err_o <= max(BF16_TOL, 0.5 * shift_o), (err_o, shift_o)
-    assert errs_g[worst_k] <= max(BF16_TOL, 0.5 * shift_g), (worst_k, errs_g[worst_k], shift_g)
+    if case.startswith("storage"):
+        assert modes["graph_encoder."] == "bf16s", modes
+    assert err_o <= max(BF16_TOL, 0.1 * shift_o), (err_o, shift_o)
+    assert errs_g[worst_k] <= max(BF16_TOL, 0.4 * shift_g), (worst_k, errs_g[worst_k], shift_g)
 
 
 @pytest.mark.parametrize("name", ["cfg_gru_s0", "cfg_lstm_s2", "tiny_gru_s1", "edge_gru_s32"])
@@ -1394,24 +1401,3 @@ def test_softmax_ce_and_bce_kernels_against_torch(M, N, masked):
     assert float((s.grad - s2.grad).abs().max()) <= 2e-6
 
 
-def test_csr_table4():
-    """ggpm_csr_table4 (first four entries, overflow marker) vs numpy."""
-    import ctypes
-    from ggpm_amd import _lib, synth, functional as F_
-    dev = _dev()
-    specs = synth.random_batch(3, 7, motifs=(3, 9), n_motif_vocab=11, n_attach_vocab=33)
-    tree, graph = synth.tensorize(specs)
-    bg = torch.from_numpy(graph[3].astype(np.int64)).to(dev)
-    E1 = bg.shape[0]
-    csr = F_.csr_from_padded(bg, ncols=E1)
-    lib = _lib.load()
-    tab = torch.empty(E1, 4, dtype=torch.int32, device=dev)
-    _lib.check(lib.ggpm_csr_table4(F_._p(csr.rowptr), F_._p(csr.col), E1, F_._p(tab), F_._stream()), "csr_table4")
-    pad = graph[3]
-    got = tab.cpu().numpy()
-    for r in range(E1):
-        ent = [int(v) for v in pad[r] if v != 0]
-        exp = (ent + [0, 0, 0, 0])[:4]
-        if len(ent) > 4:
-            exp[3] = -1
-        assert list(got[r]) == exp
