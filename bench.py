@@ -476,6 +476,7 @@ class VaeWorkload:
         mark("gradients packed")
         self.opt.step()
         mark("optimizer issued")
+        self._issued_at = time.perf_counter()      # everything of this step has been handed to the GPU (or to the worker)
         metrics["Loss"]      # the training loop reads the metrics here (vae_train.py:86): one host read-back per step
         return metrics
 
@@ -526,10 +527,12 @@ class VaeWorkload:
         _settle_gc()
         self._fence()
         t0 = time.perf_counter()
-        marks = [t0]
+        marks, issue = [t0], []
         for i in range(steps):
             fn(first + i)                     # (ends with the metrics' host read: the host is in step with the GPU)
+            issue.append(1e3 * (self._issued_at - marks[-1]))
             marks.append(time.perf_counter())
+        self.host_issue_ms = float(np.median(issue)) if issue else None      # host time to ISSUE one step (median)
         self._fence()
         dt = time.perf_counter() - t0
         if self.world > 1:
@@ -583,6 +586,7 @@ class VaeWorkload:
         for i in range(warm):
             m = self.step(i)
         ms, raw = self._timed(self.step, steps, warm)
+        host_issue = self.host_issue_ms
         per = sorted(raw)
         log("full VAE step (%s): %.2f ms/step (per step: min %.2f, median %.2f, max %.2f at step %d; reserved %.1f GB), loss %.3f"
             % (self.rnn, ms, per[0], per[len(per) // 2], per[-1], raw.index(per[-1]), torch.cuda.memory_reserved() / 1e9,
@@ -610,6 +614,7 @@ class VaeWorkload:
         for i in range(len(self.items)):
             self.step_in_loop(i)
         loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0)
+        loop_issue = self.host_issue_ms
         # ... and with the loop's iterator wrapped (dataloader.ScheduleAhead): the schedule of batch k+1 built during step k
         self._ahead = None
         for i in range(len(self.items)):
@@ -629,9 +634,11 @@ class VaeWorkload:
         fl_exec, fl_alg = self.work()
         tf = fl_exec * self.world / (ms * 1e-3) / 1e12
         out = {"ms_per_step": round(ms, 3), "value": round(B * self.world / (ms * 1e-3), 2), "unit": "molecules/s",
+               "host_issue_ms": round(host_issue, 3),      # median host time from the start of a step to its last launch
                "ms_per_step_index_structures_rebuilt": round(fresh, 3),
                "schedule_in_loop": {"ms_per_step": round(loop_ms, 3), "value": round(B * self.world / (loop_ms * 1e-3), 2),
                                     "ratio_to_resident": round(loop_ms / ms, 3),
+                                    "host_issue_ms": round(loop_issue, 3),
                                     "host_schedule_build_ms": round(build_ms, 3),
                                     "what": "model(*batch, beta=beta) as vae_train.py:78: numpy tensors + networkx graphs in, "
                                             "make_cuda and DecodeSchedule.from_graphs (csrc/schedule.hip) inside the step"},
@@ -646,7 +653,7 @@ class VaeWorkload:
                             "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
                             "algorithmic_gflop_per_step_per_gpu": round(fl_alg / 1e9, 2),
                             "note": "whole-step figure: executed flops (every row the kernels process; fwd + bwd = 3 x fwd) over "
-                                    "the step time; the step is a chain of small dependent launches (profiles/r03_vae_*), "
+                                    "the step time; the step is a chain of small dependent launches (profiles/r04_vae_*), "
                                     "not one kernel"},
                "workload": "HierPropertyVAE fwd (perturb_z) + bwd%s + Adam on the configs[1] batches: latent=%d, diterT=%d, "
                            "diterG=%d, tie_embedding=%s, metrics read back on the host every step (after optimizer.step(), where "
@@ -655,7 +662,7 @@ class VaeWorkload:
                            "step); schedule_in_loop: nothing resident"
                            % (" + all-reduce" if self.world > 1 else "", self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}
         try:        # launches per step and per-kernel-class time from the committed rocprofv3 trace of `bench.py --only-vae`
-            with open(os.path.join(ROOT, "profiles", "r03_vae_launches.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_vae_launches.json")) as f:
                 lj = json.load(f)
             out["launches_per_step"] = lj.get(self.rnn, {}).get("launches_per_step")
             out["kernel_classes"] = lj.get(self.rnn, {}).get("classes")
@@ -926,7 +933,7 @@ def main():
             if a.rnn is None and not a.no_second_cell:          # the LSTM leg of the same row
                 vl = VaeWorkload(cfg, "LSTM", a, dev, rank, world)
                 ml = vl.measure()
-                result["vae_step"]["lstm"] = {k: ml[k] for k in ("ms_per_step", "value", "unit", "schedule_in_loop",
+                result["vae_step"]["lstm"] = {k: ml[k] for k in ("ms_per_step", "value", "unit", "host_issue_ms", "schedule_in_loop",
                                                                  "schedule_ahead", "ms_per_step_index_structures_rebuilt", "roofline",
                                                                  "launches_per_step") if k in ml}
                 del vl

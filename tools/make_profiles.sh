@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ on a GPU box (run from the repo root through gpurun; writes gpurun_out/<tag>/).
-#   bash tools/make_profiles.sh r03p
+#   bash tools/make_profiles.sh r04p
 # rocprofv3 runs the program itself (python3 bench.py ...), never through env / bash -c; PMC passes are separate runs.
 set -u
-TAG=${1:-r03p}
+TAG=${1:-r04p}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
-QUICK="--no-vae --no-cpu-baseline --no-second-cell --no-full-depth --no-roofline --steps 20"
+QUICK="--no-vae --no-cpu-baseline --no-second-cell --no-full-depth --no-roofline --no-configs4 --steps 20"
 
 python3 $B > $OUT/bench_default.json 2> $OUT/bench_default.log
 python3 $B --config 4 --no-cpu-baseline > $OUT/bench_config4.json 2> $OUT/bench_config4.log
@@ -39,9 +39,16 @@ cd /tmp
 for C in GRU LSTM; do
   for CTR in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${C}_$CTR
-    rocprofv3 --pmc $CTR --output-format csv -d /tmp/pmc_${C}_$CTR -- python3 $B --no-vae --no-cpu-baseline --no-second-cell --no-full-depth --no-roofline --steps 3 --warmup 1 --rnn $C > $OUT/pmc_${C}_$CTR.log 2>&1
+    rocprofv3 --pmc $CTR --output-format csv -d /tmp/pmc_${C}_$CTR -- python3 $B --no-vae --no-cpu-baseline --no-second-cell --no-full-depth --no-roofline --no-configs4 --steps 3 --warmup 1 --pool 3 --rnn $C > $OUT/pmc_${C}_$CTR.log 2>&1
   done
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_${C}_FETCH_SIZE /tmp/pmc_${C}_WRITE_SIZE 20 > $OUT/${C}_pmc_hbm_traffic.txt 2>&1
+done
+
+# SQ counters of the depth kernels (one PMC pass, no tracing)
+for C in GRU LSTM; do
+  rm -rf /tmp/pmc_sq_$C
+  rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d /tmp/pmc_sq_$C -- python3 $B --no-vae --no-cpu-baseline --no-second-cell --no-full-depth --no-roofline --no-configs4 --steps 3 --warmup 1 --pool 3 --rnn $C > $OUT/pmc_sq_$C.log 2>&1
+  python3 $ROOT/tools/pmc_sq.py /tmp/pmc_sq_$C $(echo $C | tr A-Z a-z)_ > $OUT/${C}_sq_counters.txt 2>&1
 done
 
 cd $ROOT
