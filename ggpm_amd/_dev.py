@@ -17,6 +17,7 @@ DECODE_DRIVER = True       # the two step loops as one C call each (csrc/decode.
 ATOM_ASYNC = True          # ... issued by a worker thread of the library (ggpm_decode_steps_*_async)
 PACK_ONCE = True           # the decode steps share one packed weight set (False: every step packs again)
 TREE_COMPOSITE = True      # each tree-side decoder level as one autograd node (False: op by op)
+TREE_DRIVER = True         # ... whose two directions are one C call each (csrc/tree_level.hip; False: ~30 ctypes calls)
 ENC_NARROW = True          # the encoder's levels take two row tiles per workgroup while they run beside the atom-level chain
 
 # ---- gradients (functional.py, parallel.py, optim.py)

@@ -12,7 +12,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libggpm_hip.so")
-SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gather.hip", "mpn_gru.hip", "mpn_lstm.hip", "encoder.hip", "losses.hip", "decode.hip", "schedule.hip"]
+SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gather.hip", "mpn_gru.hip", "mpn_lstm.hip", "encoder.hip", "losses.hip", "decode.hip", "tree_level.hip", "schedule.hip"]
 HEADERS = ["common.h", "tile_mma.h", os.path.join("..", "..", "include", "ggpm_hip.h")]
 ARCH = "gfx950"
 

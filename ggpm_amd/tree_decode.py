@@ -238,6 +238,151 @@ class _TreeLevel(torch.autograd.Function):
         return (None, None, None, None, d_lower, d_extra) + (None,) * len(ctx.prm)
 
 
+class TreeLevelC(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_tree_level"""
+    _fields_ = ([(k, ctypes.c_int) for k in ("lstm", "H", "He", "E1", "n_extra", "depth", "n_inst")] +
+                [(k, ctypes.c_void_p) for k in ("ids", "mess_inst", "mess_pos", "frozen", "pred_rowptr", "pred_col",
+                                                "succ_rowptr", "succ_col", "in_rowptr", "in_col", "inT_rowptr", "inT_col",
+                                                "srcT_rowptr", "srcT_col")] +
+                [("emb", ctypes.c_void_p), ("ld_emb", ctypes.c_int), ("W", ctypes.c_void_p), ("b", ctypes.c_void_p),
+                 ("ld_w", ctypes.c_int), ("Wo", ctypes.c_void_p), ("bo", ctypes.c_void_p), ("ld_wo", ctypes.c_int),
+                 ("gate_w", ctypes.c_void_p * 4), ("ld_gate", ctypes.c_int * 4), ("gate_b", ctypes.c_void_p * 4),
+                 ("Ur", ctypes.c_void_p), ("bu", ctypes.c_void_p), ("ld_ur", ctypes.c_int),
+                 ("lower", ctypes.c_void_p), ("ld_lower", ctypes.c_int), ("extra", ctypes.c_void_p), ("ld_extra", ctypes.c_int)])
+
+
+class TreeLevelViews(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_tree_level_views"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("finput", "hnode", "hmess", "X", "hp", "cp", "Hs", "Cs", "Qs", "St", "wpack",
+                                               "nei", "node")]
+
+
+class TreeLevelGrads(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_tree_level_grads"""
+    _fields_ = [("dgate_w", ctypes.c_void_p * 4), ("ld_dgate", ctypes.c_int * 4), ("dgate_b", ctypes.c_void_p * 4),
+                ("dUr", ctypes.c_void_p), ("dbu", ctypes.c_void_p), ("dpre_w", ctypes.c_void_p), ("dpre_o", ctypes.c_void_p),
+                ("d_finput", ctypes.c_void_p), ("d_lower", ctypes.c_void_p), ("ld_dlower", ctypes.c_int),
+                ("n_pad_dlower", ctypes.c_int), ("dHin", ctypes.c_void_p)]
+
+
+def _addr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class _TreeLevelNative(torch.autograd.Function):
+    """``_TreeLevel`` with each direction as ONE call into csrc/tree_level.hip (ggpm_tree_level_forward / _backward): the same
+    launches in the same order (bit-identical results), no per-launch ctypes marshalling and two allocations per direction."""
+
+    @staticmethod
+    def forward(ctx, S: LevelSpec, lstm: bool, H: int, He: int, lower, extra, emb, W, b, Wo, bo, *rp):
+        lib = _lib.load()
+        dev = lower.device
+        Hp = F_.padded_hidden(H)
+        frozen, pred, in_csr, src_csr = S.structures()
+        succ, in_T, src_T = pred.T, in_csr.T, src_csr.T
+        n_inst, Etot = S.ids.numel(), S.E1 + S.n_extra
+        if lstm:
+            Wi, bi, Wog, bog, Wu, bu_, Wf, bf = rp
+            gw, gb, Ur, bu = (Wi, Wog, Wu, Wf), (bi, bog, bu_, bf), None, None
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh = rp
+            gw, gb = (Wz, Wr, Wh), (bz, None, bh)
+        L = TreeLevelC()
+        L.lstm, L.H, L.He, L.E1, L.n_extra, L.depth, L.n_inst = int(lstm), H, He, S.E1, S.n_extra, S.depth, n_inst
+        for k, t in (("ids", S.ids), ("mess_inst", S.mess_inst), ("mess_pos", S.mess_pos), ("frozen", frozen),
+                     ("pred_rowptr", pred.rowptr), ("pred_col", pred.col), ("succ_rowptr", succ.rowptr), ("succ_col", succ.col),
+                     ("in_rowptr", in_csr.rowptr), ("in_col", in_csr.col), ("inT_rowptr", in_T.rowptr), ("inT_col", in_T.col),
+                     ("srcT_rowptr", src_T.rowptr), ("srcT_col", src_T.col)):
+            setattr(L, k, _addr(t))
+        L.emb, L.ld_emb = _addr(emb), F_._ld(emb)
+        L.W, L.b, L.ld_w = _addr(W), _addr(b), W.stride(0)
+        L.Wo, L.bo, L.ld_wo = _addr(Wo), _addr(bo), Wo.stride(0)
+        for k, (w, bb) in enumerate(zip(gw, gb)):
+            L.gate_w[k], L.ld_gate[k], L.gate_b[k] = _addr(w), w.stride(0), _addr(bb)
+        L.Ur, L.bu, L.ld_ur = _addr(Ur), _addr(bu), (Ur.stride(0) if Ur is not None else 0)
+        L.lower, L.ld_lower = _addr(lower), F_._ld(lower)
+        L.extra, L.ld_extra = _addr(extra), (F_._ld(extra) if extra is not None else 0)
+        n_saved = int(lib.ggpm_tree_level_saved_floats(ctypes.byref(L)))
+        saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+        V = TreeLevelViews()
+        _lib.check(lib.ggpm_tree_level_forward(ctypes.byref(L), F_._p(saved), n_saved, ctypes.byref(V), F_._stream()),
+                   "tree_level_forward")
+        base = saved.data_ptr()
+
+        def view(addr, rows, cols):
+            off = (addr - base) // 4
+            return saved[off:off + rows * cols].view(rows, cols)
+
+        Hep = F_.padded_hidden(He)
+        node = view(V.node, n_inst, Hp)
+        hid = view(V.Hs, (S.depth + 1) * Etot, Hp)[S.depth * Etot:]
+        ctx.S, ctx.meta = S, (lstm, H, He, extra is not None)
+        ctx.save_for_backward(lower, saved)
+        ctx.keep = (L, V, extra, (frozen, pred, succ, in_csr, in_T, src_csr, src_T))      # (the tables the descriptor names)
+        ctx.views = (view(V.finput, n_inst, Hep), view(V.hnode, n_inst, Hp), view(V.nei, n_inst, Hp))
+        ctx.prm = (emb, W, b, Wo, bo) + tuple(rp)
+        ctx.set_materialize_grads(False)
+        return node, hid
+
+    @staticmethod
+    def backward(ctx, d_node, d_hid):
+        lib = _lib.load()
+        S = ctx.S
+        lstm, H, He, has_extra = ctx.meta
+        lower, saved = ctx.saved_tensors
+        L, V, extra, _tables = ctx.keep
+        finput, hnode, nei = ctx.views
+        emb, W, b, Wo, bo = ctx.prm[:5]
+        rp = ctx.prm[5:]
+        dev = saved.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        Hp, Hep = F_.padded_hidden(H), F_.padded_hidden(He)
+        n_inst, Etot, E1 = S.ids.numel(), S.E1 + S.n_extra, S.E1
+        if lstm:
+            Wi, bi, Wog, bog, Wu, bu_, Wf, bf = rp
+            gw, gb = (Wi, Wog, Wu, Wf), (bi, bog, bu_, bf)
+        else:
+            Wz, bz, Wr, Ur, bu, Wh, bh = rp
+            gw, gb = (Wz, Wr, Wh), (bz, None, bh)
+        dgw = [torch.empty(w.shape, **f32) for w in gw]
+        dgb = [torch.empty(H, **f32) if bb is not None else None for bb in gb]
+        dUr = torch.empty(H, H, **f32) if not lstm else None
+        dbu = torch.empty(H, **f32) if not lstm else None
+        rows = torch.empty(2, n_inst, Hp, **f32)
+        dpre_w, dpre_o = rows[0], rows[1]
+        d_finput = torch.empty(n_inst, Hep, **f32)
+        dHin = torch.empty(Etot, Hp, **f32)
+        d_lower = F_._empty_same_layout(lower) if ctx.needs_input_grad[4] else None
+        g = TreeLevelGrads()
+        for k in range(len(gw)):
+            g.dgate_w[k], g.ld_dgate[k], g.dgate_b[k] = _addr(dgw[k]), dgw[k].stride(0), _addr(dgb[k])
+        g.dUr, g.dbu = _addr(dUr), _addr(dbu)
+        g.dpre_w, g.dpre_o, g.d_finput = _addr(dpre_w), _addr(dpre_o), _addr(d_finput)
+        g.d_lower = _addr(d_lower)
+        g.ld_dlower, g.n_pad_dlower = (F_._ld(d_lower), lower.shape[1]) if d_lower is not None else (0, 0)
+        g.dHin = _addr(dHin)
+        if d_node is not None:
+            d_node = d_node.contiguous()
+        if d_hid is not None:
+            d_hid = d_hid.contiguous()
+        wb = int(lib.ggpm_tree_level_work_bytes(ctypes.byref(L)))
+        work = torch.empty((wb + 3) // 4, **f32)
+        _lib.check(lib.ggpm_tree_level_backward(ctypes.byref(L), ctypes.byref(V), F_._p(d_node), F_._p(d_hid), ctypes.byref(g),
+                                                F_._p(work), work.numel() * 4, F_._stream()), "tree_level_backward")
+        if lstm:
+            pg = (dgw[0], dgb[0], dgw[1], dgb[1], dgw[2], dgb[2], dgw[3], dgb[3])
+        else:
+            pg = (dgw[0], dgb[0], dgw[1], dUr, dbu, dgw[2], dgb[2])
+        for q, gr in zip(rp, pg):
+            F_._defer_sum(q, gr)
+        F_._defer_linear(W, b, dpre_w, [finput, lower], (He, H))
+        F_._defer_linear(Wo, bo, dpre_o, [hnode, nei], (H, H))
+        F_._defer_gather(emb, He, d_finput, S.ids)
+        d_extra = dHin[E1:, :H] if (has_extra and ctx.needs_input_grad[5]) else None
+        ctx.keep = ctx.views = None
+        return (None, None, None, None, d_lower, d_extra) + (None,) * len(ctx.prm)
+
+
 def usable(modules, params) -> bool:
     """Dropout inactive on every module of the level, deferral on, parameters publishable."""
     if not enabled() or not F_.defer_wgrads_enabled():
@@ -258,5 +403,6 @@ def tree_level(S: LevelSpec, rnn, emb_seq, lin_seq, wo_seq, lower, extra: Option
         rp = (rnn.W_z.weight, rnn.W_z.bias, rnn.W_r.weight, rnn.U_r.weight, rnn.U_r.bias, rnn.W_h.weight, rnn.W_h.bias)
     emb = emb_seq[0].weight
     lower = lower if lower.stride(1) == 1 else lower.contiguous()
-    return _TreeLevel.apply(S, lstm, rnn.hidden_size, emb.shape[1], lower, extra, emb, lin_seq[0].weight, lin_seq[0].bias,
-                            wo_seq[0].weight, wo_seq[0].bias, *rp)
+    node_fn = _TreeLevelNative if _dev.TREE_DRIVER else _TreeLevel      # (the Python composite stays as the checker)
+    return node_fn.apply(S, lstm, rnn.hidden_size, emb.shape[1], lower, extra, emb, lin_seq[0].weight, lin_seq[0].bias,
+                         wo_seq[0].weight, wo_seq[0].bias, *rp)

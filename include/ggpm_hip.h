@@ -377,6 +377,57 @@ int ggpm_decode_steps_backward_async(const ggpm_decode_steps* steps, const float
                                      ggpm_stream_t stream);
 int ggpm_decode_join(void);
 
+/* ------------------------------------------------------------------ one tree-side level of the teacher-forced decoder
+ * IncHierMPNEncoder.embed_sub_tree + IncMPNEncoder.forward (ggpm/encoder.py:208-245, 165-179), which
+ * HierMPNDecoder.forward calls once per decode step (ggpm/decoder.py:201-222), for ALL steps at once over the decode-time
+ * DAG of the level's messages (ggpm_amd/decoder.py: DecodeSchedule._level_plan), as one call per direction:
+ *   finput = E[ids]; hnode = relu([finput | lower] W^T + b); hmess = [hnode[mess_inst] | onehot(mess_pos)];
+ *   h = sparse_forward(h0, hmess, all real messages, DAG, `depth` = longest chain); node = relu([hnode | sum_in h] W_o^T + b_o)
+ * E1 message rows (row 0 = pad) + n_extra frozen rows that carry `extra` (the motif level's pseudo-messages with the root
+ * vectors); n_inst visits.  Index tables int32 on the device: ids[n_inst], mess_inst / mess_pos[E1-1], frozen[E1+n_extra],
+ * pred_* / succ_* the DAG's CSR and its transpose over E1+n_extra rows, in_* the incoming-message CSR of every visit
+ * (n_inst rows) and inT_* its transpose (E1+n_extra rows), srcT_* the transpose of the message -> visit index (n_inst rows).
+ * gate_w / gate_b: GRU {W_z, W_r, W_h} ([H, H+20+H]; W_r [H, H+20], gate_b[1] = null) + Ur, bu; LSTM {W_i, W_o, W, W_f}.
+ * Dropout must be inactive (the caller falls back to the per-op entry points otherwise).
+ * forward: `saved` = ggpm_tree_level_saved_floats floats; on return `views` names the intermediates inside it (node
+ * [n_inst, Hp] and slot `depth` of Hs [E1+n_extra, Hp] are the level's two results).  backward: d_node / d_hid nullable;
+ * `grads` names caller-owned outputs -- full-shape gate weight gradients (both halves written), gate bias gradients
+ * (null where the gate has none), dUr / dbu (GRU), dpre_w / dpre_o [n_inst, Hp] and d_finput [n_inst, pad16(He)] for the
+ * caller's contractions of W, W_o and the embedding table, d_lower (nullable) and dHin [E1+n_extra, Hp] whose rows E1.. are
+ * d(extra); work: ggpm_tree_level_work_bytes. */
+typedef struct ggpm_tree_level {
+    int lstm, H, He, E1, n_extra, depth, n_inst;
+    const int32_t *ids, *mess_inst, *mess_pos;
+    const unsigned char* frozen;
+    const int32_t *pred_rowptr, *pred_col, *succ_rowptr, *succ_col;
+    const int32_t *in_rowptr, *in_col, *inT_rowptr, *inT_col;
+    const int32_t *srcT_rowptr, *srcT_col;
+    const float* emb; int ld_emb;
+    const float *W, *b; int ld_w;
+    const float *Wo, *bo; int ld_wo;
+    const float* gate_w[4]; int ld_gate[4]; const float* gate_b[4];
+    const float *Ur, *bu; int ld_ur;
+    const float* lower; int ld_lower;
+    const float* extra; int ld_extra;
+} ggpm_tree_level;
+typedef struct ggpm_tree_level_views {
+    float *finput, *hnode, *hmess, *X, *hp, *cp, *Hs, *Cs, *Qs, *St, *wpack, *nei, *node;
+} ggpm_tree_level_views;
+typedef struct ggpm_tree_level_grads {
+    float* dgate_w[4]; int ld_dgate[4]; float* dgate_b[4];
+    float *dUr, *dbu;
+    float *dpre_w, *dpre_o, *d_finput;
+    float* d_lower; int ld_dlower, n_pad_dlower;
+    float* dHin;
+} ggpm_tree_level_grads;
+size_t ggpm_tree_level_saved_floats(const ggpm_tree_level* level);
+size_t ggpm_tree_level_work_bytes(const ggpm_tree_level* level);
+int ggpm_tree_level_forward(const ggpm_tree_level* level, float* saved, size_t saved_floats, ggpm_tree_level_views* views,
+                            ggpm_stream_t stream);
+int ggpm_tree_level_backward(const ggpm_tree_level* level, const ggpm_tree_level_views* views, const float* d_node,
+                             const float* d_hid, const ggpm_tree_level_grads* grads, float* work, size_t work_bytes,
+                             ggpm_stream_t stream);
+
 /* ------------------------------------------------------------------ decoder score-head losses
  * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in
  * (ggpm/decoder.py:66-69,143-157,268-271): z[m,:] = logits[m,:] + mask[mask_row[m],:] (mask / mask_row both null for

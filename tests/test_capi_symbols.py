@@ -45,7 +45,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     from ggpm_amd.atom_decode import DecodeSteps
     from ggpm_amd.fused import EncDims
     from ggpm_amd.schedule_native import SchedIn
-    structs = {"ggpm_enc_dims": EncDims, "ggpm_decode_steps": DecodeSteps, "ggpm_sched_in": SchedIn}
+    from ggpm_amd.tree_decode import TreeLevelC, TreeLevelGrads, TreeLevelViews
+    structs = {"ggpm_enc_dims": EncDims, "ggpm_decode_steps": DecodeSteps, "ggpm_sched_in": SchedIn,
+               "ggpm_tree_level": TreeLevelC, "ggpm_tree_level_views": TreeLevelViews, "ggpm_tree_level_grads": TreeLevelGrads}
     lines = []
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

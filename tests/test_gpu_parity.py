@@ -1217,6 +1217,35 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
         g.check_grad(k, grad, rel=TOL)
 
 
+@pytest.mark.parametrize("name", ["vae_gru_s42", "vae_lstm_s43"])
+def test_tree_level_driver_is_bit_identical_to_the_python_composite(name, monkeypatch):
+    """csrc/tree_level.hip (ggpm_tree_level_forward / _backward: one C call per direction for each tree-side decoder level)
+    issues the launches of ggpm_amd/tree_decode.py::_TreeLevel in the same order from C++: loss and EVERY parameter gradient
+    of the full VAE step must be bit-identical between the two (fixtures with tied embeddings / latent != hidden)."""
+    from golden_utils import VaeGolden
+    from ggpm_amd import _dev as dev_settings, synth
+    from ggpm_amd.decoder import DecodeSchedule
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    g = VaeGolden(name)
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    res = []
+    for driver in (True, False):
+        monkeypatch.setattr(dev_settings, "TREE_DRIVER", driver)
+        model = HierPropertyVAE(g.args(IndexPairVocab(g.n_motif, g.n_attach))).to(_dev())
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()}, strict=False)
+        sch = DecodeSchedule.from_specs(specs, tensors)
+        loss, _ = model(None, None, tensors, [None] * g.B, None, None, beta=g.beta, perturb_z=False, schedule=sch)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert set(res[0][1]) == set(res[1][1])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 @pytest.mark.parametrize("rnn,H,L,depth,B,motifs,vocab,tie,seed", [
     ("GRU", 300, 32, 20, 32, (8, 12), (500, 1500), False, 4242),      # configs[1]: the bench workload's batch shape
     ("LSTM", 250, 24, 20, 20, (6, 14), (721, 6489), False, 77),       # configs[0]: the pretrained model's shape (9 attachments per motif)
