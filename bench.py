@@ -291,13 +291,20 @@ class Workload:
         # W untimed steps, and at least one pass over the pool: every batch shape has then been seen by the caching allocator,
         # on each of the package's streams -- a shape met for the first time inside the timed region costs a device allocation
         # there (measured with tools/step_jitter.py: 5 ms at configs[1] sizes, 250-300 ms at configs[4] sizes, in ONE step)
+        # ... and for at least a second of wall time: the first GPU process on a freshly acquired box ran its first timed region
+        # 10-60 % slow (3.2 / 4.8 ms per step where every later process measured 2.9) -- clocks, page cache, lazily loaded code
         warm = max(a.warmup, len(self.dev_batches))
-        self.warmup_run = warm
-        for i in range(warm):
+        t_warm, i = time.perf_counter(), 0
+        while i < warm or (time.perf_counter() - t_warm < 1.0 and i < 4000):
             self.step(i)
             if i == 0:
                 torch.cuda.synchronize()
                 log("first step done")
+            i += 1
+            if i >= warm and i % 8 == 0:
+                torch.cuda.synchronize()          # (the host runs ahead of the GPU: count GPU time, not enqueue time)
+        warm = i
+        self.warmup_run = warm
         log("warm-up done (%d steps); timing %d steps" % (warm, a.steps))
         elapsed, host_enqueue = self.timed(a.steps, warm)
         log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,

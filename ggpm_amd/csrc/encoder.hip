@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) replicate_slots_k(ReplicateArgs r) {
 // steps a tree-side level really has to run: chain + 1 (the step after the last change also fixes the stash)
 // (a level whose depth-loop arrays are kept in bf16 -- gate mode 1 on >= 6144 messages, tile_mma.h -- runs all its steps: the
 // replication below copies fp32 slots)
-inline bool bf16_stored(const Dims& d, int E1) { return d.gate_dtype == 1 && !d.lstm && ggpm_bf16_storage_applies(E1, d.H); }
+inline bool bf16_stored(const Dims& d, int E1) { return d.gate_dtype == 1 && ggpm_bf16_storage_applies(E1, d.H); }
 inline int run_steps(const Dims& d, int level, int depth, int E1) {
     static const bool off = ggpm_dev_env("GGPM_TREE_FIXED_POINT") && atoi(ggpm_dev_env("GGPM_TREE_FIXED_POINT")) == 0;
     if (off || level == 2 || bf16_stored(d, E1) || d.tree_chain <= 0 || d.tree_chain + 1 >= depth) return depth;
@@ -637,8 +637,10 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                 CK(ggpm_lstm_backward_stashes(level_work, E1, H, depth, &DI, &DO, &DU));
                 const int lo_ = blo < 1 ? 1 : blo;      // backward steps depth .. lo ran: stash slots lo-1 .. depth-1
                 float* const src[3] = {DI, DO, DU};
+                const bool b16 = bf16_stored(d, E1);    // (then lo_ == 1 and the stashes are bf16 in the first half of their buffers)
                 for (int k = 0; k < 3; ++k)
-                    CK(ggpm_sum_slots(src[k] + (size_t)(lo_ - 1) * slot, depth - lo_ + 1, slot, dX + (size_t)k * slot, sx));
+                    CK(ggpm_sum_slots_any(src[k] + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX + (size_t)k * slot,
+                                          b16, sx));
             }
             if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
                 GgpmGemmProblem gp[4];

@@ -28,6 +28,8 @@ struct LstmFwdArgs {
     int fuse_b;                      // single column group: kernel A also forms qf' = Wf_h h' (no B launch)
     int h0_zero;                     // first depth of a dense level: h^0 = c^0 = 0 -> no gather, no gate products
     int bf16;                        // gate products on bf16 operands (packed weights are bf16 fragments then)
+    int st16;                        // bf16 storage of Hs / Qs / S / I / O / U (gate mode 1, large dense training levels; tile_mma.h)
+    float* Hout;                     // ... then the LAST depth also writes h' in fp32 here (the level's result)
     const float *src_h, *src_c;      // kernel B of a sparse forward's qf^0 launch (ggpm_forward_gather_state): the start
     const int32_t* src_idx;          // (h, c) of row r is (src_h, src_c)[src_idx[r]] (zero when < 0), written to Hnew / Cnew
 };
@@ -38,8 +40,9 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time: s over the full row (GEMM operand), the
 // forget sum fc (and its backward coefficient) only over this workgroup's column group; then the first `tg`
 // waves run [Wi_h; Wo_h; Wu_h] . s for their output tile and the gate math.
-template <bool STASH, int GM, int RTT>
+template <bool STASH, int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
+    static_assert(!ST16 || GM == 1, "bf16 storage goes with bf16 gate products");      // the cell state c and F stay fp32
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;      // gate mode (LstmFwdArgs.bf16): 0 fp32 MFMA, 1 bf16, 2 split operands
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -89,9 +92,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
                         const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp;
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            h[u][k] = ggpm_ld4(a.Hprev + p + cs[k]);
+                            h[u][k] = ggpm_ldx<ST16>(a.Hprev, p + cs[k]);
                             cc[u][k] = ggpm_ld4(a.Cprev + p + cf[k]);
-                            q[u][k] = ggpm_ld4(a.Qprev + p + cf[k]);
+                            q[u][k] = ggpm_ldx<ST16>(a.Qprev, p + cf[k]);
                         }
                     }
 #pragma unroll
@@ -109,13 +112,14 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (!on[k]) continue;
+                if constexpr (ST16) s[k] = ggpm_rne4(s[k]);
                 if constexpr (SPLIT) ggpm_split_store(Is, PLANE, LDH, lr, c[k], s[k]);
                 else ggpm_st4(Ts + lr * LD + c[k], s[k]);
                 if (mine[k]) {
                     ggpm_st4(Tf + lr * LD + c[k], fc[k]);
                     if (STASH && row < a.E1) {
                         const size_t o = (size_t)row * Hp + c[k];
-                        ggpm_st4(a.S + o, s[k]);
+                        ggpm_stx<ST16>(a.S, o, s[k]);
                         ggpm_st4(a.F + o, fco[k]);
                     }
                 }
@@ -182,16 +186,19 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
                 gi = ggpm_sigmoid4(pi);
                 go = ggpm_sigmoid4(po);
                 gu = make_float4(tanhf(pu.x), tanhf(pu.y), tanhf(pu.z), tanhf(pu.w));
+                if constexpr (ST16) { gi = ggpm_rne4(gi); go = ggpm_rne4(go); gu = ggpm_rne4(gu); }      // (as stashed)
                 cn = gi * gu + fc;
                 h = go * make_float4(tanhf(cn.x), tanhf(cn.y), tanhf(cn.z), tanhf(cn.w));
+                if constexpr (ST16) h = ggpm_rne4(h);
             }
-            ggpm_st4(a.Hnew + o, h);
+            ggpm_stx<ST16>(a.Hnew, o, h);
+            if constexpr (ST16) if (a.Hout) ggpm_st4(a.Hout + o, h);
             ggpm_st4(a.Cnew + o, cn);
             if (a.fuse_b) keep_h(h);
             if (STASH) {
-                ggpm_st4(a.I + o, gi);
-                ggpm_st4(a.O + o, go);
-                ggpm_st4(a.U + o, gu);
+                ggpm_stx<ST16>(a.I, o, gi);
+                ggpm_stx<ST16>(a.O, o, go);
+                ggpm_stx<ST16>(a.U, o, gu);
             }
         }
     }
@@ -219,13 +226,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
             } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
             else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
             const int c = 16 * tt + 4 * (lane >> 4);
-            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
+            if (row < a.E1) ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][0]));
         }
     }
 }
 
 // Kernel B (same geometry as A): qf' = Wf_h h'.
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
         }
     } else {
         if constexpr (SPLIT) ggpm_load_rows_to_lds_split<ROWS>(a.Hnew, r0, a.E1, Hp, Ih, PLANE, LDH);
-        else ggpm_load_rows_to_lds<ROWS>(a.Hnew, r0, a.E1, Hp, LD, Th);
+        else ggpm_load_rows_to_lds<ROWS, ST16>(a.Hnew, r0, a.E1, Hp, LD, Th);
     }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < RTT; ++r) {
             const int row = r0 + 16 * r + (lane & 15);
-            if (row < a.E1) ggpm_st4(a.Qnew + (size_t)row * Hp + c, ggpm_f4(acc[0][r]));
+            if (row < a.E1) ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][r]));
         }
     }
 }
@@ -313,11 +320,12 @@ struct LstmBwdArgs {
     int fuse_b;                      // single column group: kernel A also forms dS for depth t-1 (no B launch)
     int bf16;                        // gate products on bf16 operands
     int skip_xsum;                   // dXi / dXo / dXu are NOT accumulated here (the caller sums the DI / DO / DU stash slots)
+    int st16;                        // bf16 storage of Hs / Qs / I / O / U / dS / DQ / DI / DO / DU (see LstmFwdArgs)
 };
 
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
 // gate derivatives; dXf += dFC * F.
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                     cf[k] = mine[k] ? c[k] : g_lo;
                     dh[k] = ggpm_zero4(); dq[k] = ggpm_zero4(); dc[k] = ggpm_zero4();
                     cp[k] = ggpm_ld4(a.Ccur + po + cs[k]);
-                    qp[k] = ggpm_ld4(a.Qcur + po + cs[k]);
+                    qp[k] = ggpm_ldx<ST16>(a.Qcur, po + cs[k]);
                 }
                 for (int base = 0; base < rl.n; base += 64) {
                     const int chunk = ggpm_list_chunk(a.scol, rl, base, lane);
@@ -374,7 +382,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                             for (int k = 0; k < 2; ++k) {
                                 xf[u][k] = ggpm_ld4(a.Xf + e + cs[k]);
                                 dfc[u][k] = ggpm_ld4(a.dFCin + e + cs[k]);
-                                ds[u][k] = ggpm_ld4(a.dSin + e + cf[k]);
+                                ds[u][k] = ggpm_ldx<ST16>(a.dSin, e + cf[k]);
                             }
                         }
 #pragma unroll
@@ -397,7 +405,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                     if (mine[k]) {
                         ggpm_st4(T0 + lr * LD + c[k], dh[k]);
                         ggpm_st4(T2 + lr * LD + c[k], dc[k]);
-                        if (p < a.E1) ggpm_st4(a.DQ + (size_t)p * Hp + c[k], dq[k]);
+                        if (p < a.E1) ggpm_stx<ST16>(a.DQ, (size_t)p * Hp + c[k], dq[k]);
                     }
                 }
             }
@@ -430,7 +438,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             const unsigned o = ((unsigned)(row < a.E1 ? row : 0) * (unsigned)Hp + (unsigned)c) * 4u;      // BYTES (E1 * Hp < 2^29, checked by the host)
             gi[r] = go[r] = gu[r] = cc[r] = fco[r] = oxi[r] = oxo[r] = oxu[r] = oxf[r] = ggpm_zero4();
             if (!a.final_pass) {
-                gi[r] = ggpm_ld4o(a.I, o); go[r] = ggpm_ld4o(a.O, o); gu[r] = ggpm_ld4o(a.U, o); cc[r] = ggpm_ld4o(a.Ccur, o);
+                gi[r] = ggpm_ldxo<ST16>(a.I, o); go[r] = ggpm_ldxo<ST16>(a.O, o); gu[r] = ggpm_ldxo<ST16>(a.U, o); cc[r] = ggpm_ld4o(a.Ccur, o);
                 fco[r] = ggpm_ld4o(a.F, o);
                 if (!a.first) {        // depth D starts the dX sums
                     if (!a.skip_xsum) { oxi[r] = ggpm_ld4o(a.dXi, o); oxo[r] = ggpm_ld4o(a.dXo, o); oxu[r] = ggpm_ld4o(a.dXu, o); }
@@ -535,10 +543,11 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
                 dop = make_float4(r_o[0], r_o[1], r_o[2], r_o[3]);
                 dup = make_float4(r_u[0], r_u[1], r_u[2], r_u[3]);
                 dfc = make_float4(r_c[0], r_c[1], r_c[2], r_c[3]);
+                if constexpr (ST16) { dip = ggpm_rne4(dip); dop = ggpm_rne4(dop); dup = ggpm_rne4(dup); }      // (as stored)
             }
-            ggpm_st4o(a.DI, o, dip);
-            ggpm_st4o(a.DO, o, dop);
-            ggpm_st4o(a.DU, o, dup);
+            ggpm_stxo<ST16>(a.DI, o, dip);
+            ggpm_stxo<ST16>(a.DO, o, dop);
+            ggpm_stxo<ST16>(a.DU, o, dup);
             ggpm_st4o(a.dFCout, o, dfc);
             if (!a.skip_xsum) {
                 ggpm_st4o(a.dXi, o, oxi[r] + dip);
@@ -576,13 +585,13 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
             }
             const int c = 16 * tt + 4 * (lane >> 4);
             if (row < a.E1)
-                ggpm_st4(a.dSout + (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
+                ggpm_stx<ST16>(a.dSout, (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + ggpm_f4(acc[1][0]) + ggpm_f4(acc[2][0]));
         }
     }
 }
 
 // Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
-template <int GM, int RTT>
+template <int GM, int RTT, bool ST16 = false>
 __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
@@ -613,9 +622,9 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
         ggpm_load_rows_to_lds_split<ROWS>(a.DO, r0, a.E1, Hp, Ib, PLANE, LDH);
         ggpm_load_rows_to_lds_split<ROWS>(a.DU, r0, a.E1, Hp, Ic, PLANE, LDH);
     } else {
-        ggpm_load_rows_to_lds<ROWS>(a.DI, r0, a.E1, Hp, LD, Ta);
-        ggpm_load_rows_to_lds<ROWS>(a.DO, r0, a.E1, Hp, LD, Tb);
-        ggpm_load_rows_to_lds<ROWS>(a.DU, r0, a.E1, Hp, LD, Tc);
+        ggpm_load_rows_to_lds<ROWS, ST16>(a.DI, r0, a.E1, Hp, LD, Ta);
+        ggpm_load_rows_to_lds<ROWS, ST16>(a.DO, r0, a.E1, Hp, LD, Tb);
+        ggpm_load_rows_to_lds<ROWS, ST16>(a.DU, r0, a.E1, Hp, LD, Tc);
     }
     __syncthreads();
     for (int tt = grp * a.tg + wave; tt < t_end; tt += GGPM_NWA) {
@@ -635,7 +644,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
         for (int r = 0; r < RTT; ++r) {
             const int e = r0 + 16 * r + (lane & 15);
             if (e < a.E1)
-                ggpm_st4(a.dSout + (size_t)e * Hp + c, ggpm_f4(acc[0][r]) + ggpm_f4(acc[1][r]) + ggpm_f4(acc[2][r]));
+                ggpm_stx<ST16>(a.dSout, (size_t)e * Hp + c, ggpm_f4(acc[0][r]) + ggpm_f4(acc[1][r]) + ggpm_f4(acc[2][r]));
         }
     }
 }
@@ -695,14 +704,16 @@ void launch_fwd(LstmFwdArgs a, bool stash, bool with_b, double flops1, hipStream
         set_lds(kernel, la);
         kernel<<<grid_a, GGPM_NWA * 64, la, s>>>(a);
     };
-    if (rt2) { if (stash) go(lstm_fwd_a<true, 0, 2>); else go(lstm_fwd_a<false, 0, 2>); }
+    if (a.st16) go(lstm_fwd_a<true, 1, 1, true>);      // (training levels only: always with stashes; bf16 mode has no two-row-tile form)
+    else if (rt2) { if (stash) go(lstm_fwd_a<true, 0, 2>); else go(lstm_fwd_a<false, 0, 2>); }
     else if (a.bf16 == 2) { if (stash) go(lstm_fwd_a<true, 2, 1>); else go(lstm_fwd_a<false, 2, 1>); }
     else if (a.bf16 == 1) { if (stash) go(lstm_fwd_a<true, 1, 1>); else go(lstm_fwd_a<false, 1, 1>); }
     else { if (stash) go(lstm_fwd_a<true, 0, 1>); else go(lstm_fwd_a<false, 0, 1>); }
     ggpm_timing_end(2, s);
     if (with_b) {
         ggpm_timing_begin(6, s, 1 * flops1);
-        if (rt2) { set_lds(lstm_fwd_b<0, 2>, lb); lstm_fwd_b<0, 2><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        if (a.st16) { set_lds(lstm_fwd_b<1, 1, true>, lb); lstm_fwd_b<1, 1, true><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
+        else if (rt2) { set_lds(lstm_fwd_b<0, 2>, lb); lstm_fwd_b<0, 2><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         else if (a.bf16 == 2) { set_lds(lstm_fwd_b<2, 1>, lb); lstm_fwd_b<2, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         else if (a.bf16 == 1) { set_lds(lstm_fwd_b<1, 1>, lb); lstm_fwd_b<1, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
         else { set_lds(lstm_fwd_b<0, 1>, lb); lstm_fwd_b<0, 1><<<grid_a, GGPM_NWA * 64, lb, s>>>(a); }
@@ -723,14 +734,16 @@ void launch_bwd(LstmBwdArgs a, bool with_b, double flops1, hipStream_t s) {
     if (a.fuse_b) with_b = false;
     const size_t la = a.fuse_b ? l_fused : split ? lds_tiles(2, Hp) + img_b : lds_tiles(3, Hp, rows);
     ggpm_timing_begin(3, s, (a.fuse_b ? 4 : 1) * flops1);
-    if (rt2) { set_lds(lstm_bwd_a<0, 2>, la); lstm_bwd_a<0, 2><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    if (a.st16) { set_lds(lstm_bwd_a<1, 1, true>, la); lstm_bwd_a<1, 1, true><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
+    else if (rt2) { set_lds(lstm_bwd_a<0, 2>, la); lstm_bwd_a<0, 2><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     else if (a.bf16 == 2) { set_lds(lstm_bwd_a<2, 1>, la); lstm_bwd_a<2, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     else if (a.bf16 == 1) { set_lds(lstm_bwd_a<1, 1>, la); lstm_bwd_a<1, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     else { set_lds(lstm_bwd_a<0, 1>, la); lstm_bwd_a<0, 1><<<grid_a, GGPM_NWA * 64, la, s>>>(a); }
     ggpm_timing_end(3, s);
     if (with_b) {
         ggpm_timing_begin(7, s, 3 * flops1);
-        if (rt2) { set_lds(lstm_bwd_b<0, 2>, l3); lstm_bwd_b<0, 2><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        if (a.st16) { set_lds(lstm_bwd_b<1, 1, true>, l3); lstm_bwd_b<1, 1, true><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
+        else if (rt2) { set_lds(lstm_bwd_b<0, 2>, l3); lstm_bwd_b<0, 2><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         else if (a.bf16 == 2) { set_lds(lstm_bwd_b<2, 1>, l3); lstm_bwd_b<2, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         else if (a.bf16 == 1) { set_lds(lstm_bwd_b<1, 1>, l3); lstm_bwd_b<1, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
         else { set_lds(lstm_bwd_b<0, 1>, l3); lstm_bwd_b<0, 1><<<grid_a, GGPM_NWA * 64, l3, s>>>(a); }
@@ -813,19 +826,23 @@ static int lstm_forward_impl(int E1, int H, int depth, const float* Xi, const fl
     const double flops1 = 2.0 * (double)(E1 - 1) * H * H;   // algorithmic flops of ONE gate product
     int run_depth = ggpm_take_run_depth();
     if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
+    // bf16 storage (tile_mma.h): bf16 gate products, dense, training, every stash contraction on the bf16 tall kernel
+    const bool st16 = bf16 == 1 && !frozen && save_for_backward && ggpm_bf16_storage_applies(E1, H);
     for (int t = 1; t <= run_depth; ++t) {
         LstmFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xi = Xi; a.Xo = Xo; a.Xu = Xu; a.Xf = Xf;
         a.Wi = pWi; a.Wo = pWo; a.Wu = pWu; a.Wf = pWf; a.rowptr = pred_rowptr; a.col = pred_col;
         a.frozen = frozen;
         a.bf16 = bf16;
+        a.st16 = st16 ? 1 : 0;
         a.h0_zero = (t == 1 && !frozen) ? 1 : 0;
         if (save_for_backward) {
-            a.Hprev = Hs + (size_t)(t - 1) * slot; a.Hnew = Hs + (size_t)t * slot;
+            a.Hprev = ggpm_slot_ptr(Hs, t - 1, slot, st16); a.Hnew = ggpm_slot_ptr(Hs, t, slot, st16);
+            a.Hout = (st16 && t == depth) ? Hs + (size_t)depth * slot : nullptr;      // the level's result stays fp32, at its usual place
             a.Cprev = Cs + (size_t)(t - 1) * slot; a.Cnew = Cs + (size_t)t * slot;
-            a.Qprev = Qs + (size_t)(t - 1) * slot; a.Qnew = (t < depth) ? Qs + (size_t)t * slot : nullptr;
-            a.S = Ss + (size_t)(t - 1) * slot; a.I = Is + (size_t)(t - 1) * slot;
-            a.O = Os + (size_t)(t - 1) * slot; a.U = Us + (size_t)(t - 1) * slot;
+            a.Qprev = ggpm_slot_ptr(Qs, t - 1, slot, st16); a.Qnew = (t < depth) ? ggpm_slot_ptr(Qs, t, slot, st16) : nullptr;
+            a.S = ggpm_slot_ptr(Ss, t - 1, slot, st16); a.I = ggpm_slot_ptr(Is, t - 1, slot, st16);
+            a.O = ggpm_slot_ptr(Os, t - 1, slot, st16); a.U = ggpm_slot_ptr(Us, t - 1, slot, st16);
             a.F = Fs + (size_t)(t - 1) * slot;
         } else {
             a.Hprev = Hs + (size_t)((t - 1) & 1) * slot; a.Hnew = Hs + (size_t)(t & 1) * slot;
@@ -948,21 +965,25 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
     // tree-side levels: d(h^t), d(c^t) vanish below step `lo` (nilpotent Jacobian, common.h)
     int lo = ggpm_take_backward_lo();
     if (lo < 1 || lo > depth || frozen) lo = 1;
+    const bool st16 = bf16 == 1 && !frozen && ggpm_bf16_storage_applies(E1, H);      // (as the forward decided)
     for (int t = depth; t >= lo; --t) {
         LstmBwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.first = (t == depth);
+        a.st16 = st16 ? 1 : 0;
         a.Xf = Xf;
         a.Ccur = Cs + (size_t)t * slot;
-        a.Qcur = (t < depth) ? Qs + (size_t)t * slot : nullptr;
+        a.Qcur = (t < depth) ? ggpm_slot_ptr(Qs, t, slot, st16) : nullptr;
         a.F = Fs + (size_t)(t - 1) * slot;
-        a.I = Is + (size_t)(t - 1) * slot; a.O = Os + (size_t)(t - 1) * slot; a.U = Us + (size_t)(t - 1) * slot;
+        a.I = ggpm_slot_ptr(Is, t - 1, slot, st16); a.O = ggpm_slot_ptr(Os, t - 1, slot, st16);
+        a.U = ggpm_slot_ptr(Us, t - 1, slot, st16);
         a.dHD = dHD;
         a.dSin = dSb[(t + 1) & 1]; a.dFCin = dFb[(t + 1) & 1];
         a.dSout = dSb[t & 1]; a.dFCout = dFb[t & 1];
-        a.DQ = (t < depth) ? DQ + (size_t)t * slot : nullptr;
+        a.DQ = (t < depth) ? ggpm_slot_ptr(DQ, t, slot, st16) : nullptr;
         a.frozen = frozen; a.dCD = dCD; a.carry_h = carry_h; a.carry_c = carry_c; a.final_pass = 0;
         a.dHin = nullptr; a.dCin = nullptr;
-        a.DI = DI + (size_t)(t - 1) * slot; a.DO = DO + (size_t)(t - 1) * slot; a.DU = DU + (size_t)(t - 1) * slot;
+        a.DI = ggpm_slot_ptr(DI, t - 1, slot, st16); a.DO = ggpm_slot_ptr(DO, t - 1, slot, st16);
+        a.DU = ggpm_slot_ptr(DU, t - 1, slot, st16);
         a.dXi = dXi; a.dXo = dXo; a.dXu = dXu; a.dXf = dXf;
         a.WiT = pWiT; a.WoT = pWoT; a.WuT = pWuT; a.WfT = pWfT; a.bf16 = bf16;
         a.srowptr = succ_rowptr; a.scol = succ_col;
@@ -1052,23 +1073,26 @@ static int lstm_weight_grads_impl(int E1, int H, int depth, const float* Hs, con
     float* skws = w;
     const size_t skbytes = work_bytes - (size_t)((char*)skws - (char*)work);
     const int KD = (depth - lo + 1) * E1;
-    const size_t o1 = (size_t)(lo - 1) * slot;
+    // bf16 storage (as the forward / backward decided): bf16 stashes in the first half of their buffers, read as they are
+    const bool st16 = ggpm_gate_dtype() == 1 && !with_slot0 && ggpm_bf16_storage_applies(E1, H);
+    const int tall_mode = st16 ? 2 : (ggpm_gate_dtype() == 1 ? 1 : 0);
+    const float* Sl = ggpm_slot_ptr(Ss, lo - 1, slot, st16);
     int rc;
     // the three or four contractions in ONE launch and one reduce (they share the split-K workspace)
-    ggpm_gemm_problem gp[4] = {{DI + o1, Hp, Ss + o1, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DO + o1, Hp, Ss + o1, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
-                               {DU + o1, Hp, Ss + o1, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
+    ggpm_gemm_problem gp[4] = {{ggpm_slot_ptr(DI, lo - 1, slot, st16), Hp, Sl, Hp, dWi_h, ld_dwi, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {ggpm_slot_ptr(DO, lo - 1, slot, st16), Hp, Sl, Hp, dWo_h, ld_dwo, H, nullptr, 0, GGPM_ACT_NONE, 0},
+                               {ggpm_slot_ptr(DU, lo - 1, slot, st16), Hp, Sl, Hp, dWu_h, ld_dwu, H, nullptr, 0, GGPM_ACT_NONE, 0},
                                {nullptr, Hp, nullptr, Hp, dWf_h, ld_dwf, H, nullptr, 0, GGPM_ACT_NONE, 0}};
     int Ks[4] = {KD, KD, KD, 0};
     if (depth > lo || with_slot0) {
         const int first_slot = with_slot0 ? 0 : lo;    // dqf^t pairs with h^t; slot 0 exists for sparse_forward only
-        gp[3].A = DQ + (size_t)first_slot * slot;
-        gp[3].B = Hs + (size_t)first_slot * slot;
+        gp[3].A = ggpm_slot_ptr(DQ, first_slot, slot, st16);
+        gp[3].B = ggpm_slot_ptr(Hs, first_slot, slot, st16);
         Ks[3] = (depth - first_slot) * E1;
-        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
+        rc = ggpm_gemm_tall_grouped(H, H, 4, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
     } else {
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, ggpm_gate_dtype() == 1);
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dWf_h + (size_t)r * ld_dwf, 0, H * sizeof(float), s);
     }

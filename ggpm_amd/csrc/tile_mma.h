@@ -250,8 +250,10 @@ __device__ __forceinline__ void ggpm_wave_gemm_bf16(const float* const (&tiles)[
 //               (3 KiB contiguous per tile and chunk; zero padded to 32 * kc32 columns);
 //   activations split where they are PRODUCED (gather / epilogue: once per element, not once per reading wave) into an LDS
 //               image of three row-major bf16 planes [rows][LDH], LDH = Hp + 8 halves: the row pitch in dwords is
-//               4 * (Hp / 8 + 1) -- an odd multiple of four, Hp being a multiple of 16 -- so the 16 rows a ds_read_b128
-//               group reads land on 16 distinct bank quads (conflict free).  When Hp is not a multiple of 32 the last k
+//               4 * (Hp / 8 + 1) -- an odd multiple of four, Hp being a multiple of 16 -- so 16 rows read at ONE k offset
+//               land on 16 distinct bank quads.  (A ds_read_b128 lane group is {0-3, 12-15, 20-27}: eight of its rows are
+//               read one quad further, and rows r / r+5 then share a quad for every padded pitch -- the 2-way conflict the
+//               fp32 tile has as well; measured under the weight stream, profiles/r04_gru_sq_counters.txt.)  When Hp is not a multiple of 32 the last k
 //               chunk's upper lanes (k = Hp .. Hp + 15) read the row's 8 pad halves and the first 8 halves of what follows
 //               -- the next row, the next plane, or the 8-half gap that ends every image.  Their weights are zero; what
 //               must not reach the pipe is a stale NaN bit pattern, so pads and gaps are zeroed once per launch
@@ -476,6 +478,18 @@ template <bool B16>
 __device__ __forceinline__ void ggpm_stx(float* base, size_t i, float4 v) {
     if constexpr (B16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(base) + i) = ggpm_f4_to_bf16x4(v);
     else ggpm_st4(base + i, v);
+}
+// the same through a BYTE offset computed for fp32 elements (ggpm_ld4o / ggpm_st4o): halved for a bf16 array
+template <bool B16>
+__device__ __forceinline__ float4 ggpm_ldxo(const float* base, unsigned byte_off_f32) {
+    if constexpr (B16)
+        return ggpm_bf16x4_to_f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + (byte_off_f32 >> 1)));
+    else return ggpm_ld4o(base, byte_off_f32);
+}
+template <bool B16>
+__device__ __forceinline__ void ggpm_stxo(float* base, unsigned byte_off_f32, float4 v) {
+    if constexpr (B16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + (byte_off_f32 >> 1)) = ggpm_f4_to_bf16x4(v);
+    else ggpm_st4o(base, byte_off_f32, v);
 }
 // start of slot t (of `slot` elements) of such an array
 static inline float* ggpm_slot_ptr(float* base, size_t t, size_t slot, bool b16) {

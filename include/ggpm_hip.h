@@ -177,13 +177,14 @@ int ggpm_sum_slots(const float* src, int slots, size_t slot_floats, float* out, 
  * queries.  The
  * whole-encoder drivers set it from ggpm_enc_dims.gate_dtype for the duration of their call. */
 int ggpm_level_gate_dtype(int dtype);
-/* 1 when a DENSE TRAINING GRU level of E1 message rows (pad row included) and hidden size H keeps the arrays of its depth
- * loop in bf16 under gate dtype 1 (BASELINE configs[4]: "bf16 storage"): the state h and the per-message product q, the
- * stashes S / G / Z / M, the backward's dS / dG and its DQ / DZP / DMP stashes -- rounded (RNE) where they are written, in
+/* 1 when a DENSE TRAINING level (GRU or LSTM) of E1 message rows (pad row included) and hidden size H keeps the arrays of
+ * its depth loop in bf16 under gate dtype 1 (BASELINE configs[4]: "bf16 storage"): the state h and the per-message product
+ * q, the stashes S / G / Z / M (LSTM: S / I / O / U), the backward's dS / dG and its DQ / DZP / DMP (DQ / DI / DO / DU)
+ * stashes -- rounded (RNE) where they are written, in
  * the first half of the fp32 buffers the caller passes (no size or layout changes at this boundary; the level's result, slot
  * `depth` of Hs, stays fp32 at its usual place).  The rule: E1 >= 6144 and the H x H x E1 contraction qualifies for the
- * bf16 tall kernel, which then reads the stashes as they are.  Kept fp32: gate inputs X and their gradients, R, every
- * weight and weight gradient.  oracle/ref_encoder.py restates the roundings as gate_dtype "bf16s" (ggpm/rnn.py:25-50). */
+ * bf16 tall kernel, which then reads the stashes as they are.  Kept fp32: gate inputs X and their gradients, R / F, the
+ * LSTM cell state c and dFC, every weight and weight gradient.  oracle/ref_encoder.py restates the roundings as gate_dtype "bf16s" (ggpm/rnn.py:25-50). */
 int ggpm_level_bf16_storage(int E1, int H);
 /* ------------------------------------------------------------------ GRU message function
  * GRU.forward (ggpm/rnn.py:41-50) with GRU.GRU (ggpm/rnn.py:25-39) restated over CSR predecessors with

@@ -860,8 +860,9 @@ def _bf16_case(case):
     if case.startswith(("cfg", "tiny")):
         g = Golden(case)
         return (lambda: _build_encoder(g)), g.numpy_tensors(), g.H, g.rnn, (g.depthT, g.depthG), g.params
-    if case == "storage_gru_h300_d6":      # >= 6144 atom-level messages: that level keeps its depth-loop arrays in bf16 ("bf16s")
-        return _seeded_encoder_case("GRU", 300, 6, synth.random_batch(607, 80, motifs=(8, 12), n_motif_vocab=60, n_attach_vocab=180))
+    if case.startswith("storage_"):        # >= 6144 atom-level messages: that level keeps its depth-loop arrays in bf16 ("bf16s")
+        return _seeded_encoder_case("LSTM" if "lstm" in case else "GRU", 300, 6,
+                                    synth.random_batch(607, 80, motifs=(8, 12), n_motif_vocab=60, n_attach_vocab=180))
     rnn, depth = ("LSTM", 30) if "lstm" in case else ("GRU", 10)
     return _seeded_encoder_case(rnn, 600, depth, synth.random_batch(606, 3, motifs=(46, 58), n_motif_vocab=60, n_attach_vocab=180))
 
@@ -898,7 +899,7 @@ def _bf16_hip_vs_oracle(build, tensors, H, rnn, depths, params):
                               ("tree_encoder.", depthT, tensors[0][1].shape[0], chain)):
         lo = max(1, depth - c + 1) if 0 < c else 1
         modes[pre] = "bf16w" if lib.ggpm_gemm_tn_bf16_applies(H, H, (depth - lo) * E1) else "bf16"
-        if rnn == "GRU" and lib.ggpm_level_bf16_storage(E1, H):      # the level's depth-loop arrays are kept in bf16 as well
+        if lib.ggpm_level_bf16_storage(E1, H):      # the level's depth-loop arrays are kept in bf16 as well
             modes[pre] = "bf16s"
     routs = ref.hier_encoder_forward(p, rnn, depthT, depthG, tt, gt, gate_dtype=modes)
     _, rkl = ref.rsample_kl(p, routs[0])
@@ -951,7 +952,7 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
                        dx=xg.grad.cpu().numpy())
     lib = _lib.load(build_if_missing=False)
     mode = "bf16w" if lib.ggpm_gemm_tn_bf16_applies(H, H, (depth - 1) * (E + 1)) else "bf16"
-    if rnn == "GRU" and lib.ggpm_level_bf16_storage(E + 1, H):      # bf16 storage of the depth loop's arrays (tile_mma.h)
+    if lib.ggpm_level_bf16_storage(E + 1, H):      # bf16 storage of the depth loop's arrays (tile_mma.h)
         mode = "bf16s"
     p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
     xr = torch.from_numpy(x).requires_grad_(True)
@@ -981,7 +982,7 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
 
 
 @pytest.mark.parametrize("case", ["tiny_gru_s1", "cfg_gru_s0", "cfg_lstm_s2", "polymer_lstm_h600_d30", "polymer_gru_h600_d10",
-                                  "storage_gru_h300_d6"])
+                                  "storage_gru_h300_d6", "storage_lstm_h300_d6"])
 def test_bf16_gate_products_match_the_bf16_oracle(case):
     """BASELINE configs[4] names bf16: ``encoder.gate_dtype = "bf16"`` runs the H x H gate products of the depth loops
     on v_mfma_f32_16x16x32_bf16 -- operands rounded to bf16 (RNE), fp32 accumulate -- and (round 3) the tall
