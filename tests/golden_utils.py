@@ -370,11 +370,11 @@ def oracle_encoder_result(rnn, depth, sd, tree, graph, dtype=torch.float32, hois
 
 
 def oracle_fp32_orders(rnn, depth, sd, tree, graph):
-    """The oracle's fp32 arithmetic in SIX equivalent evaluation orders -- what "the reference's fp32 result" is known
+    """The oracle's fp32 arithmetic in FIVE equivalent evaluation orders -- what "the reference's fp32 result" is known
     up to: 'padded' (the reference's op order), 'hoisted' (recurrent products applied once per message, gate weights
     split into input / hidden halves: exact algebra, other summation order), 'slots_reversed' (the predecessor /
-    incoming / cluster lists of every row reversed), 'threads_2' / 'threads_4' (fewer BLAS threads: other blocking),
-    'hoisted_reversed' (both)."""
+    incoming / cluster lists of every row reversed), 'threads_4' (fewer BLAS threads: other blocking; round 3 also ran
+    'threads_2', which gave the same numbers digit for digit at four times the cost), 'hoisted_reversed' (both)."""
     rev = lambda t: tuple(reversed_slots(x) if i in idx else x for i, x in enumerate(t[:-1])) + (t[-1],)
     idx = (2, 3, 4)
     tree_r = rev(tree)
@@ -383,6 +383,5 @@ def oracle_fp32_orders(rnn, depth, sd, tree, graph):
     return {"padded": oracle_encoder_result(rnn, depth, sd, tree, graph),
             "hoisted": oracle_encoder_result(rnn, depth, sd, tree, graph, hoisted=True),
             "slots_reversed": oracle_encoder_result(rnn, depth, sd, tree_r, graph_r),
-            "threads_2": oracle_encoder_result(rnn, depth, sd, tree, graph, threads=2),
             "threads_4": oracle_encoder_result(rnn, depth, sd, tree, graph, threads=4),
             "hoisted_reversed": oracle_encoder_result(rnn, depth, sd, tree_r, graph_r, hoisted=True)}

@@ -424,6 +424,8 @@ def test_motif_encoder_matches_reference_golden(name):
 # the orders differ from each other by up to 9x on one tensor (a different BLAS blocking alone moves W_r's gradient
 # from 3e-4 to 2.8e-3), the HIP path sits at 2.2-3.2x the worst of them -- its gather-phase sigmoid runs on the hardware
 # exp2 / rcp units (~2 ulp against libm's < 1), so it enters the same amplification with about twice the rounding noise.
+# TESTED in round 4 (profiles/r04_parity_report_configs4_gru.txt): the same test under an ablation build with libm expf +
+# IEEE division in the gather phases reads 1.69x where the shipped build reads 3.22x.
 CALIBRATED_FACTOR = 4.0
 
 
@@ -474,7 +476,7 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True,
     assert set(got) == set(o32) - {"kl"}
     if calibrate:
         # Ill-conditioned recurrence: "the reference's fp32 result" is itself only known up to the spread between
-        # equivalent fp32 evaluation orders.  Measure that spread (six orders of the oracle against its fp64 run) and ask
+        # equivalent fp32 evaluation orders.  Measure that spread (five orders of the oracle against its fp64 run) and ask
         # of the HIP result, per tensor, to stay within CALIBRATED_FACTOR x the worst order's distance to fp64.
         from golden_utils import ELEM_FLOOR, ELEM_TOL, elem_rel_err, oracle_fp32_orders
         orders = oracle_fp32_orders(rnn, depth, sd, tree, graph)
@@ -545,10 +547,13 @@ def test_configs4_polymer_shard_matches_oracle(rnn):
     (its state is a SUM over predecessors, h' = (1-z) sum_p h_p + z m, and grows along branching paths until the reset
     gates saturate): the reference's own fp32 arithmetic is 2e-3 (hroot) to 8e-3 (gradients) away from its fp64 run, and by
     how much depends on the evaluation order.  So the bound is CALIBRATED, not chosen: the oracle is evaluated in fp32 in
-    six equivalent orders (golden_utils.oracle_fp32_orders: the reference's padded op order, per-message recurrent
-    products, reversed neighbour slots, other BLAS blockings), each order's distance to the fp64 run is measured per
-    tensor, and the HIP result may be at most CALIBRATED_FACTOR = 4x as far from fp64 as the worst of them (measured:
-    2.2-3.2x; tools/parity_report.py --orders prints the table: profiles/r03_parity_report_configs4_gru.txt)."""
+    five equivalent orders (golden_utils.oracle_fp32_orders: the reference's padded op order, per-message recurrent
+    products, reversed neighbour slots, another BLAS blocking), each order's distance to the fp64 run is measured per
+    tensor, and the HIP result may be at most CALIBRATED_FACTOR = 4x as far from fp64 as the worst of them.  Measured: up to
+    3.2x -- and 1.7x in an ablation build whose gather phases evaluate their sigmoid with libm expf + IEEE division instead
+    of the ~2-ulp hardware exp2 / rcp form (profiles/r04_parity_report_configs4_gru.txt): the extra distance IS that
+    sigmoid's rounding noise entering the same ill-conditioned recurrence; the accurate form costs 1.0-2.3 us per
+    atom-level launch, so the fast one ships and the factor stays at 4 with that measurement behind it."""
     from ggpm_amd import synth
     specs = synth.random_batch(505, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
     _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, calibrate=rnn == "GRU")
@@ -972,7 +977,8 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
         # and every stored array is one more rounding point per element and depth step: more rows meet a flip)
         worst_tol = 6e-3 if mode == "bf16s" else 2e-3
         frac_min = {"h": 0.9, "dx": 0.7} if mode != "bf16s" else {"h": 0.75, "dx": 0.5}
-        assert med <= 2e-6 and frac >= frac_min[k] and worst <= worst_tol, (k, med, frac, worst)
+        med_tol = 5e-6 if mode == "bf16s" else 2e-6      # (measured: <= 2.6e-6 at H = 600, 0.0 for the state at every size)
+        assert med <= med_tol and frac >= frac_min[k] and worst <= worst_tol, (k, med, frac, worst)
     errs = {k: rel_err(got["bf16"][k], want[k]) for k in sd}
     worst_k = max(errs, key=errs.get)
     print("bf16 level %s E=%d H=%d depth=%d (weight-gradient operands %s): %s; parameter gradients worst %.2e (%s) at a "
