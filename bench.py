@@ -799,7 +799,7 @@ def parse_args(argv=None):
                          "been seen (allocator blocks, lazily created streams and events) before the timed region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs[]")
     ap.add_argument("--rnn", default=None, choices=["GRU", "LSTM"], help="message function (default: the config's)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_mfma", "f32_split"],
                     help="gate products of the depth loops: fp32 MFMA (parity contract) or bf16 operands with fp32 "
                          "accumulate (configs[4]; everything else stays fp32).  --config 4 reports both.")
     ap.add_argument("--hidden", type=int, default=None)

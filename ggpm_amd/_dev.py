@@ -19,6 +19,7 @@ PACK_ONCE = True           # the decode steps share one packed weight set (False
 TREE_COMPOSITE = True      # each tree-side decoder level as one autograd node (False: op by op)
 TREE_DRIVER = True         # ... whose two directions are one C call each (csrc/tree_level.hip; False: ~30 ctypes calls)
 ENC_NARROW = True          # the encoder's levels take two row tiles per workgroup while they run beside the atom-level chain
+                           # ("fwd" / "bwd": in that direction only)
 
 # ---- gradients (functional.py, parallel.py, optim.py)
 DEFER_EARLY = True         # deferred weight-gradient contractions start beside the atom level's backward (second stream)

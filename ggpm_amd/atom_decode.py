@@ -878,6 +878,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
                 _join_worker("decode_join (backward)")
                 main = torch.cuda.current_stream(dev)
                 with torch.cuda.stream(atom_stream):
+                    F_.mark("bwd: atom loop done (its stream)")
                     grads = tail()
                     F_.mark("bwd: atom level's tail issued")
                 main.wait_stream(atom_stream)

@@ -13,7 +13,7 @@ from typing import List
 
 import torch
 
-from . import _lib
+from . import _dev, _lib
 from . import functional as F_
 from .nnutils import read_hint
 
@@ -100,7 +100,8 @@ class _HierEncoder(torch.autograd.Function):
             saved.record_stream(side)
             roots.record_stream(side)
         P = F_._p
-        narrow = bool(NARROW[0])
+        beside = bool(NARROW[0])
+        narrow = beside and _dev.ENC_NARROW in (True, "fwd")
         if narrow:
             lib.ggpm_level_prefer_narrow(1)
         try:
@@ -118,7 +119,7 @@ class _HierEncoder(torch.autograd.Function):
             # second time" error instead of failing on a cleared attribute
             ctx.save_for_backward(saved, roots, hroot, hnode, hinter, hatom, *params)
             ctx.dims, ctx.grad_sink = dims, grad_sink
-            ctx.narrow = narrow
+            ctx.narrow = beside and _dev.ENC_NARROW in (True, "bwd")
         return hroot, hnode, hinter, hatom
 
     @staticmethod

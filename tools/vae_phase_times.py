@@ -6,7 +6,7 @@ the GPU stream it was recorded on, both relative to the step's start, averaged o
 time trails its host time by little is issued as fast as the GPU consumes it (host-bound); one that trails by a lot is
 GPU-bound.
 
-    python tools/vae_phase_times.py            # RNN=LSTM, IN_LOOP=1, STEPS=20
+    python tools/vae_phase_times.py [NAME=VALUE ...]     # RNN=LSTM, IN_LOOP=1, STEPS=20, PIPE=1; NAME: a ggpm_amd/_dev.py setting
 """
 import os
 import sys
@@ -24,6 +24,13 @@ class A:
 
 
 def main():
+    import ast
+    from ggpm_amd import _dev
+    for arg in sys.argv[1:]:
+        name, value = arg.split("=", 1)
+        assert hasattr(_dev, name), name
+        setattr(_dev, name, ast.literal_eval(value))
+        print("_dev.%s = %r" % (name, getattr(_dev, name)))
     cfg = bench.CONFIGS[1]
     wl = bench.VaeWorkload(cfg, os.environ.get("RNN", "GRU"), A, torch.device("cuda:0"))
     if os.environ.get("IN_LOOP"):
