@@ -315,6 +315,18 @@ class Workload:
             i += 1
             if i >= warm and i % 8 == 0:
                 torch.cuda.synchronize()          # (the host runs ahead of the GPU: count GPU time, not enqueue time)
+        # ... and until one more pass over the pool (at least as many steps as the timed region has) goes by without a device
+        # allocation, three extra passes at most: the allocator's pool has then stopped growing for these shapes
+        extra = max(len(self.dev_batches), min(a.steps, 8))
+        for _ in range(3):
+            torch.cuda.synchronize()
+            n0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            for _k in range(extra):
+                self.step(i)
+                i += 1
+            torch.cuda.synchronize()
+            if torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) == n0:
+                break
         warm = i
         self.warmup_run = warm
         log("warm-up done (%d steps); timing %d steps" % (warm, a.steps))
@@ -744,6 +756,11 @@ def configs4_leg(a, lib, dev, budget_s=90.0):
         for key, dt in (("fp32", "f32"), ("bf16", "bf16")):
             gc.unfreeze()
             gc.collect()
+            # these batches are 50 x the size of the rows before: hand the cached blocks of those rows back first, or every
+            # large request is carved out of whatever block fits and the pool keeps growing inside the timed regions (one
+            # device allocation per 6-step region, 250-300 ms each: 55-66 ms/step where a fresh process measures 40.5)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             wl = Workload(cfg, cfg["rnn"], b, 0, 1, dev, gate_dtype=dt)
             m = wl.measure(lib, 0)
             leg = {k: m[k] for k in ("ms_per_step", "value", "unit", "step_tflops_executed", "atoms_per_molecule",

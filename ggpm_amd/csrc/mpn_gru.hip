@@ -151,7 +151,7 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
 template <bool STASH, int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
+__global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_a(GruFwdArgs a) {
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) gru_fwd_b(GruFwdArgs a) {
+__global__ void GGPM_A_BOUNDS gru_fwd_b(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -438,7 +438,7 @@ struct GruBwdArgs {
 // Kernel A (16 waves): gather over successors (dq full rows, dh partial) -> dh = partial + dq.U_r ->
 // gate derivatives for this workgroup's column group.
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
+__global__ void GGPM_A_BOUNDS gru_bwd_a(GruBwdArgs a) {
     constexpr int ROWS = RTT * 16;      // ST16: Hs, Qs, S, Z, M, dS / dG, DQ, DZP, DMP in bf16 (tile_mma.h)
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_a(GruBwdArgs a) {
 // Kernel B (same geometry as A): dG = dm_pre . Wh_h ; dS = ds_dir + dz_pre . Wz_h (for depth t-1) ;
 // dXr += dG * R with R = sum_p h_p r(1-r) stashed by the forward gather.
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) gru_bwd_b(GruBwdArgs a) {
+__global__ void GGPM_A_BOUNDS gru_bwd_b(GruBwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");

@@ -41,7 +41,7 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // forget sum fc (and its backward coefficient) only over this workgroup's column group; then the first `tg`
 // waves run [Wi_h; Wo_h; Wu_h] . s for their output tile and the gate math.
 template <bool STASH, int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
+__global__ void GGPM_A_BOUNDS lstm_fwd_a(LstmFwdArgs a) {
     static_assert(!ST16 || GM == 1, "bf16 storage goes with bf16 gate products");      // the cell state c and F stay fp32
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;      // gate mode (LstmFwdArgs.bf16): 0 fp32 MFMA, 1 bf16, 2 split operands
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_a(LstmFwdArgs a) {
 
 // Kernel B (same geometry as A): qf' = Wf_h h'.
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_fwd_b(LstmFwdArgs a) {
+__global__ void GGPM_A_BOUNDS lstm_fwd_b(LstmFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -326,7 +326,7 @@ struct LstmBwdArgs {
 // Kernel A (16 waves): successors -> dqf (full rows), dh partial / dc (own columns) -> dh += dqf.Wf_h ->
 // gate derivatives; dXf += dFC * F.
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
+__global__ void GGPM_A_BOUNDS lstm_bwd_a(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;      // RTT = 2: two row tiles per workgroup (ggpm_level_prefer_narrow), no fused P3
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_a(LstmBwdArgs a) {
 
 // Kernel B (same geometry as A): dS = di_pre.Wi_h + do_pre.Wo_h + du_pre.Wu_h (for depth t-1).
 template <int GM, int RTT, bool ST16 = false>
-__global__ void __launch_bounds__(GGPM_NWA * 64) lstm_bwd_b(LstmBwdArgs a) {
+__global__ void GGPM_A_BOUNDS lstm_bwd_b(LstmBwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");

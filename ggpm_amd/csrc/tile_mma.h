@@ -19,7 +19,15 @@
 #include <type_traits>
 
 constexpr int GGPM_NW = 4;        // waves per workgroup of the "B" kernels (one output tile per wave)
-constexpr int GGPM_NWA = 16;      // waves per workgroup of the "A" kernels: all 16 gather, the first TG own a tile
+#ifndef GGPM_NWA_VALUE
+#define GGPM_NWA_VALUE 16         // (variant builds: 8 -> two 8-wave workgroups per CU where the LDS tiles allow, 128 VGPRs each)
+#endif
+constexpr int GGPM_NWA = GGPM_NWA_VALUE;      // waves per workgroup of the "A" kernels: all gather, the first TG own a tile
+#if GGPM_NWA_VALUE == 16
+#define GGPM_A_BOUNDS __launch_bounds__(1024)
+#else
+#define GGPM_A_BOUNDS __launch_bounds__(GGPM_NWA_VALUE * 64, 4)
+#endif
 constexpr int GGPM_PF = 4;        // weight-fragment prefetch depth (k chunks)
 #ifndef GGPM_PF3
 #define GGPM_PF3 3                // ... of the three-product loops (LSTM): 4 deep spilled 13-17 registers (48 -> 45.6 us)

@@ -41,7 +41,7 @@ class EncDims(ctypes.Structure):
                [("dropout", ctypes.c_float), ("seed_lo", ctypes.c_uint), ("seed_hi", ctypes.c_uint),
                 ("gate_dtype", ctypes.c_int)]
 
-GATE_DTYPES = {"f32": 0, "fp32": 0, "bf16": 1}
+GATE_DTYPES = F_.GATE_DTYPES      # "f32" (default: split operands where they pay) | "bf16" | "f32_mfma" | "f32_split" (A/B forms)
 
 
 def _dropout_seed():
