@@ -369,19 +369,108 @@ def oracle_encoder_result(rnn, depth, sd, tree, graph, dtype=torch.float32, hois
         ref.rne_bf16 = old_rne
 
 
+def reversed_batch(tree, graph):
+    """(tree, graph) with the predecessor / incoming / cluster lists of every row reversed."""
+    rev = lambda t, idx: tuple(reversed_slots(x) if i in idx else x for i, x in enumerate(t[:-1])) + (t[-1],)
+    return rev(tree, (2, 3, 4)), rev(graph, (2, 3))
+
+
+# the five equivalent fp32 evaluation orders: name -> arguments of a job (oracle_worker.py / oracle_encoder_result)
+FP32_ORDERS = {"padded": {}, "hoisted": {"hoisted": True}, "slots_reversed": {"reverse": True}, "threads_4": {"threads": 4},
+               "hoisted_reversed": {"hoisted": True, "reverse": True}}
+
+
 def oracle_fp32_orders(rnn, depth, sd, tree, graph):
     """The oracle's fp32 arithmetic in FIVE equivalent evaluation orders -- what "the reference's fp32 result" is known
     up to: 'padded' (the reference's op order), 'hoisted' (recurrent products applied once per message, gate weights
     split into input / hidden halves: exact algebra, other summation order), 'slots_reversed' (the predecessor /
     incoming / cluster lists of every row reversed), 'threads_4' (fewer BLAS threads: other blocking; round 3 also ran
     'threads_2', which gave the same numbers digit for digit at four times the cost), 'hoisted_reversed' (both)."""
-    rev = lambda t: tuple(reversed_slots(x) if i in idx else x for i, x in enumerate(t[:-1])) + (t[-1],)
-    idx = (2, 3, 4)
-    tree_r = rev(tree)
-    idx = (2, 3)
-    graph_r = rev(graph)
-    return {"padded": oracle_encoder_result(rnn, depth, sd, tree, graph),
-            "hoisted": oracle_encoder_result(rnn, depth, sd, tree, graph, hoisted=True),
-            "slots_reversed": oracle_encoder_result(rnn, depth, sd, tree_r, graph_r),
-            "threads_4": oracle_encoder_result(rnn, depth, sd, tree, graph, threads=4),
-            "hoisted_reversed": oracle_encoder_result(rnn, depth, sd, tree_r, graph_r, hoisted=True)}
+    tree_r, graph_r = reversed_batch(tree, graph)
+    out = {}
+    for name, j in FP32_ORDERS.items():
+        t, g = (tree_r, graph_r) if j.get("reverse") else (tree, graph)
+        out[name] = oracle_encoder_result(rnn, depth, sd, t, g, hoisted=bool(j.get("hoisted")), threads=j.get("threads"))
+    return out
+
+
+class OracleRuns:
+    """Several oracle evaluations of one batch, each in its OWN process with a share of the host's cores
+    (tests/oracle_worker.py): the constructor returns at once -- the caller runs the HIP path meanwhile -- and ``results()``
+    waits.  The big parity cases spend nearly all their time in these CPU runs (fp32 + fp64, the calibrated case four
+    more fp32 orders); side by side they take as long as the slowest one.  At most MAX_PROCS run at a time: autograd's
+    first backward() asks every backend for its device count, which OPENS the GPU in a CPU-only process too
+    (tools/probe/gpu_open_probe.sh: /dev/kfd and the render node appear after a CPU backward, visible-devices variables
+    or not), and a GPU box allows six such processes -- the test process and four workers stay below that.
+    A worker that fails raises here with its stderr."""
+    MAX_PROCS = 4
+
+    def __init__(self, rnn, depth, sd, tree, graph, jobs):
+        import pickle
+        import tempfile
+        self.dir = tempfile.TemporaryDirectory(prefix="ggpm_oracle_")
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        share = max(1, cores // max(1, min(len(jobs), self.MAX_PROCS)))
+        self.pending, self.procs = [], {}
+        for name, j in jobs.items():
+            job = dict(rnn=rnn, depth=depth, sd=sd, tree=tree, graph=graph, **j)
+            job.setdefault("threads", share)
+            src, dst = os.path.join(self.dir.name, name + ".job"), os.path.join(self.dir.name, name + ".out")
+            with open(src, "wb") as f:
+                pickle.dump(job, f, protocol=pickle.HIGHEST_PROTOCOL)
+            # (the slow ones first: fp64, then the per-message orders)
+            self.pending.append((0 if j.get("dtype") == "f64" else 1 if j.get("hoisted") else 2, name, src, dst, job["threads"]))
+        self.pending.sort()
+        self._pump()
+
+    def _pump(self):
+        import subprocess
+        import sys
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
+        running = sum(1 for p, _, _ in self.procs.values() if p.poll() is None)
+        while self.pending and running < self.MAX_PROCS:
+            _, name, src, dst, threads = self.pending.pop(0)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+            err = open(os.path.join(self.dir.name, name + ".err"), "wb")
+            self.procs[name] = (subprocess.Popen([sys.executable, worker, src, dst], env=env, stdout=err, stderr=err), dst, err)
+            running += 1
+
+    def cancel(self):
+        self.pending = []
+        for p, _, err in self.procs.values():
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+            err.close()
+        self.dir.cleanup()
+
+    def results(self, timeout=900):
+        import pickle
+        import time
+        out, failed = {}, None
+        t_end = time.time() + timeout
+        try:
+            while self.pending or any(p.poll() is None for p, _, _ in self.procs.values()):
+                if time.time() > t_end:
+                    raise RuntimeError("oracle workers: no result after %d s" % timeout)
+                self._pump()
+                time.sleep(0.05)
+            for name, (p, dst, err) in self.procs.items():
+                rc = p.returncode
+                err.close()
+                if rc != 0 and failed is None:
+                    with open(err.name, "rb") as f:
+                        failed = "oracle worker %r exited with %s:\n%s" % (name, rc, f.read().decode(errors="replace")[-2000:])
+                if rc == 0:
+                    with open(dst, "rb") as f:
+                        out[name] = pickle.load(f)
+        finally:
+            self.pending = []
+            for p, _, _ in self.procs.values():
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+            self.dir.cleanup()
+        if failed:
+            raise RuntimeError(failed)
+        return out

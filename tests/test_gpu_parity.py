@@ -429,11 +429,14 @@ def test_motif_encoder_matches_reference_golden(name):
 CALIBRATED_FACTOR = 4.0
 
 
-def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None, calibrate=False):
+def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None, calibrate=False,
+                   side_by_side=False):
     """Full encoder on a synthetic batch: HIP path vs the oracle on the same weights -- the four outputs, the KL and the
     gradient of EVERY parameter.  Norm-wise 1e-4 against the oracle's fp32 run (the BASELINE bar); per element
     (golden_utils.assert_close) against the oracle's fp64 run, relative to the fp32 oracle's own rounding noise
-    (``f64=False`` skips the fp64 run -- large cases -- and leaves the norm-wise bar)."""
+    (``f64=False`` skips the fp64 run -- large cases -- and leaves the norm-wise bar).  ``side_by_side``: the oracle's runs
+    (fp32, fp64, the calibrated case's other fp32 orders) each in their own CPU process while the HIP path runs here
+    (golden_utils.OracleRuns) -- the full-size cases, whose time is all oracle."""
     from ggpm_amd import synth
     from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
     from ggpm_amd.property_vae import HierEncoderVAE
@@ -449,13 +452,35 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True,
     a.rnn_type, a.embed_size, a.hidden_size = rnn, H, H
     a.depthT = a.depthG = depth
     a.dropout, a.latent_size = 0.0, latent
-    model = HierEncoderVAE(a).to(_dev())
-    model.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
-    z, kl, outs = model((tree, graph), perturb_z=False)
-    (kl + sum((o * o).sum() for o in outs)).backward()
+    side = None
+    if side_by_side:
+        from golden_utils import FP32_ORDERS, OracleRuns
+        jobs = {"padded": {}}
+        if f64:
+            jobs["f64"] = {"dtype": "f64"}
+        if calibrate:
+            jobs.update(FP32_ORDERS)
+        side = OracleRuns(rnn, depth, sd, tree, graph, jobs)
+    try:
+        model = HierEncoderVAE(a).to(_dev())
+        model.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
+        z, kl, outs = model((tree, graph), perturb_z=False)
+        (kl + sum((o * o).sum() for o in outs)).backward()
+    except BaseException:
+        if side is not None:
+            side.cancel()
+        raise
 
-    runs = {}
-    for dtype in (torch.float32, torch.float64) if f64 else (torch.float32,):
+    runs, orders = {}, None
+    if side is not None:
+        done = side.results()
+        for r in done.values():
+            r["kl"] = float(r["kl"])
+        runs[torch.float32] = done["padded"]
+        if f64:
+            runs[torch.float64] = done.pop("f64")
+        orders = done if calibrate else None
+    for dtype in () if side is not None else (torch.float32, torch.float64) if f64 else (torch.float32,):
         p = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd.items()}
         tt, gt = ref.to_long_tensors(tree), ref.to_long_tensors(graph)
         routs = ref.hier_encoder_forward(p, rnn, depth, depth, tt, gt)
@@ -479,7 +504,8 @@ def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True,
         # equivalent fp32 evaluation orders.  Measure that spread (five orders of the oracle against its fp64 run) and ask
         # of the HIP result, per tensor, to stay within CALIBRATED_FACTOR x the worst order's distance to fp64.
         from golden_utils import ELEM_FLOOR, ELEM_TOL, elem_rel_err, oracle_fp32_orders
-        orders = oracle_fp32_orders(rnn, depth, sd, tree, graph)
+        if orders is None:
+            orders = oracle_fp32_orders(rnn, depth, sd, tree, graph)
         rows = []
         for k in got:
             if np.abs(o64[k]).max() == 0:
@@ -509,7 +535,7 @@ def test_configs1_full_batch_matches_oracle(rnn):
     """BASELINE configs[1] at full size (32 molecules, ~38 atoms, H=300, depth 20) against the oracle."""
     from ggpm_amd import synth
     specs = synth.random_batch(4242, 32, motifs=(8, 12), n_motif_vocab=500, n_attach_vocab=1500)
-    _oracle_vs_hip(rnn, 300, 20, specs, 500, 1500, latent=32)
+    _oracle_vs_hip(rnn, 300, 20, specs, 500, 1500, latent=32, side_by_side=True)
 
 
 @pytest.mark.parametrize("rnn", ["LSTM", "GRU"])
@@ -518,7 +544,7 @@ def test_configs0_plumbing_batch_matches_oracle(rnn):
     batch 20 of HOPV-15-shaped molecules (42.8 +- 13.8 atoms: 6..14 random motifs), the shipped 721 / 6214 vocabulary."""
     from ggpm_amd import synth
     specs = synth.random_batch(101, 20, motifs=(6, 14), n_motif_vocab=721, n_attach_vocab=6214)
-    _oracle_vs_hip(rnn, 250, 20, specs, 721, 6214, latent=24)
+    _oracle_vs_hip(rnn, 250, 20, specs, 721, 6214, latent=24, side_by_side=True)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -536,7 +562,7 @@ def test_configs3_h600_shard_matches_oracle():
     QM9-like molecules plus HOPV-like and OPV-like ones)."""
     from ggpm_amd import synth
     specs = synth.size_mix_batch(404, 32, n_motif_vocab=721, n_attach_vocab=6214)
-    _oracle_vs_hip("LSTM", 600, 20, specs, 721, 6214, latent=24)
+    _oracle_vs_hip("LSTM", 600, 20, specs, 721, 6214, latent=24, side_by_side=True)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
@@ -556,7 +582,7 @@ def test_configs4_polymer_shard_matches_oracle(rnn):
     atom-level launch, so the fast one ships and the factor stays at 4 with that measurement behind it."""
     from ggpm_amd import synth
     specs = synth.random_batch(505, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
-    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, calibrate=rnn == "GRU")
+    _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, calibrate=rnn == "GRU", side_by_side=True)
 
 
 def test_configs4_shape_on_chain_polymers_meets_the_plain_bar():
@@ -566,7 +592,7 @@ def test_configs4_shape_on_chain_polymers_meets_the_plain_bar():
     form against fp64) holds without any calibration."""
     from ggpm_amd import synth
     specs = synth.random_batch(506, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500, chain=1.0)
-    _oracle_vs_hip("GRU", 600, 30, specs, 500, 1500, latent=32)
+    _oracle_vs_hip("GRU", 600, 30, specs, 500, 1500, latent=32, side_by_side=True)
 
 
 @pytest.mark.parametrize("rnn", ["GRU", "LSTM"])

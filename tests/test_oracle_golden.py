@@ -489,3 +489,31 @@ def test_bf16_cells_of_the_oracle_are_the_reference_cells_up_to_the_rounding(nam
     shift_s = max(rel_err(o.detach().numpy(), g.z[k]) for k, o in zip(("hroot", "hnode", "hinter", "hatom"), outs_s))
     assert 1e-6 < shift_s < 0.5, shift_s
 
+
+
+def test_oracle_runs_side_by_side_equal_the_in_process_runs():
+    """golden_utils.OracleRuns (one CPU process per oracle evaluation; the full-size GPU parity cases use it): the same
+    numbers as the in-process evaluation with the same thread count -- fp32, fp64 and a reversed-slot order."""
+    import torch
+    from ggpm_amd import synth
+    from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+    import golden_utils as G
+    specs = synth.random_batch(12, 3, motifs=(2, 5), n_motif_vocab=11, n_attach_vocab=33)
+    tree, graph = synth.tensorize(specs)
+    sd = seeded_state_dict(encoder_param_shapes("GRU", 24, 11, 33), 5)
+    sd.update(seeded_state_dict(vae_head_shapes(24, 16), 6))
+    jobs = {k: dict(v) for k, v in G.FP32_ORDERS.items()}          # six jobs: more than OracleRuns.MAX_PROCS, so two waves
+    jobs["f64"] = {"dtype": "f64"}
+    for k in ("padded", "f64", "slots_reversed"):
+        jobs[k]["threads"] = 2
+    runs = G.OracleRuns("GRU", 3, sd, tree, graph, jobs)
+    here = {"padded": G.oracle_encoder_result("GRU", 3, sd, tree, graph, threads=2),
+            "f64": G.oracle_encoder_result("GRU", 3, sd, tree, graph, dtype=torch.float64, threads=2),
+            "slots_reversed": G.oracle_encoder_result("GRU", 3, sd, *G.reversed_batch(tree, graph), threads=2)}
+    got = runs.results(timeout=300)
+    assert set(got) == set(jobs)
+    for name in here:
+        assert set(got[name]) == set(here[name])
+        for k, v in here[name].items():
+            np.testing.assert_allclose(np.asarray(got[name][k], dtype=np.float64), np.asarray(v, dtype=np.float64),
+                                       rtol=1e-6, atol=1e-9, err_msg="%s %s" % (name, k))
