@@ -123,27 +123,7 @@ def algorithmic_work(batches, H, depth, gates, chains=None):
     return full / n, execd / n, atoms / n
 
 
-def host_cores():
-    """CPU share of this process: affinity, capped by the cgroup quota (a GPU box grants ~16 per GPU)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return max(1, min(n, int(os.environ.get("GGPM_CPU_THREADS", "64"))))
+from ggpm_amd.launcher import host_cores      # noqa: E402  (CPU share of this process: affinity capped by the cgroup quota)
 
 
 def cpu_model():

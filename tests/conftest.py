@@ -15,6 +15,11 @@ _DP = {"procs": None}
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's CPU runs: as many threads as this process may use (a GPU box shows 256 CPUs under a quota of 16, and
+    # torch's default of one thread per visible core has them fight over that share)
+    import torch
+    from ggpm_amd.launcher import host_cores
+    torch.set_num_threads(host_cores())
 
 
 def _have_gpu():

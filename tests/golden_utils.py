@@ -409,7 +409,8 @@ class OracleRuns:
         import pickle
         import tempfile
         self.dir = tempfile.TemporaryDirectory(prefix="ggpm_oracle_")
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        from ggpm_amd.launcher import host_cores          # (affinity capped by the cgroup quota: a GPU box shows 256 CPUs and
+        cores = host_cores()                               # grants 16 -- workers with 128 threads each took 70-110 s per case)
         share = max(1, cores // max(1, min(len(jobs), self.MAX_PROCS)))
         self.pending, self.procs = [], {}
         for name, j in jobs.items():
@@ -448,6 +449,7 @@ class OracleRuns:
         import pickle
         import time
         out, failed = {}, None
+        t_wait = time.time()
         t_end = time.time() + timeout
         try:
             while self.pending or any(p.poll() is None for p, _, _ in self.procs.values()):
@@ -455,6 +457,7 @@ class OracleRuns:
                     raise RuntimeError("oracle workers: no result after %d s" % timeout)
                 self._pump()
                 time.sleep(0.05)
+            print("oracle runs: waited %.1f s for %d workers" % (time.time() - t_wait, len(self.procs)))
             for name, (p, dst, err) in self.procs.items():
                 rc = p.returncode
                 err.close()
@@ -464,6 +467,8 @@ class OracleRuns:
                 if rc == 0:
                     with open(dst, "rb") as f:
                         out[name] = pickle.load(f)
+                    with open(err.name, "rb") as f:          # (pytest -s shows where a worker's time went)
+                        print("  %s: %s" % (name, f.read().decode(errors="replace").strip().splitlines()[-1:]))
         finally:
             self.pending = []
             for p, _, _ in self.procs.values():

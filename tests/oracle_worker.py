@@ -13,8 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    import time
+    t0 = time.time()
     import torch
     import golden_utils as G
+    t1 = time.time()
     with open(sys.argv[1], "rb") as f:
         job = pickle.load(f)
     tree, graph = job["tree"], job["graph"]
@@ -25,9 +28,12 @@ def main():
     res = G.oracle_encoder_result(job["rnn"], job["depth"], job["sd"], tree, graph,
                                   dtype=torch.float64 if job.get("dtype") == "f64" else torch.float32,
                                   hoisted=bool(job.get("hoisted")))
+    t2 = time.time()
     with open(sys.argv[2] + ".tmp", "wb") as f:
         pickle.dump(res, f, protocol=pickle.HIGHEST_PROTOCOL)
     os.replace(sys.argv[2] + ".tmp", sys.argv[2])
+    print("[oracle worker] imports %.1f s, evaluation %.1f s (%s threads), result written %.1f s"
+          % (t1 - t0, t2 - t1, torch.get_num_threads(), time.time() - t2), flush=True)
 
 
 if __name__ == "__main__":
