@@ -375,17 +375,22 @@ def reversed_batch(tree, graph):
     return rev(tree, (2, 3, 4)), rev(graph, (2, 3))
 
 
-# the five equivalent fp32 evaluation orders: name -> arguments of a job (oracle_worker.py / oracle_encoder_result)
-FP32_ORDERS = {"padded": {}, "hoisted": {"hoisted": True}, "slots_reversed": {"reverse": True}, "threads_4": {"threads": 4},
-               "hoisted_reversed": {"hoisted": True, "reverse": True}}
+# The equivalent fp32 evaluation orders: name -> arguments of a job (oracle_worker.py / oracle_encoder_result).  Four
+# restatements -- 'padded' (the reference's op order), 'hoisted' (recurrent products applied once per message, gate weights
+# split into input / hidden halves: exact algebra, other summation order), 'slots_reversed' (the predecessor / incoming /
+# cluster lists of every row reversed), 'hoisted_reversed' (both) -- each with 1, 2, 3 and 4 BLAS threads (another blocking
+# of every product): sixteen evaluations.  Thread counts are explicit so that the family is the same on every host; on the
+# ill-conditioned configs[4] GRU case single tensors land anywhere between 7e-4 and 6e-3 from the fp64 run across it
+# (gradient of the attachment level's W_r, 20 evaluations on one CPU), which is why five samples were too few: the worst of
+# five moved by 2x with the thread count alone.
+FP32_ORDER_BASES = {"padded": {}, "hoisted": {"hoisted": True}, "slots_reversed": {"reverse": True},
+                    "hoisted_reversed": {"hoisted": True, "reverse": True}}
+FP32_ORDERS = {"%s@%d" % (name, t): dict(j, threads=t) for name, j in FP32_ORDER_BASES.items() for t in (1, 2, 3, 4)}
 
 
 def oracle_fp32_orders(rnn, depth, sd, tree, graph):
-    """The oracle's fp32 arithmetic in FIVE equivalent evaluation orders -- what "the reference's fp32 result" is known
-    up to: 'padded' (the reference's op order), 'hoisted' (recurrent products applied once per message, gate weights
-    split into input / hidden halves: exact algebra, other summation order), 'slots_reversed' (the predecessor /
-    incoming / cluster lists of every row reversed), 'threads_4' (fewer BLAS threads: other blocking; round 3 also ran
-    'threads_2', which gave the same numbers digit for digit at four times the cost), 'hoisted_reversed' (both)."""
+    """The oracle's fp32 arithmetic in the equivalent evaluation orders of FP32_ORDERS -- what "the reference's fp32
+    result" is known up to -- one after the other in this process (OracleRuns: side by side)."""
     tree_r, graph_r = reversed_batch(tree, graph)
     out = {}
     for name, j in FP32_ORDERS.items():
@@ -419,8 +424,8 @@ class OracleRuns:
             src, dst = os.path.join(self.dir.name, name + ".job"), os.path.join(self.dir.name, name + ".out")
             with open(src, "wb") as f:
                 pickle.dump(job, f, protocol=pickle.HIGHEST_PROTOCOL)
-            # (the slow ones first: fp64, then the per-message orders)
-            self.pending.append((0 if j.get("dtype") == "f64" else 1 if j.get("hoisted") else 2, name, src, dst, job["threads"]))
+            # (the slow ones first: fp64, then the jobs with the fewest threads)
+            self.pending.append((0 if j.get("dtype") == "f64" else job["threads"], name, src, dst, job["threads"]))
         self.pending.sort()
         self._pump()
 

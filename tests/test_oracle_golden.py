@@ -502,10 +502,9 @@ def test_oracle_runs_side_by_side_equal_the_in_process_runs():
     tree, graph = synth.tensorize(specs)
     sd = seeded_state_dict(encoder_param_shapes("GRU", 24, 11, 33), 5)
     sd.update(seeded_state_dict(vae_head_shapes(24, 16), 6))
-    jobs = {k: dict(v) for k, v in G.FP32_ORDERS.items()}          # six jobs: more than OracleRuns.MAX_PROCS, so two waves
-    jobs["f64"] = {"dtype": "f64"}
-    for k in ("padded", "f64", "slots_reversed"):
-        jobs[k]["threads"] = 2
+    jobs = {k: dict(v, threads=2) for k, v in G.FP32_ORDER_BASES.items()}       # six jobs: more than OracleRuns.MAX_PROCS
+    jobs["f64"] = {"dtype": "f64", "threads": 2}
+    jobs["hoisted@1"] = dict(G.FP32_ORDERS["hoisted@1"])
     runs = G.OracleRuns("GRU", 3, sd, tree, graph, jobs)
     here = {"padded": G.oracle_encoder_result("GRU", 3, sd, tree, graph, threads=2),
             "f64": G.oracle_encoder_result("GRU", 3, sd, tree, graph, dtype=torch.float64, threads=2),
