@@ -27,6 +27,8 @@ SIGNATURES = {
     "ggpm_gemm_workspace_bytes": (c_size_t, [I, I, I]),
     "ggpm_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, I, P, I, I, I, P, c_size_t, P]),
     "ggpm_gemm_grouped": (I, [I, I, I, I, I, I, P, P]),                   # problems: ggpm_gemm_problem[count]
+    "ggpm_gemm_grouped_splitk_workspace_bytes": (c_size_t, [I, I, I, I]),
+    "ggpm_gemm_grouped_splitk": (I, [I, I, I, I, I, I, P, P, c_size_t, P]),
     "ggpm_gemm_ksegments": (I, [I, I, I, I, P, P, P, P, P, P, I, I, P, I, I, I, P]),
     "ggpm_gemm_tn_bf16": (I, [I, I, I, P, I, P, I, P, I, P, c_size_t, P]),
     "ggpm_gemm_tn_bf16_applies": (I, [I, I, I]),

@@ -905,7 +905,7 @@ def _param_grads(lstm, params, acc, dX_tot, hmess, DPRE, NEI, fn_all, H, Hp, I, 
     if bufs is None:
         bufs = [torch.empty_like(W) for W in gate_ws]
     F_.gemm_grouped(1, 0, H, I, E1, [dict(A=dX_tot[k], lda=Hp, B=hmess, ldb=x_ld, C=b, ldc=b.stride(0), n_pad=I)
-                                      for k, b in enumerate(bufs)])
+                                      for k, b in enumerate(bufs)], splitk=True)
 
     def full(W, k, hidden):                 # [input half from the summed dX | accumulated hidden half]
         dW = bufs[k]

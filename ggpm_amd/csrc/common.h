@@ -127,6 +127,11 @@ void ggpm_backward_lo_depth(int lo);
 int ggpm_take_backward_lo();
 void ggpm_wgrad_lo_depth(int lo);
 int ggpm_take_wgrad_lo();
+// The next ggpm_gru_weight_grads of this thread leaves db_u alone: the caller forms it with ggpm_gru_bias_u_grad on another
+// stream (the encoder driver's atom level: the column sum over all dq stash rows, 52 us, runs on the main stream beside the
+// tall contractions instead of behind them).  `lo` as ggpm_wgrad_lo_depth; `csws`: 256 * Hp floats.
+void ggpm_wgrad_skip_bias_u(int yes);
+int ggpm_gru_bias_u_grad(int E1, int H, int depth, int lo, float* work, float* dbu, float* csws, ggpm_stream_t stream);
 // ggpm_backward_defer_stash (include/ggpm_hip.h): caller-owned gate-gradient stashes for the next sparse backward of this
 // thread.  -> true (and the pointers) once.
 bool ggpm_take_defer_stash(float* (&out)[4]);

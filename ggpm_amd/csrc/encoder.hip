@@ -498,6 +498,10 @@ struct BwdWork {
     float *dpre_root, *df, *dn, *d_hnode_t, *d_nei_t, *dpre, *d_h, *dX, *dx_mess, *d_finput, *d_hinter, *d_hnode_i,
         *d_nei_i, *d_pooled, *d_hatom, *d_nei_g, *level_work, *skws, *csws;
     size_t level_work_bytes, skws_bytes;
+    // per level: split-K slabs and column-sum scratch of its input-half weight gradients (level_backward's x_part runs on
+    // either stream, beside the other levels' parts: nothing shared)
+    float *xws[3], *xcs[3];
+    size_t xws_bytes;
 };
 
 void layout_work(Arena& A, const Dims& d, BwdWork& w) {
@@ -531,6 +535,14 @@ void layout_work(Arena& A, const Dims& d, BwdWork& w) {
     w.skws_bytes = sk + 1024;
     w.skws = A.take<float>(w.skws_bytes / 4);
     w.csws = A.take<float>((size_t)256 * (Hp > d.ld_t ? Hp : d.ld_t));
+    const int gates = d.lstm ? 4 : 3;
+    const size_t xa = ggpm_gemm_grouped_splitk_workspace_bytes(d.H, d.It, d.E1t, gates);
+    const size_t xb = ggpm_gemm_grouped_splitk_workspace_bytes(d.H, d.Ig, d.E1g, gates);
+    w.xws_bytes = (xa > xb ? xa : xb) + 256;
+    for (int l = 0; l < 3; ++l) {
+        w.xws[l] = A.take<float>(w.xws_bytes / 4);
+        w.xcs[l] = A.take<float>((size_t)256 * Hp);
+    }
 }
 
 struct Streams {
@@ -642,16 +654,17 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
                     CK(ggpm_sum_slots_any(src[k] + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX + (size_t)k * slot,
                                           b16, sx));
             }
+            // (the light column sums first, the products last: see the GRU branch)
+            for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, dbk[k], wc.xcs[level], sx));
             if (ggpm_gemm_prefers_grouped(H, I, E1, 4)) {      // the four in one launch
                 GgpmGemmProblem gp[4];
                 for (int k = 0; k < 4; ++k) gp[k] = {dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0};
-                CK(ggpm_gemm_grouped(1, 0, H, I, E1, 4, gp, sx));
+                CK(ggpm_gemm_grouped_splitk(1, 0, H, I, E1, 4, gp, wc.xws[level], wc.xws_bytes, sx));
             } else {
                 for (int k = 0; k < 4; ++k)
                     CK(ggpm_gemm(1, 0, H, I, E1, dX + k * slot, Hp, x, ldx, dWk[k], I + H, I, nullptr, 0, GGPM_ACT_NONE, 0,
                                  wc.skws, wc.skws_bytes, sx));
             }
-            for (int k = 0; k < 4; ++k) CK(ggpm_colsum(dX + k * slot, Hp, E1, H, dbk[k], wc.csws, sx));
             return GGPM_OK;
         };
         // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE,
@@ -692,6 +705,10 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
     const BwdWork wc = w;
     const float* Hs = L.Hs; const float* St = L.St;
     float* const dbu = G[lp(level, L_BU)]; float* const dbz = G[lp(level, L_BZ)]; float* const dbh = G[lp(level, L_BH)];
+    // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE, beside
+    // the tall contractions on the second stream, instead of behind them
+    const bool x_on_main = skip_xsum && st.side != nullptr && split_tail_enabled();
+    const bool bu_here = x_on_main;
     auto x_part = [=](ggpm_stream_t sx) -> int {       // input halves + bias sums from the summed gate-input gradients
         if (skip_xsum) {
             float *DMP = nullptr, *DZP = nullptr;
@@ -701,11 +718,18 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             CK(ggpm_sum_slots_any(DZP + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX, b16, sx));
             CK(ggpm_sum_slots_any(DMP + (b16 ? 0 : (size_t)(lo_ - 1) * slot), depth - lo_ + 1, slot, dX + 2 * slot, b16, sx));
         }
+        // the light column sums first, the products last: beside the tall contractions of the second stream (one 129 KB
+        // workgroup on every CU) a 600-workgroup product takes 145 us instead of 20, and whatever follows it on this stream
+        // ends the step -- so what follows it is nothing
+        CK(ggpm_colsum(dX, Hp, E1, H, dbz, wc.xcs[level], sx));
+        CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, dbh, wc.xcs[level], sx));
+        // db_u here too when this part has the main stream to itself: the second stream then ends with the tall contraction
+        if (bu_here) CK(ggpm_gru_bias_u_grad(E1, H, depth, blo, level_work, dbu, wc.xcs[level], sx));
         if (ggpm_gemm_prefers_grouped(H, I, E1, 3)) {      // the three in one launch
             const GgpmGemmProblem gp[3] = {{dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0},
                                            {dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0},
                                            {dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0}};
-            CK(ggpm_gemm_grouped(1, 0, H, I, E1, 3, gp, sx));
+            CK(ggpm_gemm_grouped_splitk(1, 0, H, I, E1, 3, gp, wc.xws[level], wc.xws_bytes, sx));
         } else {
             CK(ggpm_gemm(1, 0, H, I, E1, dX, Hp, x, ldx, dWz, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes, sx));
             CK(ggpm_gemm(1, 0, H, I, E1, dX + slot, Hp, x, ldx, dWr, I, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws, wc.skws_bytes,
@@ -713,16 +737,12 @@ int level_backward(const Dims& d, int E1, int I, int depth, const float* x, int 
             CK(ggpm_gemm(1, 0, H, I, E1, dX + 2 * slot, Hp, x, ldx, dWh, I + H, I, nullptr, 0, GGPM_ACT_NONE, 0, wc.skws,
                          wc.skws_bytes, sx));
         }
-        CK(ggpm_colsum(dX, Hp, E1, H, dbz, wc.csws, sx));
-        CK(ggpm_colsum(dX + 2 * slot, Hp, E1, H, dbh, wc.csws, sx));
         return GGPM_OK;
     };
-    // a level with nothing behind it on this stream (the atom level: no input gradient): its input halves run HERE, beside
-    // the tall contractions on the second stream, instead of behind them
-    const bool x_on_main = skip_xsum && st.side != nullptr && split_tail_enabled();
     const int rc_side = st.on_side([=]() -> int {
         if (!x_on_main) CK(x_part(sw));
         ggpm_wgrad_lo_depth(blo);
+        ggpm_wgrad_skip_bias_u(bu_here ? 1 : 0);
         GateDtypeScope tall_dtype(gate_dtype);      // (thread-local: this body may run on the side worker's thread)
         CK(ggpm_gru_weight_grads(E1, H, depth, Hs, St, St + ds, level_work, wc.level_work_bytes, dWz + I, I + H, dUr, H,
                                  dbu, dWh + I, I + H, sw));

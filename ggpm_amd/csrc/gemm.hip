@@ -408,11 +408,16 @@ struct SmallStage {
     }
 };
 
+// `chunk`: the K chunk [chunk * k_chunk, ...) of a split-K launch (g.ws set: the partial tile goes to slab `chunk` of the
+// workspace, splitk_reduce_group sums the slabs in fixed order and applies the epilogue); 0 with k_chunk >= K otherwise.
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, float (&Ls)[2][2][SK * SLD]) {
+__device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, int chunk, float (&Ls)[2][2][SK * SLD]) {
     constexpr int LDA = SmallStage<!TA>::LD, LDB = SmallStage<TB>::LD;
     const int m0 = by * SM, n0 = bx * SN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kbeg = g.nseg ? 0 : chunk * g.k_chunk;
+    const int klen = min(g.K, kbeg + g.k_chunk) - kbeg;
+    const size_t a_off = TA ? (size_t)kbeg * g.lda : (size_t)kbeg, b_off = TB ? (size_t)kbeg : (size_t)kbeg * g.ldb;
 
     f32x16 acc;
 #pragma unroll
@@ -420,11 +425,11 @@ __device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, 
 
     if (n0 < g.N) {
         const int nseg = g.nseg ? g.nseg : 1;
-        auto seg_A = [&](int sg) { return g.nseg ? g.segA[sg] : g.A; };
-        auto seg_B = [&](int sg) { return g.nseg ? g.segB[sg] : g.B; };
+        auto seg_A = [&](int sg) { return g.nseg ? g.segA[sg] : g.A + a_off; };
+        auto seg_B = [&](int sg) { return g.nseg ? g.segB[sg] : g.B + b_off; };
         auto seg_lda = [&](int sg) { return g.nseg ? g.seg_lda[sg] : g.lda; };
         auto seg_ldb = [&](int sg) { return g.nseg ? g.seg_ldb[sg] : g.ldb; };
-        auto seg_K = [&](int sg) { return g.nseg ? g.segK[sg] : g.K; };
+        auto seg_K = [&](int sg) { return g.nseg ? g.segK[sg] : klen; };
         int total_steps = 0;
         for (int sg = 0; sg < nseg; ++sg) total_steps += (seg_K(sg) + SK - 1) / SK;
 
@@ -518,6 +523,12 @@ __device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, 
         const int idx = threadIdx.x + 256 * j, r = idx >> 6, l = idx & 63;
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = n0 + (l & 31);
         if (m >= g.M) continue;
+        if (g.ws) {
+            if (n < g.N)
+                g.ws[((size_t)chunk * g.M + m) * g.N + n] = (part[(0 * 16 + r) * 64 + l] + part[(1 * 16 + r) * 64 + l]) +
+                                                             (part[(2 * 16 + r) * 64 + l] + part[(3 * 16 + r) * 64 + l]);
+            continue;
+        }
         if (n < g.N) {
             float v = (part[(0 * 16 + r) * 64 + l] + part[(1 * 16 + r) * 64 + l]) +
                       (part[(2 * 16 + r) * 64 + l] + part[(3 * 16 + r) * 64 + l]);
@@ -534,11 +545,28 @@ __device__ __forceinline__ void gemm_v3_tile(const GemmArgs& g, int bx, int by, 
 }
 
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(256) gemm_small_v3(GemmGroupArgs gg) {
+__global__ void __launch_bounds__(256) gemm_small_v3(GemmGroupArgs gg, int splits) {      // grid.z = problems x K chunks
     __shared__ __attribute__((aligned(16))) float Ls[2][2][SK * SLD];
     int bx, by, bz;
     xcd_tile(bx, by, bz);
-    gemm_v3_tile<TA, TB>(gg.p[bz], bx, by, Ls);
+    gemm_v3_tile<TA, TB>(gg.p[bz / splits], bx, by, bz % splits, Ls);
+}
+
+// sums the K-chunk slabs of a split gemm_small_v3 launch (fixed order) and applies the epilogue; blockIdx.z: the problem
+__global__ void splitk_reduce_group(GemmGroupArgs gg, int splits) {
+    const GemmArgs& g = gg.p[blockIdx.z];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= g.n_pad) return;
+    float* dst = g.C + (size_t)m * g.ldc + n;
+    if (n >= g.N) { *dst = 0.f; return; }
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += g.ws[((size_t)z * g.M + m) * g.N + n];
+    if (g.bias) v += g.bias[n];
+    if (g.accumulate) v += *dst;
+    v = apply_act(v, g.act);
+    if (g.zero_row0 && m == 0) v = 0.f;
+    *dst = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1140,12 +1168,24 @@ inline bool small_launch(int M, int N, int count) {
     static const int max_tiles = [] { const char* e = ggpm_dev_env("GGPM_GEMM_V3_TILES"); return e ? atoi(e) : 300; }();
     return use_v3 && (size_t)ggpm_ceil_div(M, BM) * ggpm_ceil_div(N, BN) * count <= (size_t)max_tiles;
 }
-inline void launch_small(int trans_a, int trans_b, const GemmGroupArgs& gg, int count, int M, int n_pad_max, hipStream_t s) {
-    dim3 grid(ggpm_ceil_div(n_pad_max, SN), ggpm_ceil_div(M, SM), count);
-    if (!trans_a && !trans_b) gemm_small_v3<false, false><<<grid, 256, 0, s>>>(gg);
-    else if (!trans_a && trans_b) gemm_small_v3<false, true><<<grid, 256, 0, s>>>(gg);
-    else if (trans_a && !trans_b) gemm_small_v3<true, false><<<grid, 256, 0, s>>>(gg);
-    else gemm_small_v3<true, true><<<grid, 256, 0, s>>>(gg);
+inline void launch_small(int trans_a, int trans_b, const GemmGroupArgs& gg, int count, int M, int n_pad_max, hipStream_t s,
+                         int splits = 1) {
+    dim3 grid(ggpm_ceil_div(n_pad_max, SN), ggpm_ceil_div(M, SM), count * splits);
+    if (!trans_a && !trans_b) gemm_small_v3<false, false><<<grid, 256, 0, s>>>(gg, splits);
+    else if (!trans_a && trans_b) gemm_small_v3<false, true><<<grid, 256, 0, s>>>(gg, splits);
+    else if (trans_a && !trans_b) gemm_small_v3<true, false><<<grid, 256, 0, s>>>(gg, splits);
+    else gemm_small_v3<true, true><<<grid, 256, 0, s>>>(gg, splits);
+}
+// K chunks of a grouped small launch whose few 32 x 32 tiles would each walk a long K alone (the input halves of a level's
+// gate weight gradients: 60 tiles x 2848 rows = 45 dependent k-steps, 177 us at the very end of the step): enough chunks
+// for ~1000 workgroups, never shorter than four k-steps
+inline int small_splits(int M, int N, int K, int count, int* k_chunk) {
+    const int tiles = ggpm_ceil_div(M, SM) * ggpm_ceil_div(N, SN) * count;
+    int want = 1024 / tiles, maxs = K / (4 * SK);
+    int sp = want < maxs ? want : maxs;
+    if (sp < 2) { *k_chunk = ggpm_round_up(K, BK); return 1; }
+    *k_chunk = ggpm_round_up(ggpm_ceil_div(K, sp), SK);
+    return ggpm_ceil_div(K, *k_chunk);
 }
 }  // namespace
 
@@ -1384,6 +1424,42 @@ extern "C" int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, 
     else if (!trans_a && trans_b) gemm_group_v2<false, true><<<grid, 256, 0, s>>>(gg);
     else if (trans_a && !trans_b) gemm_group_v2<true, false><<<grid, 256, 0, s>>>(gg);
     else gemm_group_v2<true, true><<<grid, 256, 0, s>>>(gg);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+extern "C" size_t ggpm_gemm_grouped_splitk_workspace_bytes(int M, int N, int K, int count) {
+    if (M <= 0 || N <= 0 || K <= 0 || count <= 0 || count > GGPM_GEMM_MAX_GROUP || !small_launch(M, N, count)) return 0;
+    int kc;
+    const int sp = small_splits(M, N, K, count, &kc);
+    return sp > 1 ? (size_t)sp * count * M * N * sizeof(float) : 0;
+}
+
+extern "C" int ggpm_gemm_grouped_splitk(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* p,
+                                        float* ws, size_t ws_bytes, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (count <= 0 || count > GGPM_GEMM_MAX_GROUP || !p || M <= 0 || N <= 0 || K <= 0) return GGPM_ERR_ARG;
+    const size_t need = ggpm_gemm_grouped_splitk_workspace_bytes(M, N, K, count);
+    bool ok = need > 0 && ws && ws_bytes >= need;
+    int n_pad_max = 0;
+    for (int i = 0; i < count && ok; ++i) {
+        if (!p[i].A || !p[i].B || !p[i].C || p[i].n_pad < N || p[i].n_pad > p[i].ldc) return GGPM_ERR_ARG;
+        ok = v2_operands_ok(p[i].A, p[i].lda, trans_a ? K : M, p[i].B, p[i].ldb, trans_b ? N : K);
+        n_pad_max = max(n_pad_max, p[i].n_pad);
+    }
+    if (!ok) return ggpm_gemm_grouped(trans_a, trans_b, M, N, K, count, p, stream);
+    int kc;
+    const int sp = small_splits(M, N, K, count, &kc);
+    GemmGroupArgs gg;
+    for (int i = 0; i < count; ++i) {
+        fill_args(gg.p[i], M, N, K, p[i]);
+        gg.p[i].k_chunk = kc;
+        gg.p[i].ws = ws + (size_t)i * sp * M * N;
+    }
+    for (int i = count; i < GGPM_GEMM_MAX_GROUP; ++i) gg.p[i] = gg.p[0];
+    hipStream_t s = (hipStream_t)stream;
+    launch_small(trans_a, trans_b, gg, count, M, N, s, sp);
+    splitk_reduce_group<<<dim3(ggpm_ceil_div(n_pad_max, 256), M, count), 256, 0, s>>>(gg, sp);
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }

@@ -932,6 +932,8 @@ void ggpm_backward_lo_depth(int lo) { g_bwd_lo = lo; }
 int ggpm_take_backward_lo() { const int v = g_bwd_lo; g_bwd_lo = 0; return v; }
 void ggpm_wgrad_lo_depth(int lo) { g_wgrad_lo = lo; }
 int ggpm_take_wgrad_lo() { const int v = g_wgrad_lo; g_wgrad_lo = 0; return v; }
+namespace { thread_local bool g_wgrad_skip_bu = false; }
+void ggpm_wgrad_skip_bias_u(int yes) { g_wgrad_skip_bu = yes != 0; }
 namespace { thread_local float* g_defer[4] = {nullptr, nullptr, nullptr, nullptr}; thread_local bool g_defer_set = false; }
 extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3) {
     g_defer[0] = s0; g_defer[1] = s1; g_defer[2] = s2; g_defer[3] = s3;
@@ -1246,6 +1248,8 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
     GGPM_CLEAR_STALE_ERROR();
     if (E1 <= 0 || H <= 0 || depth <= 0 || !Hs || !Ss || !Gs || !work || !dWz_h || !dUr || !dbu || !dWh_h)
         return GGPM_ERR_ARG;
+    const bool skip_bu = g_wgrad_skip_bu;                 // (consumed: ggpm_gru_bias_u_grad forms db_u elsewhere)
+    g_wgrad_skip_bu = false;
     if (lo < 1 || lo > depth || with_slot0) lo = 1;       // backward steps depth .. lo ran (stash slots lo-1 .. depth-1)
     if (work_bytes < ggpm_gru_backward_workspace_bytes(E1, H, depth)) return GGPM_ERR_WORKSPACE;
     const int Hp = ggpm_padded_hidden(H);
@@ -1282,16 +1286,35 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         Ks[2] = KQ;
         rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
-        rc = ggpm_colsum_any(dq0, Hp, KQ, H, dbu, csws, st16, stream);
-        if (rc) return rc;
+        if (!skip_bu) {
+            rc = ggpm_colsum_any(dq0, Hp, KQ, H, dbu, csws, st16, stream);
+            if (rc) return rc;
+        }
     } else {
         rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
         for (int r = 0; r < H; ++r) (void)hipMemsetAsync(dUr + (size_t)r * ld_dur, 0, H * sizeof(float), s);
-        (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
+        if (!skip_bu) (void)hipMemsetAsync(dbu, 0, H * sizeof(float), s);
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+// db_u of a dense level by itself (what gru_weight_grads_impl does last unless ggpm_wgrad_skip_bias_u was set): the column
+// sum of the dq stash slots lo .. depth-1 (dq^t pairs with h^t; the dense level never produces dq^0).
+int ggpm_gru_bias_u_grad(int E1, int H, int depth, int lo, float* work, float* dbu, float* csws, ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (E1 <= 0 || H <= 0 || depth <= 0 || !work || !dbu || !csws) return GGPM_ERR_ARG;
+    if (lo < 1 || lo > depth) lo = 1;
+    const int Hp = ggpm_padded_hidden(H);
+    const size_t slot = (size_t)E1 * Hp;
+    const float* DQ = work + 3 * ggpm_packed_matrix_slot(Hp) + 2 * (size_t)depth * slot;      // (layout of gru_backward_impl)
+    if (depth <= lo) {
+        (void)hipMemsetAsync(dbu, 0, H * sizeof(float), (hipStream_t)stream);
+        return GGPM_OK;
+    }
+    const bool st16 = ggpm_gate_dtype() == 1 && ggpm_bf16_storage_applies(E1, H);
+    return ggpm_colsum_any(ggpm_slot_ptr(DQ, lo, slot, st16), Hp, (depth - lo) * E1, H, dbu, csws, st16, stream);
 }
 
 namespace {

@@ -235,16 +235,24 @@ class GemmProblem(ctypes.Structure):
                 ("accumulate", ctypes.c_int), ("act", ctypes.c_int), ("zero_row0", ctypes.c_int)]
 
 
-def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems) -> None:
+def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems, splitk: bool = False) -> None:
     """problems: list of dicts(A, lda, B, ldb, C, ldc, n_pad, bias=None, accumulate=False, act=ACT_NONE, zero_row0=False);
-    up to four independent products of one shape in one launch."""
+    up to four independent products of one shape in one launch.  ``splitk``: the K range in chunks where the group has few
+    output tiles and a long K (ggpm_gemm_grouped_splitk: weight gradients over all rows of a level)."""
+    lib = _lib.load()
     arr = (GemmProblem * len(problems))()
     for i, q in enumerate(problems):
         arr[i] = GemmProblem(_p(q["A"]), q["lda"], _p(q["B"]), q["ldb"], _p(q["C"]), q["ldc"], q["n_pad"],
                              _p(q.get("bias")), int(q.get("accumulate", False)), q.get("act", ACT_NONE),
                              int(q.get("zero_row0", False)))
-    _lib.check(_lib.load().ggpm_gemm_grouped(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p),
-                                             _stream()), "gemm_grouped")
+    wsb = int(lib.ggpm_gemm_grouped_splitk_workspace_bytes(M, N, K, len(problems))) if splitk else 0
+    if wsb:
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=problems[0]["C"].device)
+        _lib.check(lib.ggpm_gemm_grouped_splitk(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p), _p(ws), wsb,
+                                                _stream()), "gemm_grouped_splitk")
+        return
+    _lib.check(lib.ggpm_gemm_grouped(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()),
+               "gemm_grouped")
 
 
 def gemm_ksegments(tb: int, M: int, N: int, As, ldas, Bs, ldbs, Ks, C: torch.Tensor, ldc: int, n_pad: int,

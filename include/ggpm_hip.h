@@ -97,6 +97,15 @@ typedef struct ggpm_gemm_problem {
 } ggpm_gemm_problem;
 int ggpm_gemm_grouped(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* problems,
                       ggpm_stream_t stream);
+/* ggpm_gemm_grouped with the K range cut into chunks (deterministic: partial tiles to `ws`, summed in fixed order by a
+ * second launch that applies bias / accumulate / activation): for groups with few output tiles and a long K -- the input
+ * halves dW[:, :I] = dX^T x of a level's gate weights (autograd's mm backward of the nn.Linear layers of ggpm/rnn.py:13-16,
+ * 69-72 over all E messages), whose 60 tiles would otherwise walk 2 848 rows each.  `ws` needs
+ * ggpm_gemm_grouped_splitk_workspace_bytes() bytes; when that is 0 (nothing to split) or `ws` is NULL / too small the call
+ * is ggpm_gemm_grouped. */
+size_t ggpm_gemm_grouped_splitk_workspace_bytes(int M, int N, int K, int count);
+int ggpm_gemm_grouped_splitk(int trans_a, int trans_b, int M, int N, int K, int count, const ggpm_gemm_problem* problems,
+                             float* ws, size_t ws_bytes, ggpm_stream_t stream);
 int ggpm_gemm_ksegments(int trans_b, int M, int N, int nseg, const float* const* A, const int* lda,
                         const float* const* B, const int* ldb, const int* K, float* C, int ldc, int n_pad,
                         const float* bias, int accumulate, int act, int zero_row0, ggpm_stream_t stream);

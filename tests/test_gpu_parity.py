@@ -129,10 +129,15 @@ def test_gemm_tn_bf16_against_fp64_of_the_rounded_operands(M, N, K, ld):
     assert shift > 1e-5            # (so the comparison above does tell bf16 operands from fp32 ones)
 
 
-@pytest.mark.parametrize("ta,tb,M,N,K,count,aligned", [(0, 1, 573, 300, 600, 3, True), (0, 1, 45, 16, 30, 4, True),
-                                                      (1, 0, 300, 340, 573, 3, True), (0, 0, 130, 300, 300, 2, True),
-                                                      (0, 1, 77, 50, 41, 3, False)])
-def test_gemm_grouped_against_fp64(ta, tb, M, N, K, count, aligned):
+@pytest.mark.parametrize("ta,tb,M,N,K,count,aligned,splitk", [
+    (0, 1, 573, 300, 600, 3, True, False), (0, 1, 45, 16, 30, 4, True, False), (1, 0, 300, 340, 573, 3, True, False),
+    (0, 0, 130, 300, 300, 2, True, False), (0, 1, 77, 50, 41, 3, False, False),
+    # K in chunks (ggpm_gemm_grouped_splitk): the input halves of the atom level's gate weight gradients (GRU / LSTM), a K
+    # that is no multiple of the chunk, the other operand layouts, a group too short to split, the unaligned fallback
+    (1, 0, 300, 62, 2848, 3, True, True), (1, 0, 300, 62, 2848, 4, True, True), (1, 0, 250, 47, 5001, 3, True, True),
+    (0, 1, 90, 40, 3000, 2, True, True), (0, 0, 64, 33, 1500, 2, True, True), (1, 1, 100, 30, 2000, 1, True, True),
+    (1, 0, 300, 62, 300, 3, True, True), (1, 0, 77, 50, 2100, 3, False, True)])
+def test_gemm_grouped_against_fp64(ta, tb, M, N, K, count, aligned, splitk):
     """Up to four products of one shape in one launch; per-problem bias / accumulate / leading dimensions; the
     unaligned case takes the sequential fallback."""
     from ggpm_amd import functional as F_
@@ -157,7 +162,7 @@ def test_gemm_grouped_against_fp64(ta, tb, M, N, K, count, aligned):
         probs.append(dict(A=torch.from_numpy(A).to(_dev()), lda=lda, B=torch.from_numpy(B).to(_dev()), ldb=ldb,
                           C=torch.from_numpy(C0).to(_dev()), ldc=ldc, n_pad=N,
                           bias=None if bias is None else torch.from_numpy(bias).to(_dev()), accumulate=acc))
-    F_.gemm_grouped(ta, tb, M, N, K, probs)
+    F_.gemm_grouped(ta, tb, M, N, K, probs, splitk=splitk)
     for q, ref in zip(probs, refs):
         assert rel_err(q["C"].cpu().numpy()[:, :N], ref) < 3e-6
 
