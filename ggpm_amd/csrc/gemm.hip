@@ -910,10 +910,14 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
                 for (int e = 0; e < 4; ++e) {
                     const float x = r[i][e];
                     w1[e] = (__bf16)x;
+#if defined(GGPM_ABL_TALL) && GGPM_ABL_TALL == 1      // timing ablation (variant build): no residual arithmetic in the producers
+                    r1b[e] = r2b[e] = __builtin_bit_cast(unsigned, x);
+#else
                     const float r1 = x - (float)w1[e];
                     r1b[e] = __builtin_bit_cast(unsigned, r1);
                     const float x2f = __builtin_bit_cast(float, r1b[e] & 0xffff0000u);
                     r2b[e] = __builtin_bit_cast(unsigned, r1 - x2f);
+#endif
                 }
                 // upper halves of two registers into one: bytes {lo.2, lo.3, hi.2, hi.3}
                 const unsigned w2a = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), w2b = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
@@ -954,6 +958,11 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
     };
     ggpm_lds_barrier();
     int cur = 0;
+#if defined(GGPM_ABL_TALL) && GGPM_ABL_TALL == 2          // timing ablation (variant build): fragments read, no products
+#define GGPM_TALL_MFMA(a, b, c) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define GGPM_TALL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
     for (int k0 = kbeg; k0 < kend; k0 += BTK, cur ^= 1) {
         const __bf16* img = Lsp + (size_t)cur * 3 * PLANE;
         gbf16x8 fb[3][5], fa[5];
@@ -967,7 +976,7 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 5; ++j) acc[i][j] = GGPM_TALL_MFMA(fa[i], fb[0][j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < 5; ++i) fa[i] = frag(img + PLANE + fa0 + 16 * i);
 #pragma unroll
@@ -975,7 +984,7 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[pl][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 5; ++j) acc[i][j] = GGPM_TALL_MFMA(fa[i], fb[pl][j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < 5; ++i) fa[i] = frag(img + fa0 + 16 * i);
 #pragma unroll
@@ -983,7 +992,7 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_tall_split(GemmGroupArgs gg, i
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[pl][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 5; ++j) acc[i][j] = GGPM_TALL_MFMA(fa[i], fb[pl][j], acc[i][j]);
         ggpm_lds_barrier();
     }
     // split-K slab in the fragment order of gemm_tn_tall (lane l: rows 4*(l>>4) + 0..3, column l & 15 of every block)

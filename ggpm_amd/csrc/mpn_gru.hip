@@ -1284,12 +1284,12 @@ static int gru_weight_grads_impl(int E1, int H, int depth, const float* Hs, cons
         gp[2].A = dq0;
         gp[2].B = ggpm_slot_ptr(Hs, first_slot, slot, st16);
         Ks[2] = KQ;
-        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, tall_mode);
-        if (rc) return rc;
-        if (!skip_bu) {
+        if (!skip_bu) {      // (the light column sum first, the contraction last)
             rc = ggpm_colsum_any(dq0, Hp, KQ, H, dbu, csws, st16, stream);
             if (rc) return rc;
         }
+        rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream, tall_mode);
+        if (rc) return rc;
     } else {
         rc = ggpm_gemm_tall_grouped(H, H, 2, gp, Ks, skws, skbytes, stream, tall_mode);
         if (rc) return rc;
@@ -1375,9 +1375,10 @@ extern "C" int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const 
                                      {DZP, Hp, Ss, Hp, dWz_h, ld_dwz, H, nullptr, 0, GGPM_ACT_NONE, 0},
                                      {DQ, Hp, Hs, Hp, dUr, ld_dur, H, nullptr, 0, GGPM_ACT_NONE, 0}};
     const int Ks[3] = {rows, rows, rows_q};
-    int rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
+    // (the light column sum first: whatever else shares the GPU at the end of a pass, the stream ends with the contraction)
+    int rc = ggpm_colsum(DQ, Hp, rows_q, H, dbu, csws, stream);
     if (rc) return rc;
-    rc = ggpm_colsum(DQ, Hp, rows_q, H, dbu, csws, stream);
+    rc = ggpm_gemm_tall_grouped(H, H, 3, gp, Ks, skws, skbytes, stream);
     if (rc) return rc;
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
