@@ -19,12 +19,14 @@ for C in GRU LSTM; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc_$C -- python3 $B $QUICK --rnn $C > $OUT/prof_enc_$C.log 2>&1
   python3 $ROOT/tools/prof_summary.py /tmp/prof_enc_$C --steps 16 --label "encoder step $C (bench.py $QUICK --rnn $C)" > $OUT/${C}_kernel_stats.txt
   python3 $ROOT/tools/vae_timeline.py /tmp/prof_enc_$C 3 > $OUT/${C}_queue_timeline.txt
+  python3 $ROOT/tools/step_listing.py /tmp/prof_enc_$C 30 > $OUT/${C}_step_listing.txt
   rm -rf /tmp/prof_vae_$C
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_vae_$C -- python3 $B --only-vae --vae-profile resident --rnn $C > $OUT/prof_vae_$C.log 2>&1
   python3 $ROOT/tools/prof_summary.py /tmp/prof_vae_$C --steps 20 --label "full VAE step $C, schedules resident (bench.py --only-vae --vae-profile resident)" > $OUT/vae_${C}_kernel_stats.txt
 done
 python3 $ROOT/tools/vae_launches.py GRU=/tmp/prof_vae_GRU LSTM=/tmp/prof_vae_LSTM > $OUT/vae_launches.json
 python3 $ROOT/tools/vae_timeline.py /tmp/prof_vae_GRU 3 > $OUT/vae_GRU_queue_timeline.txt
+python3 $ROOT/tools/step_listing.py /tmp/prof_vae_GRU 25 > $OUT/vae_GRU_step_listing.txt
 rm -rf /tmp/prof_vae_loop
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_vae_loop -- python3 $B --only-vae --vae-profile in_loop > $OUT/prof_vae_loop.log 2>&1
 python3 $ROOT/tools/prof_summary.py /tmp/prof_vae_loop --steps 20 --label "full VAE step GRU as vae_train.py:78 calls it: host batch in, schedule + uploads inside the step, no memoised index structures" > $OUT/vae_GRU_in_loop_kernel_stats.txt
@@ -52,6 +54,5 @@ for C in GRU LSTM; do
 done
 
 cd $ROOT
-python3 tools/parity_report.py --config 4 --rnn GRU --batch 4 --orders > $OUT/parity_report_configs4_gru.txt 2>&1
 python3 tools/parity_report.py --config 1 --rnn GRU > $OUT/parity_report_configs1_gru.txt 2>&1
 ls -la $OUT | head -40

@@ -28,6 +28,8 @@ from oracle import ref_encoder as ref
 
 
 def main():
+    from ggpm_amd.launcher import host_cores
+    torch.set_num_threads(host_cores())        # (the oracle's CPU runs: this process's CPU share, not every visible core)
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--rnn", default=None)
