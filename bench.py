@@ -227,10 +227,26 @@ class Workload:
             from ggpm_amd.dataloader import DevicePrefetcher
             self.host_iter = iter(DevicePrefetcher(itertools.cycle(self.pool), device=dev, depth=2))
 
+    # steps the host may be ahead of the GPU.  This loop reads nothing back, so without a bound the host (2.0 ms of enqueue
+    # per 2.8 ms step) gets 8-10 steps ahead inside a 30-step region, every step in flight holds its own ~1 GB arena of saved
+    # states, and whenever the lead reaches a new maximum the caching allocator goes to the device for one more (5 ms each;
+    # tools/probe/pool_growth.py: 22 arenas = 21.6 GB reserved for 0.06 GB of live tensors, still growing at step 210).  A real
+    # loop is bounded by its own metrics read (vae_train.py:86-94 reads them every step); here: step i waits for step i - 2.
+    MAX_LEAD = 2
+
     def step(self, i):
         from ggpm_amd.property_vae import rsample
         m = self.model
         tree, graph = next(self.host_iter) if self.host_iter is not None else self.dev_batches[i % len(self.dev_batches)]
+        evs = getattr(self, "_step_events", None)
+        if evs is None:
+            evs = self._step_events = [torch.cuda.Event() for _ in range(self.MAX_LEAD)]
+            self._step_no = 0
+        ev = evs[self._step_no % self.MAX_LEAD]
+        self._step_no += 1
+        t_w = time.perf_counter()
+        ev.synchronize()                  # (the step MAX_LEAD back; returns at once while the host is not that far ahead)
+        self._lead_wait = getattr(self, "_lead_wait", 0.0) + (time.perf_counter() - t_w)
         self.sync.zero_grad()
         hroot, hnode, hinter, hatom = m.encoder.forward_padded(tree, graph)
         _, kl = rsample(hroot, m.R_mean, m.R_var, perturb=False)
@@ -238,6 +254,7 @@ class Workload:
         loss.backward()
         self.sync.all_reduce()
         self.opt.step()
+        ev.record()
         return loss
 
     def fence(self):
@@ -259,10 +276,11 @@ class Workload:
             _settle_gc()
             self.fence()
             allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            self._lead_wait = 0.0
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(first + i)
-            host = time.perf_counter() - t0
+            host = time.perf_counter() - t0 - self._lead_wait      # (enqueue time proper: without the waits of MAX_LEAD)
             self.fence()
             elapsed = time.perf_counter() - t0
             grew = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0
@@ -333,6 +351,7 @@ class Workload:
                "unit": "molecules/s", "rnn_type": self.rnn, "warmup_steps_run": warm,
                "timed_regions_repeated": getattr(self, "regions_repeated", 0),
                "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 4),
+               "host_lead_bound_steps": self.MAX_LEAD,
                "algorithmic_gflop_per_step_per_gpu": round(fl_full / 1e9, 2),
                "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
                # executed flops over the measured time: the tree-side levels are credited only with the depth steps
@@ -917,6 +936,7 @@ def main():
                    "algorithmic_gflop_per_step_per_gpu": m["algorithmic_gflop_per_step_per_gpu"],
                    "executed_gflop_per_step_per_gpu": m["executed_gflop_per_step_per_gpu"]},
         "host_enqueue_ms_per_step": m["host_enqueue_ms_per_step"],
+        "host_lead_bound_steps": m["host_lead_bound_steps"],       # step i waits for step i - 2 (Workload.MAX_LEAD)
         "step_tflops_executed": m["step_tflops_executed"],
     }
     for k in ("full_depth_loops", "roofline"):
