@@ -257,6 +257,15 @@ class Workload:
         ev.record()
         return loss
 
+    def _any_rank(self, flag: bool) -> bool:
+        """`flag` on any rank (one rank: itself) -- for decisions that change how many steps, i.e. collectives, a rank runs."""
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if flag else 0.0], device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
     def fence(self):
         import torch.distributed as dist
         torch.cuda.synchronize()
@@ -303,16 +312,22 @@ class Workload:
         # there (measured with tools/step_jitter.py: 5 ms at configs[1] sizes, 250-300 ms at configs[4] sizes, in ONE step)
         # ... and for at least a second of wall time: the first GPU process on a freshly acquired box ran its first timed region
         # 10-60 % slow (3.2 / 4.8 ms per step where every later process measured 2.9) -- clocks, page cache, lazily loaded code
+        # Every rank runs the SAME number of warm-up steps -- each step holds a collective -- so what ends the warm-up (a
+        # second of wall time, an allocation-free pass) is decided by all ranks together (`_any_rank`), in chunks of 8 steps.
         warm = max(a.warmup, len(self.dev_batches))
         t_warm, i = time.perf_counter(), 0
-        while i < warm or (time.perf_counter() - t_warm < 1.0 and i < 4000):
+        while i < warm:
             self.step(i)
             if i == 0:
                 torch.cuda.synchronize()
                 log("first step done")
             i += 1
-            if i >= warm and i % 8 == 0:
-                torch.cuda.synchronize()          # (the host runs ahead of the GPU: count GPU time, not enqueue time)
+        torch.cuda.synchronize()
+        while i < 4000 and self._any_rank(time.perf_counter() - t_warm < 1.0):
+            for _k in range(8):
+                self.step(i)
+                i += 1
+            torch.cuda.synchronize()              # (the host runs ahead of the GPU: count GPU time, not enqueue time)
         # ... and until one more pass over the pool (at least as many steps as the timed region has) goes by without a device
         # allocation, three extra passes at most: the allocator's pool has then stopped growing for these shapes
         extra = max(len(self.dev_batches), min(a.steps, 8))
@@ -323,7 +338,7 @@ class Workload:
                 self.step(i)
                 i += 1
             torch.cuda.synchronize()
-            if torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) == n0:
+            if not self._any_rank(torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) != n0):
                 break
         warm = i
         self.warmup_run = warm
