@@ -19,7 +19,7 @@ def pytest_configure(config):
     # torch's default of one thread per visible core has them fight over that share)
     import torch
     from ggpm_amd.launcher import host_cores
-    torch.set_num_threads(host_cores())
+    torch.set_num_threads(min(16, host_cores()))
 
 
 def _have_gpu():

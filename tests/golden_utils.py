@@ -416,7 +416,7 @@ class OracleRuns:
         self.dir = tempfile.TemporaryDirectory(prefix="ggpm_oracle_")
         from ggpm_amd.launcher import host_cores          # (affinity capped by the cgroup quota: a GPU box shows 256 CPUs and
         cores = host_cores()                               # grants 16 -- workers with 128 threads each took 70-110 s per case)
-        share = max(1, cores // max(1, min(len(jobs), self.MAX_PROCS)))
+        share = max(1, min(16, cores // max(1, min(len(jobs), self.MAX_PROCS))))      # (the oracle's small ops gain nothing past 16 threads)
         self.pending, self.procs = [], {}
         for name, j in jobs.items():
             job = dict(rnn=rnn, depth=depth, sd=sd, tree=tree, graph=graph, **j)
