@@ -340,6 +340,25 @@ class Workload:
             torch.cuda.synchronize()
             if not self._any_rank(torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) != n0):
                 break
+        # more than one rank: ONE all-reduce of the flat gradient behind the backward, or the slice in front of the atom level's
+        # parameters reduced on the second stream while that level's backward still runs (FlatGradSync.bucketed) -- which is
+        # faster depends on the fabric and on what a collective costs beside the depth kernels, so both forms are timed here
+        # (8 steps each, max over ranks: every rank sees the same two numbers and makes the same choice)
+        self.allreduce_choice = None
+        if self.world > 1 and self.sync.early_numel > 0 and "GGPM_BUCKETED_ALLREDUCE" not in os.environ:
+            t_form = {}
+            for form in (False, True):
+                self.sync.bucketed = form
+                for _k in range(4):
+                    self.step(i)
+                    i += 1
+                t_form[form] = self.timed(8, i)[0] / 8
+                i += 8
+            self.sync.bucketed = t_form[True] < t_form[False]
+            self.allreduce_choice = {"form": "bucketed" if self.sync.bucketed else "single",
+                                     "ms_per_step_single": round(1e3 * t_form[False], 4),
+                                     "ms_per_step_bucketed": round(1e3 * t_form[True], 4)}
+            log("all-reduce: %s" % self.allreduce_choice)
         warm = i
         self.warmup_run = warm
         log("warm-up done (%d steps); timing %d steps" % (warm, a.steps))
@@ -367,6 +386,7 @@ class Workload:
                "timed_regions_repeated": getattr(self, "regions_repeated", 0),
                "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 4),
                "host_lead_bound_steps": self.MAX_LEAD,
+               "allreduce": getattr(self, "allreduce_choice", None),
                "algorithmic_gflop_per_step_per_gpu": round(fl_full / 1e9, 2),
                "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
                # executed flops over the measured time: the tree-side levels are credited only with the depth steps
@@ -952,6 +972,7 @@ def main():
                    "executed_gflop_per_step_per_gpu": m["executed_gflop_per_step_per_gpu"]},
         "host_enqueue_ms_per_step": m["host_enqueue_ms_per_step"],
         "host_lead_bound_steps": m["host_lead_bound_steps"],       # step i waits for step i - 2 (Workload.MAX_LEAD)
+        "allreduce": m.get("allreduce"),                           # N > 1: which form of the gradient exchange was faster here
         "step_tflops_executed": m["step_tflops_executed"],
     }
     for k in ("full_depth_loops", "roofline"):
