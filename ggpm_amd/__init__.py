@@ -11,6 +11,9 @@ import os as _os
 # 5.45 ms/step).  Read by the HIP runtime when it starts, so it is set HERE -- importing the package comes before the
 # first HIP call of any program that uses it -- and never overrides a value the user chose.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work (RCCL, tensors shared between rank processes): this pool's host driver supports dmabuf IPC only; with
+# the legacy mode hipIpcGetMemHandle fails with "invalid argument".  Same rule: before the runtime starts, never overriding.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 __all__ = ["GRU", "LSTM", "MPNEncoder", "HierMPNEncoder", "MotifEncoder", "IncMPNEncoder", "IncHierMPNEncoder",
            "IncEncoder", "HierEncoderVAE", "rsample", "make_cuda", "DevicePrefetcher"]
