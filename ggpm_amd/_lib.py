@@ -83,6 +83,7 @@ SIGNATURES = {
     "ggpm_softmax_ce": (I, [P, I, I, I, P, I, P, P, P, P, I, P, P, P]),
     "ggpm_bce_logits": (I, [P, P, I, P, P, P, P]),
     "ggpm_scale_rows": (I, [P, I, I, I, P, P]),
+    "ggpm_head_accuracies": (I, [P, P, P, P, I, P, I, P, I, P, I, I, I, I, P, P]),
     "ggpm_dropout": (I, [P, I, I, I, ctypes.c_float, ctypes.c_uint, ctypes.c_uint, I, P]),
     "ggpm_encoder_saved_bytes": (c_size_t, [P]),
     "ggpm_encoder_work_bytes": (c_size_t, [P]),

@@ -129,6 +129,63 @@ extern "C" int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scal
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The four accuracies of a teacher-forced decoder pass in ONE launch (reference ggpm/decoder.py:262-283, get_accuracy /
+// get_accuracy_bin / get_accuracy_sym of ggpm/nnutils.py:84-97): block 0 = motif class, 1 = attachment class (arg-max
+// of the loss kernel against the label), 2 = topology (score >= 0 against the label), 3 = attachment (the first
+// candidate holds the row maximum).  Counts are integers: the result does not depend on the summation order.
+namespace {
+struct AccArgs {
+    const int32_t *cls_pred, *icls_pred;
+    const void *cls_lab, *icls_lab, *topo_lab;
+    const float *topo, *assm;
+    int n_cls, n_topo, ld_topo, P, C, ld_assm, lab64;
+    float* out;
+};
+__device__ __forceinline__ long long acc_label(const void* p, int i, int lab64) {
+    return lab64 ? reinterpret_cast<const long long*>(p)[i] : (long long)reinterpret_cast<const int32_t*>(p)[i];
+}
+__global__ void __launch_bounds__(256) head_accuracies_k(AccArgs a) {
+    __shared__ int red[256];
+    const int which = blockIdx.x;
+    const int n = which < 2 ? a.n_cls : which == 2 ? a.n_topo : a.P;
+    int hit = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (which == 0) hit += (long long)a.cls_pred[i] == acc_label(a.cls_lab, i, a.lab64);
+        else if (which == 1) hit += (long long)a.icls_pred[i] == acc_label(a.icls_lab, i, a.lab64);
+        else if (which == 2) hit += (long long)(a.topo[(size_t)i * a.ld_topo] >= 0.f) == acc_label(a.topo_lab, i, a.lab64);
+        else {
+            const float* row = a.assm + (size_t)i * a.ld_assm;
+            float m = row[0];
+            for (int c = 1; c < a.C; ++c) m = fmaxf(m, row[c]);
+            hit += row[0] == m;
+        }
+    }
+    red[threadIdx.x] = hit;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.out[which] = (which == 3 && n <= 0) ? 1.f : (float)red[0] / (float)n;
+}
+}  // namespace
+
+extern "C" int ggpm_head_accuracies(const int32_t* cls_pred, const void* cls_lab, const int32_t* icls_pred, const void* icls_lab,
+                                    int n_cls, const float* topo, int ld_topo, const void* topo_lab, int n_topo,
+                                    const float* assm, int ld_assm, int P, int C, int labels_int64, float* out4,
+                                    ggpm_stream_t stream) {
+    GGPM_CLEAR_STALE_ERROR();
+    if (!out4 || n_cls < 0 || n_topo < 0 || P < 0 || (n_cls > 0 && (!cls_pred || !cls_lab || !icls_pred || !icls_lab)) ||
+        (n_topo > 0 && (!topo || !topo_lab || ld_topo < 1)) || (P > 0 && (!assm || C < 1 || ld_assm < C)))
+        return GGPM_ERR_ARG;
+    AccArgs a = {cls_pred, icls_pred, cls_lab, icls_lab, topo_lab, topo, assm, n_cls, n_topo, ld_topo, P, C, ld_assm,
+                 labels_int64 ? 1 : 0, out4};
+    head_accuracies_k<<<4, 256, 0, (hipStream_t)stream>>>(a);
+    GGPM_CHECK_LAUNCH();
+    return GGPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // KL head of HierPropertyVAE.rsample (reference ggpm/property_vae.py:26-33), the elementwise part after the two
 // [B,H]x[H,L] products:  lv = -|pv| ; kl = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B ; z = mean + exp(lv/2) * eps.
 // One workgroup (B*L is ~1e3); the sum runs over fixed slots -> bitwise reproducible.

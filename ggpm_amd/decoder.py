@@ -725,19 +725,22 @@ class HierMPNDecoder(ScoreHeads):
         cls_vecs = torch.cat([init_vecs, rnn_cell.get_hidden_state(h_t).index_select(0, T["cls_mess"])], dim=0)
         return htree_node[:, :H], cls_vecs, assm_vecs, assm_dest
 
-    def _assm_head(self, schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev):
+    def _assm_head(self, schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev, want_scores=False):
         """(attachment loss, accuracy) of the batch -- ggpm/decoder.py:252-254, 276-281"""
         H = self.hidden_size
         P, C = D["n_assm"], schedule.max_cls_size
         if P <= 0:
-            return 0, 1
+            return 0, (None if want_scores else 1)
         vec = torch.cat(assm_vecs, dim=0)
         buf = torch.zeros(P * C, vec.shape[1], dtype=torch.float32, device=dev)
         buf = buf.index_copy(0, torch.cat(assm_dest), vec)       # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
         scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H])
         labels = torch.zeros(P, dtype=torch.long, device=dev)    # "the label is always the first of assm_cands"
-        assm_loss, _ = cross_entropy_sum(scores.contiguous(), labels)
+        scores = scores.contiguous()
+        assm_loss, _ = cross_entropy_sum(scores, labels)
         s = scores.detach()
+        if want_scores:                 # (the caller forms all four accuracies in one launch)
+            return assm_loss, s
         assm_acc = (s[:, 0] == s.max(dim=-1)[0]).float().sum() / P      # get_accuracy_sym
         return assm_loss, assm_acc
 
@@ -746,12 +749,18 @@ class HierMPNDecoder(ScoreHeads):
         H = self.hidden_size
         topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch32"], topo_vecs)
         topo_loss = bce_with_logits_sum(topo_scores, D["topo_label"])
-        topo_acc = ((topo_scores.detach() >= 0).long() == D["topo_label"]).float().sum() / D["topo_label"].numel()
-
         cls_loss, cls_pred, icls_pred = self.cls_losses(src_tree_vecs, D["cls_batch32"], cls_vecs, D["cls_clab"],
                                                         D["cls_ilab"])
-        cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
-
-        assm_loss, assm_acc = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev)
+        labs = (D["topo_label"], D["cls_clab"], D["cls_ilab"])
+        if topo_scores.is_cuda and len({t.dtype for t in labs}) == 1 and labs[0].dtype in (torch.int64, torch.int32):
+            # the four accuracies in ONE launch (ggpm_head_accuracies) instead of ~19 elementwise / reduction launches
+            assm_loss, assm_scores = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev, want_scores=True)
+            acc = F_.head_accuracies(cls_pred, D["cls_clab"], icls_pred, D["cls_ilab"], topo_scores.detach(), D["topo_label"],
+                                     assm_scores)
+            cls_acc, icls_acc, topo_acc, assm_acc = acc[0], acc[1], acc[2], acc[3]
+        else:
+            topo_acc = ((topo_scores.detach() >= 0).long() == D["topo_label"]).float().sum() / D["topo_label"].numel()
+            cls_acc, icls_acc = _accuracy(cls_pred, D["cls_clab"]), _accuracy(icls_pred, D["cls_ilab"])
+            assm_loss, assm_acc = self._assm_head(schedule, D, src_graph_vecs, assm_vecs, assm_dest, dev)
         loss = (topo_loss + cls_loss + assm_loss) / B
         return loss, cls_acc, icls_acc, topo_acc, assm_acc

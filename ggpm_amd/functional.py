@@ -255,6 +255,23 @@ def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems, splitk: boo
                "gemm_grouped")
 
 
+def head_accuracies(cls_pred, cls_lab, icls_pred, icls_lab, topo, topo_lab, assm) -> torch.Tensor:
+    """-> [4] float tensor {motif-class, attachment-class, topology, attachment accuracy} (ggpm_head_accuracies: one launch).
+    ``cls_pred`` / ``icls_pred``: int32 arg-max per row; ``topo``: 1-D scores (any stride); ``assm``: [P, C] scores or None."""
+    _need_gpu(topo, cls_pred)
+    out = torch.empty(4, dtype=torch.float32, device=topo.device)
+    lab64 = int(cls_lab.dtype == torch.int64)
+    labs = [t if t.is_contiguous() else t.contiguous() for t in (cls_lab, icls_lab, topo_lab)]
+    preds = [t if (t.dtype == torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous() for t in (cls_pred, icls_pred)]
+    n_topo = topo.numel()
+    ld_topo = topo.stride(0) if n_topo > 1 else 1
+    P_, C_, ld_assm = (assm.shape[0], assm.shape[1], assm.stride(0)) if assm is not None else (0, 1, 1)
+    _lib.check(_lib.load().ggpm_head_accuracies(_p(preds[0]), _p(labs[0]), _p(preds[1]), _p(labs[1]), preds[0].numel(), _p(topo),
+                                                ld_topo, _p(labs[2]), n_topo, _p(assm), ld_assm, P_, C_, lab64, _p(out),
+                                                _stream()), "head_accuracies")
+    return out
+
+
 def gemm_ksegments(tb: int, M: int, N: int, As, ldas, Bs, ldbs, Ks, C: torch.Tensor, ldc: int, n_pad: int,
                    bias: Optional[torch.Tensor] = None, accumulate: bool = False, act: int = ACT_NONE,
                    zero_row0: bool = False) -> None:

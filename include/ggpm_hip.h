@@ -450,6 +450,14 @@ int ggpm_softmax_ce(const float* logits, int ld, int M, int N, const float* mask
                     ggpm_stream_t stream);
 int ggpm_bce_logits(const float* x, const float* y, int M, float* loss, float* dx, float* work, ggpm_stream_t stream);
 int ggpm_scale_rows(float* d, int ld, int M, int N, const float* scale, ggpm_stream_t stream);
+/* The four accuracies of the teacher-forced decoder pass (ggpm/decoder.py:262-283 with get_accuracy / get_accuracy_bin /
+ * get_accuracy_sym, ggpm/nnutils.py:84-97) in one launch: out4 = {motif class, attachment class, topology, attachment}.
+ * cls_pred / icls_pred: the arg-max ggpm_softmax_ce returned; topo: the topology scores (element i at topo[i * ld_topo]);
+ * assm: the [P x C] attachment scores (row stride ld_assm; P = 0: out4[3] = 1 as the reference's `assm_acc = 1`); labels
+ * int64 (labels_int64 = 1) or int32. */
+int ggpm_head_accuracies(const int32_t* cls_pred, const void* cls_lab, const int32_t* icls_pred, const void* icls_lab,
+                         int n_cls, const float* topo, int ld_topo, const void* topo_lab, int n_topo, const float* assm,
+                         int ld_assm, int P, int C, int labels_int64, float* out4, ggpm_stream_t stream);
 
 /* KL head, elementwise part of HierPropertyVAE.rsample (ggpm/property_vae.py:26-33) after the two [B,H]x[H,L] products:
  * lv = -|pv|; kl[0] = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B; z = mean + exp(lv/2) * eps (eps null: z = mean).

@@ -1470,3 +1470,29 @@ def test_softmax_ce_and_bce_kernels_against_torch(M, N, masked):
     assert float((s.grad - s2.grad).abs().max()) <= 2e-6
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cls,n_topo,P,C,dtype", [(700, 1400, 300, 9, torch.int64), (1, 1, 1, 1, torch.int32), (513, 257, 0, 4, torch.int64),
+                                                     (3000, 5000, 2049, 13, torch.int32)])
+def test_head_accuracies_match_the_reference_formulas(n_cls, n_topo, P, C, dtype):
+    """ggpm_head_accuracies (one launch) against get_accuracy / get_accuracy_bin / get_accuracy_sym as the reference writes
+    them (ggpm/nnutils.py:84-97): strided topology scores, ties in the attachment rows, no attachment prediction at all."""
+    from ggpm_amd import functional as F_
+    dev = _dev()
+    g = torch.Generator().manual_seed(n_cls + 3 * n_topo + 7 * P)
+    cls_lab = torch.randint(0, 50, (n_cls,), generator=g).to(dtype)
+    icls_lab = torch.randint(0, 90, (n_cls,), generator=g).to(dtype)
+    cls_pred = torch.where(torch.rand(n_cls, generator=g) < 0.6, cls_lab.long(), torch.randint(0, 50, (n_cls,), generator=g)).to(torch.int32)
+    icls_pred = torch.where(torch.rand(n_cls, generator=g) < 0.3, icls_lab.long(), torch.randint(0, 90, (n_cls,), generator=g)).to(torch.int32)
+    topo_full = torch.randn(n_topo, 4, generator=g)
+    topo_full[::7, 0] = 0.0                                   # (>= 0 counts as a "1")
+    topo_lab = torch.randint(0, 2, (n_topo,), generator=g).to(dtype)
+    assm = torch.randn(max(P, 1), C, generator=g).round(decimals=1)[:P]      # coarse values: ties between candidates
+    want = [float((cls_pred.long() == cls_lab.long()).float().sum() / n_cls),
+            float((icls_pred.long() == icls_lab.long()).float().sum() / n_cls),
+            float(((topo_full[:, 0] >= 0).long() == topo_lab.long()).float().sum() / n_topo),
+            float((assm[:, 0] == assm.max(dim=-1)[0]).float().sum() / P) if P else 1.0]
+    got = F_.head_accuracies(cls_pred.to(dev), cls_lab.to(dev), icls_pred.to(dev), icls_lab.to(dev), topo_full.to(dev)[:, 0],
+                             topo_lab.to(dev), assm.to(dev) if P else None).cpu().tolist()
+    assert np.allclose(got, want, rtol=0, atol=1e-6), (got, want)
