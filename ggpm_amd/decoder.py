@@ -439,6 +439,14 @@ def synth_orders(specs, tree_scope):
     return out
 
 
+def _memo(D: dict, key: str, make):
+    """``D[key]``, made on first use: tensors derived from a decode schedule's device tables live as long as the tables."""
+    v = D.get(key)
+    if v is None:
+        v = D[key] = make()
+    return v
+
+
 def _accuracy(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """get_accuracy (ggpm/nnutils.py:84-87) from the arg-max the loss kernel already produced."""
     return (pred.long() == labels).float().sum() / labels.numel()
@@ -732,10 +740,18 @@ class HierMPNDecoder(ScoreHeads):
         if P <= 0:
             return 0, (None if want_scores else 1)
         vec = torch.cat(assm_vecs, dim=0)
+        # (index tables of a resident schedule: concatenated once per ordering -- the batched and the step-by-step forms list
+        # the predictions in different orders -- and ONE entry, so a caller that rebuilds the pieces every step keeps nothing)
+        key = tuple(id(t) for t in assm_dest)
+        held = D.get("assm_dest_all")
+        if held is None or held[0] != key:
+            held = D["assm_dest_all"] = (key, torch.cat(assm_dest), list(assm_dest))      # (the pieces are kept: ids stay theirs)
+        dest = held[1]
         buf = torch.zeros(P * C, vec.shape[1], dtype=torch.float32, device=dev)
-        buf = buf.index_copy(0, torch.cat(assm_dest), vec)       # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
-        scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H])
-        labels = torch.zeros(P, dtype=torch.long, device=dev)    # "the label is always the first of assm_cands"
+        buf.index_copy_(0, dest, vec)                             # F.pad to max_cls_size rows, ggpm/decoder.py:252-254
+        scores = self.get_assm_score(src_graph_vecs, D["assm_batch32"], buf.view(P, C, -1)[:, :, :H], rows_padded=buf)
+        # "the label is always the first of assm_cands"
+        labels = _memo(D, "assm_labels32", lambda: torch.zeros(P, dtype=torch.int32, device=dev))
         scores = scores.contiguous()
         assm_loss, _ = cross_entropy_sum(scores, labels)
         s = scores.detach()
@@ -748,9 +764,11 @@ class HierMPNDecoder(ScoreHeads):
         """The three batched heads and their losses / accuracies (ggpm/decoder.py:261-284)."""
         H = self.hidden_size
         topo_scores = self.get_topo_score(src_tree_vecs, D["topo_batch32"], topo_vecs)
-        topo_loss = bce_with_logits_sum(topo_scores, D["topo_label"])
-        cls_loss, cls_pred, icls_pred = self.cls_losses(src_tree_vecs, D["cls_batch32"], cls_vecs, D["cls_clab"],
-                                                        D["cls_ilab"])
+        # the loss kernels read float targets / int32 labels: converted once per schedule, not once per step
+        topo_loss = bce_with_logits_sum(topo_scores, _memo(D, "topo_label_f32", lambda: D["topo_label"].to(torch.float32)))
+        cls_loss, cls_pred, icls_pred = self.cls_losses(
+            src_tree_vecs, D["cls_batch32"], cls_vecs, _memo(D, "cls_clab32", lambda: D["cls_clab"].to(torch.int32).contiguous()),
+            _memo(D, "cls_ilab32", lambda: D["cls_ilab"].to(torch.int32).contiguous()))
         labs = (D["topo_label"], D["cls_clab"], D["cls_ilab"])
         if topo_scores.is_cuda and len({t.dtype for t in labs}) == 1 and labs[0].dtype in (torch.int64, torch.int32):
             # the four accuracies in ONE launch (ggpm_head_accuracies) instead of ~19 elementwise / reduction launches

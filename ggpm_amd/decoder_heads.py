@@ -122,7 +122,9 @@ class ScoreHeads(nn.Module):
         return F_.gather_rows(src, idx, F_.csr_from_index(idx, ncols=src.shape[0]), L, (L + 3) // 4 * 4)
 
     def _parts(self, src_vecs, batch_idx, vecs):
-        return [vecs.contiguous(), self._context(src_vecs, batch_idx)], [self.hidden_size, self.latent_size]
+        # (a [rows, H] view of a row-padded buffer goes to the GEMM as it is: its leading dimension is the buffer's)
+        v = vecs if vecs.dim() == 2 and vecs.stride(1) == 1 and vecs.stride(0) % 4 == 0 else vecs.contiguous()
+        return [v, self._context(src_vecs, batch_idx)], [self.hidden_size, self.latent_size]
 
     def get_topo_score(self, src_tree_vecs, batch_idx, topo_vecs):
         """reference ggpm/decoder.py:136-141"""
@@ -148,10 +150,11 @@ class ScoreHeads(nn.Module):
         l2, a2 = cross_entropy_sum(icls_scores, icls_labs, mask=mask, mask_row=cls_labs)
         return l1 + l2, a1, a2
 
-    def get_assm_score(self, src_graph_vecs, batch_idx, assm_vecs):
-        """reference ggpm/decoder.py:159-164"""
+    def get_assm_score(self, src_graph_vecs, batch_idx, assm_vecs, rows_padded=None):
+        """reference ggpm/decoder.py:159-164.  ``rows_padded``: ``assm_vecs`` as a contiguous [P * C, ld >= H] buffer (then
+        ``assm_vecs`` itself is only read for its shape [P, C, H]: no slice-and-copy of the padded rows)."""
         shape = assm_vecs.shape
-        flat = assm_vecs.reshape(-1, shape[-1]).contiguous()
+        flat = rows_padded if rows_padded is not None else assm_vecs.reshape(-1, shape[-1]).contiguous()
         proj = F_.linear([flat], [self.hidden_size], self.W_assm.weight, self.W_assm.bias)[:, :self.latent_size]
         cxt = self._context(src_graph_vecs, batch_idx)[:, :self.latent_size]
         return (proj * cxt).sum(dim=-1).view(shape[:-1])
