@@ -190,6 +190,35 @@ def cpu_baseline(batches, rnn, H, depth, latent, n_motif, n_attach, budget_s=24.
     return out
 
 
+def depth_kernel_bytes(kname, E, H, dbar, st16):
+    """HBM bytes ONE launch of a depth kernel reads + writes on a level of E messages (algorithmic: every array once, the
+    gathered rows dbar times; weights stream from L2 and are left out), at the stored element sizes: `s` = 2 B for the arrays
+    ggpm_level_bf16_storage keeps in bf16 (state h / q, stashes S G Z M resp. S I O U, dS / dG, DQ / DZP / DMP resp. DQ / DI /
+    DO / DU), 4 B for the rest (gate inputs X and their gradients, R / F, the LSTM cell state, ds_dir).  Per message row and
+    hidden column (csrc/mpn_gru.hip, mpn_lstm.hip; the unfused forms, as two-row-tile levels launch them):
+      gru_fwd_a   reads Xr Xz Xh (12), gathers h q (2 s dbar); writes h' (s), S G Z M (4 s), R (4)
+      gru_fwd_b   reads h' (s); writes q' (s)
+      gru_bwd_a   reads own h q (2 s), per successor Xr dS dG ((4 + 2 s) dbar), S Z M (3 s); writes DQ DZP DMP (3 s), ds_dir (4)
+      gru_bwd_b   reads DZP DMP (2 s), ds_dir R (8); writes dS dG (2 s); dXr read-modify-write (8)
+      lstm_fwd_a  reads Xf Xi Xo Xu (16), gathers h qf (2 s dbar) and c (4 dbar); writes h' (s), c' (4), S I O U (4 s), F (4)
+      lstm_fwd_b  reads h' (s); writes qf' (s)
+      lstm_bwd_a  reads own h qf (2 s), c (4), per successor Xf dS (4 + s) dbar and dFC (4 dbar), S I O U (4 s), c' (4);
+                  writes DQ DI DO DU (4 s), dFC (4), ds_dir (4)
+      lstm_bwd_b  reads DI DO DU (3 s), ds_dir F (8); writes dS (s); dXf read-modify-write (8)"""
+    s = 2.0 if st16 else 4.0
+    per_elem = {
+        "gru_fwd_a": 12 + 2 * s * dbar + s + 4 * s + 4,
+        "gru_fwd_b": 2 * s,
+        "gru_bwd_a": 2 * s + (4 + 2 * s) * dbar + 3 * s + 3 * s + 4,
+        "gru_bwd_b": 2 * s + 8 + 2 * s + 8,
+        "lstm_fwd_a": 16 + (2 * s + 4) * dbar + s + 4 + 4 * s + 4,
+        "lstm_fwd_b": 2 * s,
+        "lstm_bwd_a": 2 * s + 4 + (4 + s + 4) * dbar + 4 * s + 4 + 4 * s + 8,
+        "lstm_bwd_b": 3 * s + 8 + s + 8,
+    }[kname]
+    return per_elem * E * H
+
+
 class Workload:
     """One (config, message function) pair on this rank: model, optimizer, device-resident batches."""
 
@@ -273,14 +302,17 @@ class Workload:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(self, steps, first):
+    def timed(self, steps, first, what="timed"):
         """EXACTLY `steps` steps between two fences; max over ranks.  -> (elapsed s, host enqueue s)
 
         A region during which PyTorch's caching allocator went to the device for memory (``num_device_alloc`` moved) is
-        measured again, at most three times, and the count is kept in ``self.regions_repeated``: such a call stalls ONE step by
-        5 ms (configs[1] sizes) to 300 ms (configs[4]) however long the loop has run before (tools/step_jitter.py) -- a
-        one-time cost of the process, not throughput of the step.  (One rank only: ranks must agree on what they run.)"""
+        measured again, at most three times: such a call stalls ONE step by 5 ms (configs[1] sizes) to 300 ms (configs[4])
+        however long the loop has run before (tools/step_jitter.py) -- a one-time cost of the process, not throughput of the
+        step.  Nothing is hidden by that: ``self.region_log[what]`` keeps, for the REPORTED region, the reading of every
+        attempt (the first one included) and the device allocations inside the attempt that was kept.  The same rule on every
+        world size: the ranks decide together (`_any_rank`), since each attempt holds collectives."""
         import torch.distributed as dist
+        readings = []
         for attempt in range(4):
             _settle_gc()
             self.fence()
@@ -293,14 +325,19 @@ class Workload:
             self.fence()
             elapsed = time.perf_counter() - t0
             grew = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0
-            if grew == 0 or self.world > 1 or attempt == 3:
+            if self.world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            readings.append(round(1e3 * elapsed / steps, 4))
+            if attempt == 3 or not self._any_rank(grew > 0):
                 break
             self.regions_repeated = getattr(self, "regions_repeated", 0) + 1
             log("  (%d device allocation(s) inside the timed region, %.3f ms/step: measuring it again)" % (grew, 1e3 * elapsed / steps))
-        if self.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        if not hasattr(self, "region_log"):
+            self.region_log = {}
+        self.region_log[what] = {"attempts": len(readings), "ms_per_step_of_each_attempt": readings,
+                                 "device_allocs_in_reported_attempt": int(grew)}
         return elapsed, host
 
     def measure(self, lib, rank):
@@ -352,7 +389,7 @@ class Workload:
                 for _k in range(4):
                     self.step(i)
                     i += 1
-                t_form[form] = self.timed(8, i)[0] / 8
+                t_form[form] = self.timed(8, i, "allreduce_trial")[0] / 8
                 i += 8
             self.sync.bucketed = t_form[True] < t_form[False]
             self.allreduce_choice = {"form": "bucketed" if self.sync.bucketed else "single",
@@ -362,7 +399,7 @@ class Workload:
         warm = i
         self.warmup_run = warm
         log("warm-up done (%d steps); timing %d steps" % (warm, a.steps))
-        elapsed, host_enqueue = self.timed(a.steps, warm)
+        elapsed, host_enqueue = self.timed(a.steps, warm, "value")
         log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (1e3 * elapsed / a.steps,
                                                                              1e3 * host_enqueue / a.steps))
         chains = [int(getattr(t[0][3], "ggpm_chain", 0)) for t in self.dev_batches]
@@ -375,7 +412,7 @@ class Workload:
             self.dev_batches = [(list(tree[:3]) + [tree[3].view_as(tree[3])] + list(tree[4:]), graph) for tree, graph in hinted]
             for i in range(max(min(a.warmup, 4), min(len(self.dev_batches), 4))):
                 self.step(i)
-            full_elapsed, _ = self.timed(a.steps, warm)
+            full_elapsed, _ = self.timed(a.steps, warm, "full_depth_loops")
             self.dev_batches = hinted
             log("without the tree fixed-point hint: %.3f ms/step" % (1e3 * full_elapsed / a.steps))
         gates = 3 if self.rnn == "GRU" else 4
@@ -384,6 +421,7 @@ class Workload:
         res = {"ms_per_step": round(1e3 * elapsed / a.steps, 4), "value": round(mols / elapsed, 2),
                "unit": "molecules/s", "rnn_type": self.rnn, "warmup_steps_run": warm,
                "timed_regions_repeated": getattr(self, "regions_repeated", 0),
+               "timed_region": self.region_log.get("value"),
                "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 4),
                "host_lead_bound_steps": self.MAX_LEAD,
                "allreduce": getattr(self, "allreduce_choice", None),
@@ -401,6 +439,7 @@ class Workload:
                 "test_tree_fixed_point_shortcut_is_bit_identical)" % (min(chains), max(chains), depth, depth))
             res["full_depth_loops"] = {"ms_per_step": round(1e3 * full_elapsed / a.steps, 4),
                                        "value": round(mols / full_elapsed, 2), "unit": "molecules/s",
+                                       "timed_region": self.region_log.get("full_depth_loops"),
                                        "step_tflops_algorithmic": round(fl_full * self.world / (full_elapsed / a.steps) / 1e12, 3)}
         if not a.no_roofline:
             roof = self.roofline(lib)
@@ -461,18 +500,32 @@ class Workload:
                "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "tree_levels": tree,
                "all_depth_kernels": per}
         if self.gate_dtype == "bf16":
-            # with bf16 gate products the depth kernels are HBM bound.  Algorithmic bytes of one depth step of the
-            # atom level: s H E (2 + G + g dbar) forwards (X reads, gathered state rows, h' / q' written) and twice that
-            # backwards, plus S = 4 stash arrays written (forward) / read (backward); the A launch is charged with all of it.
+            # The bf16 leg is priced against HBM (bf16 gate products leave the matrix pipe 16x faster than fp32).
+            # Bytes of a launch = the arrays THAT kernel reads and writes, at the element size they are stored in
+            # (`depth_kernel_bytes`: 2 B where ggpm_level_bf16_storage keeps a depth-loop array in bf16, 4 B otherwise); the
+            # A + B pair of a depth step stands beside the dominant kernel.  Weights come from L2 and are not counted.
             from ggpm_amd import synth
             st = [synth.batch_stats(t, g)["atom"] for t, g in self.pool]
             E, dbar = float(np.mean([x["E"] for x in st])), float(np.mean([x["dbar"] for x in st]))
-            G, g_rows, S, H = (3, 2, 4, self.cfg["hidden"]) if self.rnn == "GRU" else (4, 3, 4, self.cfg["hidden"])
-            per_depth = 4.0 * H * E * (2 + G + g_rows * dbar)
-            nbytes = (2.0 * per_depth if "bwd" in kname else per_depth) + 4.0 * H * E * S
+            H = self.cfg["hidden"]
+            st16 = bool(lib.ggpm_level_bf16_storage(int(E) + 1, H))
+            nbytes = depth_kernel_bytes(kname, E, H, dbar, st16)
             gbs = nbytes / (k["avg_launch_us"] * 1e-6) / 1e9
+            pair = {}
+            for direction in ("fwd", "bwd"):
+                names = [n for n in per["atom"] if direction in n]
+                if names:
+                    us = sum(per["atom"][n]["avg_launch_us"] for n in names)
+                    by = sum(depth_kernel_bytes(n, E, H, dbar, st16) for n in names)
+                    pair[direction] = {"kernels": names, "us_per_depth_step": round(us, 2), "bytes_per_depth_step": round(by, 1),
+                                       "achieved": round(by / (us * 1e-6) / 1e9, 1), "unit": "GB/s",
+                                       "frac": round(by / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
             out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": round(nbytes, 1),
+                        "stored_element_bytes": 2 if st16 else 4, "depth_step_pairs": pair,
+                        "regime": "latency / phase bound: gather, gate products and epilogue follow each other inside one "
+                                  "workgroup per CU, so neither HBM (this figure) nor the bf16 matrix pipe (`mfma`) binds "
+                                  "(DESIGN 12.5)",
                         "mfma": {"achieved": k["tflops"], "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(k["tflops"] / PEAK_MFMA_BF16_TFLOPS, 4),
                                  "note": "the gate products' flops against the dense bf16 MFMA peak"}})
@@ -588,9 +641,19 @@ class VaeWorkload:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def _timed(self, fn, steps, first):
-        """EXACTLY `steps` calls between two fences, max over ranks -> (ms per step, per-step host marks)"""
-        for attempt in range(4):          # (a region with a device allocation inside is measured again: Workload.timed)
+    def _any_rank(self, flag: bool) -> bool:
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if flag else 0.0], device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
+    def _timed(self, fn, steps, first, what="resident"):
+        """EXACTLY `steps` calls between two fences, max over ranks -> (ms per step, per-step host marks).  A region with a
+        device allocation inside is measured again (Workload.timed: same rule, same record in ``self.region_log[what]``)."""
+        readings = []
+        for attempt in range(4):
             _settle_gc()
             self._fence()
             allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
@@ -604,15 +667,20 @@ class VaeWorkload:
             self._fence()
             dt = time.perf_counter() - t0
             grew = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0
-            if grew == 0 or self.world > 1 or attempt == 3:
+            if self.world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            readings.append(round(1e3 * dt / steps, 4))
+            if attempt == 3 or not self._any_rank(grew > 0):
                 break
             self.regions_repeated = getattr(self, "regions_repeated", 0) + 1
             log("  (%d device allocation(s) inside the timed region, %.3f ms/step: measuring it again)" % (grew, 1e3 * dt / steps))
-        if self.world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        if not hasattr(self, "region_log"):
+            self.region_log = {}
+        self.region_log[what] = {"attempts": len(readings), "ms_per_step_of_each_attempt": readings,
+                                 "device_allocs_in_reported_attempt": int(grew)}
         return 1e3 * dt / steps, [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
 
     def work(self):
@@ -658,7 +726,7 @@ class VaeWorkload:
         warm = 2 * len(self.items)        # two passes over the pool: every batch shape seen, clocks up
         for i in range(warm):
             m = self.step(i)
-        ms, raw = self._timed(self.step, steps, warm)
+        ms, raw = self._timed(self.step, steps, warm, "resident")
         host_issue = self.host_issue_ms
         per = sorted(raw)
         log("full VAE step (%s): %.2f ms/step (per step: min %.2f, median %.2f, max %.2f at step %d; reserved %.1f GB), loss %.3f"
@@ -669,7 +737,7 @@ class VaeWorkload:
         if getattr(self.a, "vae_profile", None) == "in_loop":
             for i in range(len(self.items)):
                 self.step_in_loop(i)
-            loop_ms, _ = self._timed(self.step_in_loop, steps, 0)
+            loop_ms, _ = self._timed(self.step_in_loop, steps, 0, "in_loop")
             return {"ms_per_step": round(ms, 3), "schedule_in_loop_ms": round(loop_ms, 3), "steps": steps, "rnn_type": self.rnn}
         # the same steps with the index structures derived from the resident decode tables (CSRs, transposes, frozen masks)
         # rebuilt on the device every step, as a stream of never-seen batches would have it
@@ -679,20 +747,20 @@ class VaeWorkload:
             F_._MEMO_ON = False
             for i in range(len(self.items)):
                 self.step(i)
-            fresh, _ = self._timed(self.step, min(steps, 20), 0)
+            fresh, _ = self._timed(self.step, min(steps, 20), 0, "rebuilt")
         finally:
-            F_._MEMO_ON = True
+            F_._MEMO_ON = None
         log("  ... %.2f ms/step with the index structures rebuilt every step" % fresh)
         # vae_train.py:78 unchanged: host batch in, make_cuda + decode schedule (C++ builder, two uploads) inside the step
         for i in range(len(self.items)):
             self.step_in_loop(i)
-        loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0)
+        loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0, "in_loop")
         loop_issue = self.host_issue_ms
         # ... and with the loop's iterator wrapped (dataloader.ScheduleAhead): the schedule of batch k+1 built during step k
         self._ahead = None
         for i in range(len(self.items)):
             self.step_ahead(i)
-        ahead_ms, _ = self._timed(self.step_ahead, min(steps, 20), 0)
+        ahead_ms, _ = self._timed(self.step_ahead, min(steps, 20), 0, "ahead")
         self._ahead.close()
         self._ahead = None
         t0 = time.perf_counter()
@@ -709,14 +777,15 @@ class VaeWorkload:
         out = {"ms_per_step": round(ms, 3), "value": round(B * self.world / (ms * 1e-3), 2), "unit": "molecules/s",
                "host_issue_ms": round(host_issue, 3),      # median host time from the start of a step to its last launch
                "timed_regions_repeated": getattr(self, "regions_repeated", 0),
+               "timed_region": self.region_log.get("resident"),
                "ms_per_step_index_structures_rebuilt": round(fresh, 3),
-               "schedule_in_loop": {"ms_per_step": round(loop_ms, 3), "value": round(B * self.world / (loop_ms * 1e-3), 2),
+               "schedule_in_loop": {"ms_per_step": round(loop_ms, 3), "timed_region": self.region_log.get("in_loop"), "value": round(B * self.world / (loop_ms * 1e-3), 2),
                                     "ratio_to_resident": round(loop_ms / ms, 3),
                                     "host_issue_ms": round(loop_issue, 3),
                                     "host_schedule_build_ms": round(build_ms, 3),
                                     "what": "model(*batch, beta=beta) as vae_train.py:78: numpy tensors + networkx graphs in, "
                                             "make_cuda and DecodeSchedule.from_graphs (csrc/schedule.hip) inside the step"},
-               "schedule_ahead": {"ms_per_step": round(ahead_ms, 3), "value": round(B * self.world / (ahead_ms * 1e-3), 2),
+               "schedule_ahead": {"ms_per_step": round(ahead_ms, 3), "timed_region": self.region_log.get("ahead"), "value": round(B * self.world / (ahead_ms * 1e-3), 2),
                                   "ratio_to_resident": round(ahead_ms / ms, 3),
                                   "what": "the same loop with ONE changed line, `for batch in ScheduleAhead(dataset, model)` "
                                           "(ggpm_amd/dataloader.py): batch k+1's schedule is built on a worker thread during "
@@ -727,7 +796,7 @@ class VaeWorkload:
                             "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
                             "algorithmic_gflop_per_step_per_gpu": round(fl_alg / 1e9, 2),
                             "note": "whole-step figure: executed flops (every row the kernels process; fwd + bwd = 3 x fwd) over "
-                                    "the step time; the step is a chain of small dependent launches (profiles/r04_vae_*), "
+                                    "the step time; the step is a chain of small dependent launches (profiles/r05_vae_*), "
                                     "not one kernel"},
                "workload": "HierPropertyVAE fwd (perturb_z) + bwd%s + Adam on the configs[1] batches: latent=%d, diterT=%d, "
                            "diterG=%d, tie_embedding=%s, metrics read back on the host every step (after optimizer.step(), where "
@@ -736,7 +805,8 @@ class VaeWorkload:
                            "step); schedule_in_loop: nothing resident"
                            % (" + all-reduce" if self.world > 1 else "", self.cfg["latent"], self.DITER_T, self.DITER_G, self.TIE)}
         try:        # launches per step and per-kernel-class time from the committed rocprofv3 trace of `bench.py --only-vae`
-            with open(os.path.join(ROOT, "profiles", "r04_vae_launches.json")) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_vae_launches.json")))[-1]) as f:      # (the latest round's)
                 lj = json.load(f)
             out["launches_per_step"] = lj.get(self.rnn, {}).get("launches_per_step")
             out["kernel_classes"] = lj.get(self.rnn, {}).get("classes")
@@ -798,7 +868,7 @@ def configs4_leg(a, lib, dev, budget_s=90.0):
             wl = Workload(cfg, cfg["rnn"], b, 0, 1, dev, gate_dtype=dt)
             m = wl.measure(lib, 0)
             leg = {k: m[k] for k in ("ms_per_step", "value", "unit", "step_tflops_executed", "atoms_per_molecule",
-                                     "warmup_steps_run", "timed_regions_repeated") if k in m}
+                                     "warmup_steps_run", "timed_regions_repeated", "timed_region") if k in m}
             r = m.get("roofline")
             if r:
                 leg["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
@@ -879,11 +949,11 @@ def parse_args(argv=None):
 
 def launch_ranks(a, argv):
     """``python bench.py --gpus N`` with nobody having set up the ranks: this process -- which has made no HIP call and
-    makes none -- starts N fresh copies of itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
-    (ggpm_amd/launcher.py), relays rank 0's JSON line and exits non-zero if any rank does."""
+    makes none, torch.cuda included -- starts N fresh copies of itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (ggpm_amd/launcher.py), relays rank 0's JSON line and exits non-zero if any rank does."""
     from ggpm_amd import launcher
-    have = torch.cuda.device_count()                 # (counting devices does not initialise HIP)
-    if have < a.gpus and not os.environ.get("GGPM_BENCH_ONE_DEVICE"):
+    have = launcher.visible_gpu_count()              # the driver's topology files (-1: unreadable -- rank 0 will say)
+    if 0 <= have < a.gpus and not os.environ.get("GGPM_BENCH_ONE_DEVICE"):
         raise SystemExit("--gpus %d but this node shows %d GPU(s) (rehearsal on one GPU: GGPM_BENCH_ONE_DEVICE=1 "
                          "--backend gloo)" % (a.gpus, have))
     log("starting %d rank processes (backend %s)" % (a.gpus, a.backend))
@@ -943,11 +1013,13 @@ def main():
     m = main_wl.measure(lib, rank)
     n_motif, n_attach = cfg["vocab"]
     result = {
-        "metric": "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32) -- HierMPNEncoder fwd+bwd target row "
-                  "(encoder + KL heads + optimizer)",
+        "metric": "HierMPNEncoder fwd+bwd target row (SURVEY 8(d): encoder + KL heads + optimizer, tree fixed-point hint on; "
+                  "full depth loops in full_depth_loops, the full VAE fwd+bwd row in vae_step) of BASELINE's "
+                  "molecules/sec VAE fwd+bwd (hidden=300, depth=20, batch=32)",
         "value": m["value"], "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "warmup_steps_run": m.get("warmup_steps_run", a.warmup),
-        "timed_regions_repeated": m.get("timed_regions_repeated", 0), "ms_per_step": m["ms_per_step"],
+        "timed_regions_repeated": m.get("timed_regions_repeated", 0), "timed_region": m.get("timed_region"),
+        "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic" + (" (host-resident batches, PCIe-inclusive diagnostic)" if a.host_input else ""),

@@ -2,7 +2,8 @@
 
 None of these is an environment switch.  Every default is the measured-fastest form (DESIGN.md sections 6, 8, 9 carry the
 figures); a test or a tool under ``tools/`` changes an attribute here (``monkeypatch.setattr(_dev, "ATOM_COMPACT", False)``)
-to run the other form against the same fixtures.  The runtime switches a user of the package sees are the few in
+to run the other form against the same fixtures; every module reads these attributes at CALL time (none copies one
+into a module global at import), so a change made after the package was imported takes effect.  The runtime switches a user of the package sees are the few in
 README.md; the compile-time tuning switches of the kernels live in the ``dev`` variant of the library
 (``python -m ggpm_amd.build --variant dev -DGGPM_DEV_SWITCHES``, csrc/common.h: ggpm_dev_env).
 """

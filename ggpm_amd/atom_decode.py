@@ -16,7 +16,7 @@ attachment candidate (``enum_attach``) reads the step's atom vectors.  ``atom_de
 projections of ALL bonds computed once (they are depth- and step-invariant one-hot look-ups), and every weight gradient
 formed once per call (the read-out's from the stacked rows of all steps, the input halves from the summed ``dX``).
 
-Compact steps (default, GGPM_ATOM_COMPACT=0 switches them off): a step recomputes a few hundred of the level's thousands
+Compact steps (default, _dev.ATOM_COMPACT = False switches them off): a step recomputes a few hundred of the level's thousands
 of bond messages, so its ``sparse_forward`` runs on the step's COMPACT row set -- the step's bonds plus the frozen
 older bonds they read, renumbered 0..n-1 with host-built local CSRs -- instead of on every row of the level with a
 frozen mask: the rows are gathered from / scattered back into the level-wide state (``ggpm_gather_rows`` /
@@ -53,7 +53,7 @@ class AtomPlan:
 
     def __init__(self, schedule, n_gnodes: int, n_gmess: int, full: Optional[bool] = None):
         """``full``: also build the level-wide per-step tables of the full-level form (``_AtomDecode``; default: only when
-        GGPM_ATOM_COMPACT=0 -- the compact form does not read them and they are the larger half of the build and upload)."""
+        _dev.ATOM_COMPACT = False -- the compact form does not read them and they are the larger half of the build and upload)."""
         P, steps = schedule.plan, schedule.steps
         self._native, self._schedule, self._raw_cache = None, None, None
         self.T, self.N1, self.E1 = len(steps), n_gnodes, n_gmess
@@ -419,13 +419,13 @@ def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
     return d, keep
 
 
-_DRIVER = _dev.DECODE_DRIVER    # (False: the step loops are issued from Python; dev A/B, tests)
+# _dev.DECODE_DRIVER (False: the step loops are issued from Python; dev A/B, tests) -- read at CALL time, like every
+# _dev setting: a tool or test that flips the attribute after this module was imported gets the other form.
 # The two step loops are ~280 launches = 1.5-1.8 ms of host time each, inside one C call.  _dev.ATOM_ASYNC (default)
 # hands them to a worker thread of the library (ggpm_decode_steps_*_async): the forward loop is then issued beside the
 # encoder's forward, the backward loop beside the encoder's backward -- the autograd engine reaches the two nodes at about
 # the same time and would otherwise issue one chain only after the other, although they do not depend on each other.
 # What follows a loop on its stream (read-out / parameter gradients) is enqueued after ggpm_decode_join.
-_ASYNC = _dev.ATOM_ASYNC
 _INFLIGHT: list = []         # buffers named by loops the worker may still be issuing (released by the next join)
 _PENDING: dict = {}          # id(plan) -> the forward's `finish` closure, taken by atom_decode()
 
@@ -433,7 +433,9 @@ _PENDING: dict = {}          # id(plan) -> the forward's `finish` closure, taken
 def _join_worker(what: str) -> None:
     _lib.check(_lib.load().ggpm_decode_join(), what)
     del _INFLIGHT[:]
-_PACK_ONCE = _dev.PACK_ONCE      # (False: every decode step packs its weights again; dev A/B)
+
+
+# _dev.PACK_ONCE = False: every decode step packs its weights again (dev A/B)
 
 
 def compact_enabled() -> bool:
@@ -446,7 +448,7 @@ def _vp(addr: int) -> ctypes.c_void_p:
 
 class _AtomDecode(torch.autograd.Function):
     """(pooled cluster vectors of all visits [n_inst, Hp], attachment-candidate atom vectors [n_cand, Hp]) -- the
-    full-level form: every step runs over all E1 rows of the level with a frozen mask (GGPM_ATOM_COMPACT=0)."""
+    full-level form: every step runs over all E1 rows of the level with a frozen mask (_dev.ATOM_COMPACT = False)."""
 
     @staticmethod
     def forward(ctx, plan: AtomPlan, cell: str, depth: int, H: int, Fdim: int, I: int, fn_all, hmess, drop, *params):
@@ -646,17 +648,17 @@ class _AtomDecodeCompact(torch.autograd.Function):
         W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
         ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
         deferred = False
-        if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
+        if _dev.DECODE_DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
             tmp = torch.empty(2 * max(plan.nloc), Hp, **f32)
-            fn = lib.ggpm_decode_steps_forward_async if _ASYNC else lib.ggpm_decode_steps_forward
+            fn = lib.ggpm_decode_steps_forward_async if _dev.ATOM_ASYNC else lib.ggpm_decode_steps_forward
             _lib.check(fn(
                 ctypes.byref(desc), W_arr, ld_arr, None if lstm else P(bu), P(X_all), P(Hs_all), P(Cs_all) if lstm else None,
                 P(Qs_all), P(St_all), St_all.stride(0), P(wpack), P(tmp), s), "decode_steps_forward")
-            if _ASYNC:
+            if _dev.ATOM_ASYNC:
                 deferred = True
                 _INFLIGHT.append((desc, _keep, X_all, Hs_all, Cs_all, Qs_all, St_all, wpack, tmp, params))
-        for t in (() if _DRIVER else range(T)):
+        for t in (() if _dev.DECODE_DRIVER else range(T)):
             n = plan.nloc[t]
             src = _vp(cp[("srcH", t)])
             h_in = torch.empty(n, Hp, **f32)
@@ -665,7 +667,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
             hs, qs = Hs_all[qoff[t]:qoff[t + 1]], Qs_all[roff[t]:roff[t + 1]]
             st = St_all[:, roff[t]:roff[t + 1]]
             fz, rp, col = _vp(frz_loc + plan.floc_off[t]), _vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)])
-            if t > 0 and _PACK_ONCE:
+            if t > 0 and _dev.PACK_ONCE:
                 lib.ggpm_weights_packed(1)          # same weights, same `wpack`: packed by the first step
             if lstm:
                 c_in = torch.empty(n, Hp, **f32)
@@ -733,7 +735,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
         # host time: with the step loop handed to the worker thread they are issued AFTER the loop has been posted (below),
         # so that the longest chain of the pass starts first; without the worker, here.
         F_.mark("bwd: atom level's node reached")
-        flush_after_post = _DRIVER and _ASYNC
+        flush_after_post = _dev.DECODE_DRIVER and _dev.ATOM_ASYNC
         if not flush_after_post:
             F_.flush_deferred_early()
         plan, (cell, depth, H, Fdim, I), drop = ctx.plan, ctx.meta, ctx.drop
@@ -794,8 +796,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
         work = torch.empty((wb + 3) // 4, **f32)
         frz_loc = D["frozen_loc"].data_ptr()
         params_ref = ctx.params_ref
-        go_async = (_DRIVER and _ASYNC and F_.can_publish(*params_ref) and all(ctx.needs_input_grad[10:]))
-        if _DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
+        go_async = (_dev.DECODE_DRIVER and _dev.ATOM_ASYNC and F_.can_publish(*params_ref) and all(ctx.needs_input_grad[10:]))
+        if _dev.DECODE_DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             if lstm:
                 hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
             else:
@@ -816,7 +818,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
         if flush_after_post:
             F_.flush_deferred_early()
         F_.mark("bwd: atom node returns")
-        for t in (() if _DRIVER else range(T - 1, -1, -1)):
+        for t in (() if _dev.DECODE_DRIVER else range(T - 1, -1, -1)):
             n = plan.nloc[t]
             dhd, dhin = dF[foff[t]:foff[t + 1]], torch.empty(n, Hp, **f32)
             dx = dX_all[G * foff[t]:G * foff[t + 1]].view(G, n, Hp)
@@ -825,7 +827,7 @@ class _AtomDecodeCompact(torch.autograd.Function):
             fz = _vp(frz_loc + plan.floc_off[t])
             csr = (_vp(ptr[("lpred_rp", t)]), _vp(ptr[("lpred_col", t)]), _vp(ptr[("lsucc_rp", t)]), _vp(ptr[("lsucc_col", t)]))
             srcF = _vp(cp[("srcF", t)])
-            if t < T - 1 and _PACK_ONCE:
+            if t < T - 1 and _dev.PACK_ONCE:
                 lib.ggpm_weights_packed(1)          # same weights, same `work`: the transposes were packed by the first call
             if lstm:
                 dcin = torch.empty(n, Hp, **f32)
@@ -942,7 +944,7 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
                 defer_finish: bool = False, prelaunch: bool = False):
     """-> (pooled [n_inst, Hp], cand [n_cand, Hp]) for ``graph_encoder`` = the decoder's atom-level ``IncMPNEncoder``.
     ``defer_finish``: -> (pooled, cand, finish); the caller calls ``finish()`` before it reads the two tensors or lets any
-    other stream wait on the current one (with GGPM_ATOM_ASYNC the step loop is still being issued by a worker thread
+    other stream wait on the current one (with _dev.ATOM_ASYNC the step loop is still being issued by a worker thread
     when this returns, and the read-out behind it is enqueued by ``finish``)."""
     from .rnn import LSTM
     rnn, wo = graph_encoder.rnn, graph_encoder.W_o
@@ -958,7 +960,7 @@ def atom_decode(plan: AtomPlan, graph_encoder, hnode_a: torch.Tensor, hmess_a: t
         drop = (float(wo[2].p), int(seed[0]), int(seed[1]))
     fn = _AtomDecodeCompact if compact_enabled() else _AtomDecode
     if fn is _AtomDecode and not plan.full:
-        raise RuntimeError("this AtomPlan was built without the level-wide tables (GGPM_ATOM_COMPACT changed after the plan "
+        raise RuntimeError("this AtomPlan was built without the level-wide tables (_dev.ATOM_COMPACT changed after the plan "
                            "was built?); build it with full=True")
     args = (plan, "LSTM" if lstm else "GRU", rnn.depth, rnn.hidden_size, graph_encoder.node_fdim, rnn.input_size, fn_all,
             hmess_a, drop)

@@ -37,22 +37,38 @@ inline const char* ggpm_dev_env(const char*) { return nullptr; }
 // host threads at once (autograd's, the library's decode and side workers): the limit is only ever RAISED, under a lock, and
 // the size on record is stored after the call succeeded -- a thread can therefore never see a size on record that is larger
 // than the attribute in force.
-template <typename K>
-inline void ggpm_set_lds(K kernel, size_t bytes) {
-    constexpr int MAXDEV = 16;
-    static std::atomic<size_t> have[MAXDEV];      // (one set per kernel instantiation; zero-initialised)
+// The record is keyed by the kernel's ADDRESS and the device: every instantiation of a kernel template shares one function-
+// pointer type (gru_fwd_a<true,2,1> and gru_fwd_a<true,0,2> are both void(*)(GruFwdArgs)), so a record per TYPE would let
+// one instantiation's size stand for another's.  A small open-addressed table (the library has ~150 kernel instantiations);
+// a full table only costs the attribute call again.
+inline void ggpm_set_lds_addr(const void* kernel, size_t bytes) {
+    constexpr int MAXDEV = 16, SLOTS = 1024;
+    struct Rec { std::atomic<const void*> key; std::atomic<size_t> have[MAXDEV]; };
+    static Rec table[SLOTS];                      // zero-initialised
     static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
-    if (bytes <= have[dev].load(std::memory_order_acquire)) return;
+    size_t h = (reinterpret_cast<uintptr_t>(kernel) >> 4) * 0x9E3779B97F4A7C15ull >> 54;      // 10 bits
+    Rec* rec = nullptr;
+    for (int probe = 0; probe < SLOTS; ++probe, h = (h + 1) % SLOTS) {
+        const void* k = table[h].key.load(std::memory_order_acquire);
+        if (k == kernel) { rec = &table[h]; break; }
+        if (k == nullptr) {
+            const void* expect = nullptr;
+            if (table[h].key.compare_exchange_strong(expect, kernel, std::memory_order_acq_rel) || expect == kernel) { rec = &table[h]; break; }
+        }
+    }
+    if (rec && bytes <= rec->have[dev].load(std::memory_order_acquire)) return;
     std::lock_guard<std::mutex> lock(mu);
-    if (bytes <= have[dev].load(std::memory_order_relaxed)) return;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
-        hipSuccess)
-        have[dev].store(bytes, std::memory_order_release);
-    else
+    if (rec && bytes <= rec->have[dev].load(std::memory_order_relaxed)) return;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) {
+        if (rec) rec->have[dev].store(bytes, std::memory_order_release);
+    } else {
         (void)hipGetLastError();                   // (the launch that follows reports the failure)
+    }
 }
+template <typename K>
+inline void ggpm_set_lds(K kernel, size_t bytes) { ggpm_set_lds_addr(reinterpret_cast<const void*>(kernel), bytes); }
 
 static inline int ggpm_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int ggpm_round_up(int a, int b) { return ggpm_ceil_div(a, b) * b; }
@@ -81,17 +97,44 @@ __device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
     return make_float4(ggpm_sigmoid(a.x), ggpm_sigmoid(a.y), ggpm_sigmoid(a.z), ggpm_sigmoid(a.w));
 }
 __device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-// sigmoid on the hardware exp2 / rcp units (~2 ulp): the gather phases of the depth kernels evaluate one per gathered
-// neighbour element and were VALU bound with the libm expf + IEEE division forms
+// The gather phases of the depth kernels evaluate one sigmoid per gathered neighbour element (rnn.py:31-32, 90) and are VALU
+// bound with libm expf + IEEE division (1.0 / 2.3 us per atom-level launch, round 4).  Two forms on the hardware units:
+// FAST (bf16 gate modes only): v_exp_f32(-x * log2e), v_rcp_f32.  The rounding of the product -x * log2e alone is worth
+// |x| * log2e * 2^-24 * ln2 relative error of the exponential (1.4 ulp at |x| = 5, 3 ulp at |x| = 10), then v_exp_f32 and
+// v_rcp_f32 add ~1 ulp each: measured mean 1.30 ulp, 25 % of the arguments above 1 ulp, 29.5 ulp at x = -29.8
+// (tools/probe/sigmoid_ulp.hip), and a sum-aggregating GRU over 30 depths amplifies it (twice the distance
+// to fp64 on the deciding configs[4] tensors).
+__device__ __forceinline__ float ggpm_fsigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// ACCURATE (fp32 gate modes): measured mean 0.42 ulp, 6.9 % above 1 ulp, worst 3.4 ulp -- at |x| ~ 16.7, where 1 + e itself
+// rounds -- against 0.40 / 5.3 % / 2.5 for libm expf + IEEE division, in 11 instructions instead of ~35 (and FEWER issue
+// slots than the fast form, whose __expf carries denormal-range handling: 2.57 against 3.82 ms for 2^33 evaluations):
+//   t = -x * log2e as a two-term product t_hi + t_lo (log2e = L_hi + L_lo, the rounding of the leading product recovered by
+//   fma); exp2(t_hi) on v_exp_f32 -- the unit's own range reduction of the ROUNDED argument is exact --, times
+//   2^t_lo = 1 + t_lo ln2 (|t_lo| < 2^-17: first order is exact to 2^-35); then 1 / (1 + e) as v_rcp_f32 + one Newton step.
+//   |x| is clamped to 88 first so that e stays finite (inf * 0 in the correction would be NaN); sigmoid(+-88) is 1 / 6e-39.
+__device__ __forceinline__ float ggpm_fsigmoid_acc(float x) {
+    const float L_hi = 1.44269502162933349609375f, L_lo = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    const float nx = -__builtin_amdgcn_fmed3f(x, -88.f, 88.f);
+    const float t = nx * L_hi;
+    float lo = __builtin_fmaf(nx, L_hi, -t);
+    lo = __builtin_fmaf(nx, L_lo, lo);
+    float e = __builtin_amdgcn_exp2f(t);
+    e = __builtin_fmaf(e, lo * LN2, e);
+    const float d = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
 #ifdef GGPM_ABL_EXACT_GATHER_SIGMOID      // ablation build (python -m ggpm_amd.build --variant exactsig -DGGPM_ABL_EXACT_GATHER_SIGMOID):
-__device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_sigmoid(x); }      // libm expf + IEEE division in the gathers too
+template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_sigmoid(x); }      // libm expf + IEEE division in the gathers too
+#elif defined(GGPM_ABL_FAST_GATHER_SIGMOID)      // ablation build: the round-4 form in every gate mode (timing A/B)
+template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_fast(x); }
+#elif defined(GGPM_ABL_ACC_SIGMOID_BF16)        // ablation build: the accurate form in the bf16 gate modes as well (timing / flip-count A/B)
+template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_acc(x); }
 #else
-__device__ __forceinline__ float ggpm_fsigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return FAST ? ggpm_fsigmoid_fast(x) : ggpm_fsigmoid_acc(x); }
 #endif
-// tanh(x) = 1 - 2 / (1 + exp(2x)) on the same units (absolute error ~2e-7)
-__device__ __forceinline__ float ggpm_ftanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
-__device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {
-    return make_float4(ggpm_fsigmoid(a.x), ggpm_fsigmoid(a.y), ggpm_fsigmoid(a.z), ggpm_fsigmoid(a.w));
+template <bool FAST> __device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {
+    return make_float4(ggpm_fsigmoid<FAST>(a.x), ggpm_fsigmoid<FAST>(a.y), ggpm_fsigmoid<FAST>(a.z), ggpm_fsigmoid<FAST>(a.w));
 }
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global stores / loads

@@ -214,7 +214,7 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
                     for (int u = 0; u < GGPM_GATHER_U; ++u)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {          // null slots: h[0] == 0 contributes nothing
-                            const float4 r = ggpm_fsigmoid4(xr[k] + q[u][k]);
+                            const float4 r = ggpm_fsigmoid4<BF16>(xr[k] + q[u][k]);
                             const float4 rh = r * h[u][k];
                             s[k] = s[k] + h[u][k];
                             g[k] = g[k] + rh;
@@ -500,7 +500,7 @@ __global__ void GGPM_A_BOUNDS gru_bwd_a(GruBwdArgs a) {
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                const float4 r = ggpm_fsigmoid4(xr[u][k] + qp[k]);
+                                const float4 r = ggpm_fsigmoid4<BF16>(xr[u][k] + qp[k]);
                                 const float4 dgr = dg[u][k] * r;
                                 dh[k] = dh[k] + ds[u][k] + dgr;
                                 dq[k] = dq[k] + dgr * hp[k] * one_minus(r);

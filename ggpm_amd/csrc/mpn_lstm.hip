@@ -101,7 +101,7 @@ __global__ void GGPM_A_BOUNDS lstm_fwd_a(LstmFwdArgs a) {
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {          // null slots: h[0] = c[0] = 0
-                            const float4 f = ggpm_fsigmoid4(xf[k] + q[u][k]);
+                            const float4 f = ggpm_fsigmoid4<BF16>(xf[k] + q[u][k]);
                             const float4 fcc = f * cc[u][k];
                             s[k] = s[k] + h[u][k];
                             fc[k] = fc[k] + fcc;
@@ -389,7 +389,7 @@ __global__ void GGPM_A_BOUNDS lstm_bwd_a(LstmBwdArgs a) {
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                const float4 f = ggpm_fsigmoid4(xf[u][k] + qp[k]);
+                                const float4 f = ggpm_fsigmoid4<BF16>(xf[u][k] + qp[k]);
                                 const float4 dff = dfc[u][k] * f;
                                 dh[k] = dh[k] + ds[u][k];
                                 dc[k] = dc[k] + dff;

@@ -152,14 +152,14 @@ def upload(a, device) -> torch.Tensor:
     return _STAGING.upload(a, device)
 
 
-_MEMO_ON = _dev.INDEX_MEMO
+_MEMO_ON = None        # None: _dev.INDEX_MEMO, read at call time; True / False: forced (bench.py's "index structures rebuilt" leg)
 
 
 def _memo_get(t: torch.Tensor, slot: str, key):
     """Index structures derived from an index tensor are remembered ON that tensor object, keyed by its in-place
     version counter: a batch whose tables stay resident -- a DecodeSchedule on the device, the encoder's graph
     tensors -- pays for their CSRs and transposes once, not once per step."""
-    if not _MEMO_ON:
+    if not (_dev.INDEX_MEMO if _MEMO_ON is None else _MEMO_ON):
         return None
     m = getattr(t, slot, None)
     # `_version` counts in-place writes: a resident index tensor that is refilled (``t.copy_(next_batch)``) must not
@@ -520,6 +520,21 @@ def _side_stream(device) -> torch.cuda.Stream:
     return _SIDE[key]
 
 
+def writer_streams(device) -> list:
+    """Every helper stream of the package on `device` that writes parameter gradients: the second stream and the decoder's
+    atom-level stream (parallel.FlatGradSync._join_writers)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    out = [_SIDE[key]] if key in _SIDE else []
+    try:
+        from .decoder import HierMPNDecoder
+        s = HierMPNDecoder._ATOM_STREAMS.get(key)
+        if s is not None:
+            out.append(s)
+    except Exception:
+        pass
+    return out
+
+
 # A gradient tensor computed on a helper stream (second stream, atom-level stream) and then read on the main stream
 # (optimizer, clipping, the flat-buffer pack) would ordinarily be marked with ``record_stream(main)``.  On ROCm every such
 # mark costs an event record on that stream when the tensor is released -- ~4.7 us of queue time each, and the ~55
@@ -528,11 +543,10 @@ def _side_stream(device) -> torch.cuda.Stream:
 # until the optimizer side releases it, i.e. after everything that reads it has been ENQUEUED on the main stream, and every
 # helper stream of this package waits for the main stream (``wait_stream(main)``) before the first allocation of its next use
 # -- the block cannot be handed out again in front of its readers.  _dev.RECORD_GRADS restores the marks.
-_RECORD_GRADS = _dev.RECORD_GRADS
 
 
 def hand_to(g: torch.Tensor, main: torch.cuda.Stream) -> None:
-    if _RECORD_GRADS:
+    if _dev.RECORD_GRADS:
         g.record_stream(main)
 
 

@@ -5,11 +5,15 @@ body on every rank (forward, backward, gradient all-reduce in front of clip_grad
 ``python bench.py --gpus N`` uses when nobody else (torch.distributed.run) has set up the ranks.
 
 Rules it keeps:
-  * the parent makes NO HIP call: it may import torch, it only ever counts devices; a process that has initialised the
-    GPU must not start other programs on this pool, and nothing here re-executes a running process;
+  * the parent makes NO HIP call and no torch.cuda call at all: it counts GPUs from the kernel driver's topology files
+    (``visible_gpu_count``; torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is not usable, which
+    starts the runtime and keeps /dev/kfd open in the parent for the whole run).  Starting fresh child processes is always
+    fine; what is forbidden on this pool is REPLACING a process that has initialised the GPU (os.exec*), and nothing here
+    re-executes a running process;
   * every child is a fresh interpreter in its own process group with RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / MASTER_PORT set (the container hostname may not resolve);
-  * rank 0's stdout is relayed verbatim (the ONE JSON line), the other ranks' stdout goes to stderr;
+  * rank 0's stdout is relayed verbatim (the ONE JSON line), the other ranks' stdout goes to stderr (or nowhere when the
+    caller's ``err`` has no file descriptor -- never to the parent's stdout);
   * any child that exits non-zero fails the run at once (the others are ended by process group, exact PIDs only), and so
     does the timeout.
 """
@@ -29,6 +33,35 @@ def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def visible_gpu_count(env: Optional[Dict[str, str]] = None, topology: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process would see, WITHOUT touching HIP: the amdkfd topology lists one node per agent, GPU nodes are those
+    with ``simd_count > 0``; ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` (comma lists) narrow
+    it.  -> 0 without the driver's topology directory (no amdkfd: no GPU), -1 when it exists but cannot be read (the
+    caller then lets rank 0 find out)."""
+    env = os.environ if env is None else env
+    n = 0
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda d: int(d) if d.isdigit() else 1 << 30)
+    except FileNotFoundError:
+        return 0
+    except OSError:
+        return -1
+    for d in nodes:
+        try:
+            with open(os.path.join(topology, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for key in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(key)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
 
 
 def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
@@ -81,8 +114,10 @@ def run_ranks(script: str, argv: Sequence[str], world: int, timeout: float = 150
     except Exception:
         err_fd = None
     for rank, (cmd, env) in enumerate(rank_commands(script, argv, world, port, python, base_env)):
+        # ranks > 0 never inherit the parent's stdout (it carries ONE JSON line): the caller's stderr, or nowhere
+        other_out = err_fd if err_fd is not None else subprocess.DEVNULL
         procs.append(subprocess.Popen(cmd, env=env, stdin=subprocess.DEVNULL,
-                                      stdout=subprocess.PIPE if rank == 0 else (err_fd if err_fd is not None else None),
+                                      stdout=subprocess.PIPE if rank == 0 else other_out,
                                       stderr=err_fd, start_new_session=True))
 
     def drain():                              # rank 0's result line can exceed a pipe buffer

@@ -100,12 +100,38 @@ class FlatGradSync:
     def wants_early_bucket(self) -> bool:
         return self.bucketed and self.early_numel > 0 and self.collective()
 
+    def _join_writers(self) -> None:
+        """Order the CURRENT stream behind every stream of this package that writes gradients (the second stream: weight-
+        gradient contractions of the drivers and of the deferred queue; the atom-level stream: the decode loop's backward and
+        its stacked contractions), explicitly and HERE -- a collective reads the flat buffer on a stream of its own that is
+        ordered behind the current stream only (RCCL: its internal stream waits for an event recorded on the current one;
+        gloo: its device-to-host copy likewise).  The end-of-pass callbacks of the backward have made the same joins already;
+        this one does not depend on the collective being called from inside the pass that queued them.
+
+        A host-side (CPU) backend additionally gets an IDLE device: the current stream is synchronised on the host before the
+        copy is issued.  gloo blocks the host for the whole collective anyway, so this costs nothing, and the device-to-host
+        copy then waits for no event at all: with two rank processes on one GPU, each with five streams on shared hardware
+        queues, an event wait queued behind another process's packets is the one ingredient of the round-3 stall
+        that is still there by construction -- with this it is gone for the rehearsal backend."""
+        if not self.flat.is_cuda:
+            return
+        from . import functional as F_
+        cur = torch.cuda.current_stream(self.flat.device)
+        for s in F_.writer_streams(self.flat.device):
+            if s.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(s)
+        if not self._avg:
+            cur.synchronize()
+
     def _reduce(self, t: torch.Tensor, async_op: bool):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
     def reduce_early_bucket(self) -> None:
-        """Called on the second stream between the two phases of the encoder backward."""
+        """Called on the second stream between the two phases of the encoder backward (the slice's writers are that stream
+        and the main stream, which it has just waited for)."""
+        if self.flat.is_cuda and not self._avg:
+            torch.cuda.current_stream(self.flat.device).synchronize()      # CPU backend: see _join_writers
         self._early_work = self._reduce(self.flat[:self.early_numel], async_op=True)
 
     # ------------------------------------------------------------------ step interface
@@ -141,6 +167,7 @@ class FlatGradSync:
                 for p, v in zip(self.encoder_params, self.encoder_views))
             self.pack(start=len(self.encoder_params) if in_place else 0)
             return None
+        self._join_writers()
         early, self._early_work = self._early_work, None
         if early is not None:
             # the encoder backward wrote its gradients into the flat buffer and the front slice is already being

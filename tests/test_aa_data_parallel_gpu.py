@@ -1,8 +1,10 @@
 """Data parallelism through the real encoder and the gradient sink: two gloo ranks on the GPU box's one MI355X.
 
 The two rank processes (tests/dp_rank_worker.py) are started by ``conftest.pytest_collection_finish`` BEFORE this
-pytest process touches the GPU (a process that has initialised HIP must not start other programs on this pool); this
-module only waits for them and checks what they reported.  (Named ``test_aa_`` so that it is collected first.)
+pytest process touches the GPU, so that the ranks' first HIP calls do not compete with a GPU-initialised parent for the
+box's limit of six GPU-using processes (starting a fresh child from a GPU-initialised process is fine -- golden_utils.
+OracleRuns does it; what this pool forbids is REPLACING such a process, os.exec*); this module only waits for them and
+checks what they reported.  (Named ``test_aa_`` so that it is collected first.)
 """
 import pytest
 

@@ -425,13 +425,16 @@ def test_motif_encoder_matches_reference_golden(name):
 
 
 # How far the HIP result may be from the fp64 run, in units of the WORST of the oracle's own fp32 evaluation orders, where the
-# recurrence is ill conditioned (``calibrate=True``).  Measured on configs[4] GRU (profiles/r03_parity_report_configs4_gru.txt):
+# recurrence is ill conditioned (``calibrate=True``).  Measured on configs[4] GRU (profiles/r0*_parity_report_configs4_gru.txt):
 # the orders differ from each other by up to 9x on one tensor (a different BLAS blocking alone moves W_r's gradient
-# from 3e-4 to 2.8e-3), the HIP path sits at 2.2-3.2x the worst of them -- its gather-phase sigmoid runs on the hardware
-# exp2 / rcp units (~2 ulp against libm's < 1), so it enters the same amplification with about twice the rounding noise.
-# TESTED in round 4 (profiles/r04_parity_report_configs4_gru.txt): the same test under an ablation build with libm expf +
-# IEEE division in the gather phases reads 1.69x where the shipped build reads 3.22x.
-CALIBRATED_FACTOR = 4.0
+# from 3e-4 to 2.8e-3).  Rounds 3-4: the HIP path sat at 2.1-3.2x the worst of them, because its gather-phase sigmoid ran on
+# the hardware exp2 / rcp units as v_exp(-x log2e), v_rcp -- up to 4 ulp in the sigmoid's steep part (tools/probe/sigmoid_ulp.hip)
+# -- and entered the same amplification with about twice the rounding noise (an ablation build with libm expf + IEEE
+# division read 1.69x); the factor was 4.  Round 5 ships a <= 1-ulp form on the same units for the fp32 gate modes (two-term
+# product for the exponent, one Newton step on the reciprocal; csrc/common.h: ggpm_fsigmoid_acc; it is also 1.5 % FASTER per
+# step than the fast form, whose __expf carries denormal handling): worst ratio over the sixteen-order family 1.27
+# (profiles/r05_parity_report_configs4_gru.txt), so the factor is 2.
+CALIBRATED_FACTOR = 2.0
 
 
 def _oracle_vs_hip(rnn, H, depth, specs, n_motif, n_attach, latent=16, f64=True, tol=TOL, slack=None, calibrate=False,
@@ -580,16 +583,116 @@ def test_configs4_polymer_shard_matches_oracle(rnn):
     how much depends on the evaluation order.  So the bound is CALIBRATED, not chosen: the oracle is evaluated in fp32 in
     sixteen equivalent orders (golden_utils.FP32_ORDERS: the reference's padded op order, per-message recurrent products,
     reversed neighbour slots, both -- each under four BLAS blockings), each order's distance to the fp64 run is measured
-    per tensor, and the HIP result may be at most CALIBRATED_FACTOR = 4x as far from fp64 as the worst of them.  (Round 3
+    per tensor, and the HIP result may be at most CALIBRATED_FACTOR = 2x as far from fp64 as the worst of them.  (Round 3
     used five orders at whatever thread count the host gave: the worst of five moved from 2.8e-3 to 1.6e-3 with the thread
-    count alone on the tensor that decides the test, HIP 8.95e-3 both times.)  Measured against the worst of five: up to
-    3.2x -- and 1.7x in an ablation build whose gather phases evaluate their sigmoid with libm expf + IEEE division instead
-    of the ~2-ulp hardware exp2 / rcp form (profiles/r04_parity_report_configs4_gru.txt): the extra distance IS that
-    sigmoid's rounding noise entering the same ill-conditioned recurrence; the accurate form costs 1.0-2.3 us per
-    atom-level launch, so the fast one ships and the factor stays at 4 with that measurement behind it."""
+    count alone on the tensor that decides the test.)  Measured: rounds 3-4, with the ~2-4-ulp hardware sigmoid in the gather
+    phases, up to 3.2x the worst of five / 2.1x the worst of sixteen; round 5, with the <= 1-ulp form on the same units
+    (csrc/common.h: ggpm_fsigmoid_acc), 1.27x the worst of sixteen (profiles/r05_parity_report_configs4_gru.txt) -- the
+    extra distance WAS that sigmoid's rounding noise entering the same ill-conditioned recurrence."""
     from ggpm_amd import synth
     specs = synth.random_batch(505, 4, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500)
     _oracle_vs_hip(rnn, 600, 30, specs, 500, 1500, latent=32, calibrate=rnn == "GRU", side_by_side=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_configs4_full_batch_is_invariant_under_batch_composition(dtype):
+    """configs[4] at the size bench.py runs it (B = 32: ~15 K atom messages = ~950 row tiles, the two-row-tile launches, and under
+    ``gate_dtype = "bf16"`` the bf16 STORAGE of the atom level's depth-loop arrays at that size) -- a size the oracle cannot
+    evaluate in test time and a launch geometry no B = 4 parity case reaches.  The property used instead needs no oracle:
+    molecules of a batch are disjoint graphs (ggpm/mol_graph.py:247-250), so the encoder's per-molecule rows and every
+    parameter gradient are those of the SAME model on sub-batches -- which run the one-row-tile geometry that the oracle
+    pins elsewhere (fp32: eight B = 4 sub-batches, the shape of test_configs4_polymer_shard_matches_oracle; bf16: two B = 16
+    halves, whose atom level still has >= 6144 messages and therefore the same storage rounding points as the full batch,
+    the form test_bf16_gate_products_match_the_bf16_oracle[storage_*] pins).
+
+    The bound is CALIBRATED like the configs[4] GRU parity case, and for the same reason (a sum-aggregating GRU over 30 depths
+    amplifies rounding, by how much depends on the molecule): the sub-batches are evaluated a second time in an equivalent
+    form that differs in rounding only -- fp32: gate products on fp32 MFMA instead of split operands (gate dtype "f32_mfma");
+    bf16: the two-row-tile kernels forced on the halves (``fused.NARROW``) -- and per tensor the full batch may be at most
+    4 x as far from the sub-batches as those two evaluations of the sub-batches are from each other (never asked to be below
+    2e-4 / BF16_TOL).  A wrong row-tile mapping, stash slot or storage offset at the 950-tile geometry moves results by O(1).
+    Gradients: the full batch's loss is sum_mol ||rows||^2 + KL with KL a MEAN over the batch (ggpm/property_vae.py:30), so
+    the sub-batch losses carry their KL with weight sub/32 and the parameter gradients must add up."""
+    from ggpm_amd import _lib, fused, synth
+    from ggpm_amd.params import encoder_param_shapes, vae_head_shapes, seeded_state_dict
+    from ggpm_amd.property_vae import HierEncoderVAE
+    H, depth, B, latent = 600, 30, 32, 32
+    sub = 4 if dtype == "f32" else 16
+    specs = synth.random_batch(515, B, motifs=(46, 58), n_motif_vocab=500, n_attach_vocab=1500, chain=1.0)
+    sd = seeded_state_dict(encoder_param_shapes("GRU", H, 500, 1500), 5)
+    sd.update(seeded_state_dict(vae_head_shapes(H, latent), 6))
+
+    class A:
+        pass
+    a = A()
+    a.vocab, a.atom_vocab = _Vocab((500, 1500)), _Vocab(38)
+    a.rnn_type, a.embed_size, a.hidden_size = "GRU", H, H
+    a.depthT = a.depthG = depth
+    a.dropout, a.latent_size = 0.0, latent
+
+    def run(group, kl_weight, dt, narrow=False):
+        tree, graph = synth.tensorize(group)
+        model = HierEncoderVAE(a).to(_dev())
+        model.load_state_dict({(k if k.startswith("R_") else "encoder." + k): torch.from_numpy(v) for k, v in sd.items()})
+        model.encoder.gate_dtype = dt
+        fused.NARROW[0] = narrow
+        try:
+            z, kl, outs = model((tree, graph), perturb_z=False)
+            (kl_weight * kl + sum((o * o).sum() for o in outs)).backward()
+        finally:
+            fused.NARROW[0] = False
+        torch.cuda.synchronize()
+        grads = {k: (v.grad.double().cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in model.named_parameters()}
+        rows = [o.detach().cpu().numpy() for o in outs]                     # hroot [B], hnode / hinter [Nt + 1], hatom [Na + 1]
+        res = dict(rows=rows, scopes=(tree[-1], graph[-1]), grads=grads, E1=int(graph[1].shape[0]))
+        del model
+        return res
+
+    def per_molecule(r, i):
+        (t0, tn), (a0, an) = r["scopes"][0][i], r["scopes"][1][i]
+        return [r["rows"][0][i:i + 1], r["rows"][1][t0:t0 + tn], r["rows"][2][t0:t0 + tn], r["rows"][3][a0:a0 + an]]
+
+    def pieces(dt, narrow=False):
+        return [run(specs[j:j + sub], sub / B, dt, narrow) for j in range(0, B, sub)]
+
+    def distance(big, small, scale):
+        """-> (per-output max row distance, {param: gradient distance}) between `big` (one run, or a list of pieces) and the pieces"""
+        rows = [0.0] * 4
+        for j, sm in enumerate(small):
+            for i in range(sub):
+                x = per_molecule(big, j * sub + i) if isinstance(big, dict) else per_molecule(big[j], i)
+                for n, (u, v) in enumerate(zip(x, per_molecule(sm, i))):
+                    assert u.shape == v.shape
+                    rows[n] = max(rows[n], float(np.abs(u - v).max()) / scale[n])
+        g_big = big["grads"] if isinstance(big, dict) else {k: sum(q["grads"][k] for q in big) for k in big[0]["grads"]}
+        grads = {}
+        for k, g in g_big.items():
+            tot = sum(sm["grads"][k] for sm in small)
+            grads[k] = float(np.abs(g - tot).max()) / max(float(np.abs(tot).max()), 1e-30)
+        return rows, grads
+
+    big = run(specs, 1.0, dtype)
+    small = pieces(dtype)
+    other = pieces("f32_mfma") if dtype == "f32" else pieces("bf16", narrow=True)      # the same pieces, rounding differs
+    lib = _lib.load(build_if_missing=False)
+    assert big["E1"] - 1 >= 512 * 16, "the B = 32 batch must reach the two-row-tile geometry (>= 512 row tiles)"
+    assert bool(lib.ggpm_level_bf16_storage(big["E1"], H))
+    if dtype == "bf16":
+        assert all(lib.ggpm_level_bf16_storage(q["E1"], H) for q in small), "the halves must round where the full batch rounds"
+    names = ("hroot", "hnode", "hinter", "hatom")
+    scale = [float(np.abs(r).max()) for r in big["rows"]]
+    row_err, grad_err = distance(big, small, scale)
+    row_noise, grad_noise = distance(other, small, scale)
+    floor = 2e-4 if dtype == "f32" else BF16_TOL
+    worst_k = max(grad_err, key=lambda k: grad_err[k] / max(4 * grad_noise[k], floor))
+    print("configs[4] B=32 (%s) vs its %d B=%d sub-batches: rows %s (between two evaluations of the sub-batches: %s); gradients "
+          "worst %s %.2e (between the two evaluations %.2e)" % (
+              dtype, B // sub, sub, ", ".join("%s %.1e" % kv for kv in zip(names, row_err)),
+              ", ".join("%.1e" % v for v in row_noise), worst_k, grad_err[worst_k], grad_noise[worst_k]))
+    for n, e, noise in zip(names, row_err, row_noise):
+        assert e <= max(4 * noise, floor), (n, e, noise)
+    for k in grad_err:
+        assert grad_err[k] <= max(4 * grad_noise[k], floor), (k, grad_err[k], grad_noise[k])
 
 
 def test_configs4_shape_on_chain_polymers_meets_the_plain_bar():
@@ -1012,6 +1115,11 @@ def test_bf16_level_kernels_match_the_bf16_oracle(rnn, E, I, H, depth):
         frac_min = {"h": 0.9, "dx": 0.7} if mode != "bf16s" else {"h": 0.75, "dx": 0.5}
         med_tol = 5e-6 if mode == "bf16s" else 2e-6      # (measured: <= 2.6e-6 at H = 600, 0.0 for the state at every size)
         assert med <= med_tol and frac >= frac_min[k] and worst <= worst_tol, (k, med, frac, worst)
+        # What the relaxed row fractions above still pin: a wrong rounding point, rounding mode, operand
+        # order or accumulation moves EVERY row.  Under bf16 storage a state row without a flipped rounding is BIT-EQUAL to
+        # the oracle (both round the same fp32 value to the same bf16), so the median row distance is exactly zero -- asserted.
+        if mode == "bf16s" and k == "h":
+            assert med == 0.0, ("bf16 storage: the median state row must be bit-equal to the oracle", med)
     errs = {k: rel_err(got["bf16"][k], want[k]) for k in sd}
     worst_k = max(errs, key=errs.get)
     print("bf16 level %s E=%d H=%d depth=%d (weight-gradient operands %s): %s; parameter gradients worst %.2e (%s) at a "
@@ -1231,8 +1339,7 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     monkeypatch.setattr(dev_settings, "ATOM_COMPACT", mode != "batched_full")     # compact row sets per decode step
     monkeypatch.setattr(dev_settings, "ATOM_AHEAD", mode == "batched")
     if mode == "batched_pyloop":        # the decode step loops issued from Python instead of csrc/decode.hip
-        import ggpm_amd.atom_decode as _ad
-        monkeypatch.setattr(_ad, "_DRIVER", False)
+        monkeypatch.setattr(dev_settings, "DECODE_DRIVER", False)
     from golden_utils import VaeGolden
     from ggpm_amd import synth
     from ggpm_amd.decoder import DecodeSchedule
@@ -1335,6 +1442,24 @@ def test_vae_step_at_config_shapes_matches_oracle(rnn, H, L, depth, B, motifs, v
     assert abs(metrics["KL:"] - float(rkl.detach())) <= TOL * max(1.0, abs(float(rkl.detach())))
     assert np.allclose([metrics[k] for k in ("Word", "I-Word", "Topo", "Assm")], [float(x) for x in accs], atol=1e-6)
     gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    # The step is piecewise smooth: every ReLU (W_o / W_i / W_c read-outs, the hidden layers of the four heads) is a kink, and
+    # a pre-activation within rounding of zero falls on one side or the other depending on the arithmetic.  When that happens
+    # the reference's OWN answer depends on it: on the configs[1] case (seed 4242) the oracle's fp32 and fp64 runs differ by
+    # 1.0e-3 on E_c's gradient and 2e-2 on iclsNN's (one flipped hidden unit), the HIP path -- with the <= 1-ulp gather sigmoid
+    # of round 5 -- sits 7.8e-6 / 6e-7 from the fp64 run (tools/probe/vae_cfg_err.py; with the 2-ulp sigmoid of round 4 it sat
+    # 9e-6 from the fp32 run instead).  Both runs are the reference: a tensor must be within TOL of the fp32 run OR, where the
+    # two disagree by more than TOL, of the fp64 run (evaluated only when the fp32 comparison fails).
+    p64 = None
+
+    def fp64_grads():
+        q = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items()}
+        if tie:
+            for k in ("E_c.0.weight", "E_i.0.weight"):
+                q["encoder." + k] = q["decoder.hmpn." + k]
+        l64, _, _, _ = refd.vae_forward(q, rnn, depth, depth, 1, 5, tt, gt, sch, voc.mask.double(), 0.1)
+        l64.backward()
+        return q
+
     for k, v in model.named_parameters():
         want = p[k].grad.numpy() if p[k].grad is not None else np.zeros(tuple(v.shape), np.float32)
         got = v.grad.cpu().numpy() if v.grad is not None else np.zeros_like(want)
@@ -1342,7 +1467,15 @@ def test_vae_step_at_config_shapes_matches_oracle(rnn, H, L, depth, B, motifs, v
         if scale <= 1e-6 * gmax:            # analytically zero gradients (a bias under a softmax over all rows): rounding only
             assert float(np.abs(got).max()) <= 1e-4 * gmax, k
             continue
-        assert float(np.abs(got - want).max()) / scale < TOL, (k, float(np.abs(got - want).max()) / scale)
+        e32 = float(np.abs(got - want).max()) / scale
+        if e32 < TOL:
+            continue
+        if p64 is None:
+            p64 = fp64_grads()
+        w64 = p64[k].grad.numpy()
+        e64 = float(np.abs(got - w64).max()) / float(np.abs(w64).max())
+        split = float(np.abs(want - w64).max()) / float(np.abs(w64).max())
+        assert split > TOL and e64 < TOL, (k, "HIP vs the oracle's fp32 run %.2e, vs its fp64 run %.2e; fp32 vs fp64 %.2e" % (e32, e64, split))
 
 
 @pytest.mark.parametrize("M,N,ld", [(1, 1, 4), (37, 300, 304), (600, 250, 256), (2048, 62, 64), (2049, 300, 304),

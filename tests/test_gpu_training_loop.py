@@ -167,7 +167,7 @@ def test_schedule_ahead_loop_equals_the_plain_loop():
 
 def test_metrics_read_through_the_event_equal_the_blocking_read(monkeypatch):
     """StepMetrics: the six values copied to pinned memory behind the forward and read through the copy's event are the
-    floats the blocking read returns (GGPM_METRICS_ASYNC=0) and the reference's ``.item()`` values (GGPM_LAZY_METRICS=0)."""
+    floats the blocking read returns (_dev.METRICS_ASYNC = False) and the reference's ``.item()`` values (GGPM_LAZY_METRICS=0)."""
     from ggpm_amd import synth
     from ggpm_amd.property_vae import HierPropertyVAE
     from ggpm_amd.vocab import IndexPairVocab

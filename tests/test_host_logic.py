@@ -186,7 +186,7 @@ def test_state_dict_keys_are_the_references(name):
 
 def test_published_gradients_are_not_stream_marked_by_default():
     """functional.hand_to: a gradient handed from a helper stream to the main stream gets no record_stream mark (on ROCm
-    each mark is an event record on that stream when the tensor is released); GGPM_RECORD_GRADS=1 at import restores it"""
+    each mark is an event record on that stream when the tensor is released); _dev.RECORD_GRADS = True restores it"""
     from ggpm_amd import functional as F_
 
     class Probe:
@@ -195,6 +195,15 @@ def test_published_gradients_are_not_stream_marked_by_default():
         def record_stream(self, stream):
             Probe.marks += 1
 
+    from ggpm_amd import _dev
     F_.hand_to(Probe(), object())
-    assert Probe.marks == (1 if F_._RECORD_GRADS else 0)
+    assert Probe.marks == (1 if _dev.RECORD_GRADS else 0)
+    # the setting is read at call time: flipping it after import takes effect
+    was, _dev.RECORD_GRADS = _dev.RECORD_GRADS, not _dev.RECORD_GRADS
+    try:
+        before = Probe.marks
+        F_.hand_to(Probe(), object())
+        assert Probe.marks - before == (1 if _dev.RECORD_GRADS else 0)
+    finally:
+        _dev.RECORD_GRADS = was
 

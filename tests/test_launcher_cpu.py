@@ -117,3 +117,43 @@ def test_bench_argument_parsing_and_launch_decision(monkeypatch):
     monkeypatch.delenv("GGPM_BENCH_ONE_DEVICE")
     with pytest.raises(SystemExit):                         # this container shows no GPU: a clear refusal, not a hang
         bench.launch_ranks(a, [])
+
+
+def test_gpus_are_counted_from_the_driver_topology_without_hip(tmp_path, monkeypatch):
+    """launcher.visible_gpu_count: GPU nodes of the amdkfd topology (simd_count > 0), narrowed by *_VISIBLE_DEVICES; the
+    parent of a multi-rank run must not call torch.cuda (device_count() can fall back to hipGetDeviceCount)."""
+    topo = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):        # two CPU agents, three GPUs
+        d = topo / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    assert launcher.visible_gpu_count({}, str(topo)) == 3
+    assert launcher.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,2"}, str(topo)) == 2
+    assert launcher.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}, str(topo)) == 1
+    assert launcher.visible_gpu_count({"HIP_VISIBLE_DEVICES": ""}, str(topo)) == 0
+    assert launcher.visible_gpu_count({}, str(tmp_path / "absent")) == 0
+    # bench.launch_ranks asks the launcher, never torch.cuda
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import torch
+
+    def boom(*a, **k):
+        raise AssertionError("torch.cuda touched in the launcher parent")
+
+    monkeypatch.setattr(torch.cuda, "device_count", boom)
+    monkeypatch.setattr(torch.cuda, "is_available", boom)
+    monkeypatch.setattr(launcher, "visible_gpu_count", lambda *a, **k: 8)
+    monkeypatch.setattr(launcher, "run_ranks", lambda script, argv, world, timeout=0, **kw: 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("GGPM_BENCH_ONE_DEVICE", raising=False)
+    assert bench.launch_ranks(bench.parse_args(["--gpus", "8"]), ["--gpus", "8"]) == 0
+
+
+def test_other_ranks_never_write_to_the_parents_stdout(stub, capfd):
+    """`err` without a file descriptor (io.StringIO): ranks > 0 go to DEVNULL, not to the inherited stdout."""
+    script, marker = stub
+    out, err = io.StringIO(), io.StringIO()
+    rc = launcher.run_ranks(script, ["ok", marker], 2, timeout=60, out=out, err=err)
+    assert rc == 0 and len(out.getvalue().strip().splitlines()) == 1
+    assert '"rank": 1' not in capfd.readouterr().out

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import bench
+from ggpm_amd import _dev
 from ggpm_amd.nnutils import make_cuda
 from ggpm_amd.parallel import FlatGradSync
 from ggpm_amd.property_vae import HierEncoderVAE, rsample
@@ -15,7 +16,7 @@ pool = bench.make_batches(8, CFG["batch"], seed0=1000, gen=CFG["gen"], n_motif=C
 dev_batches = [make_cuda(b) for b in pool]
 torch.manual_seed(0)
 model = HierEncoderVAE(bench.make_args(rnn, CFG["hidden"], CFG["depth"], CFG["latent"], *CFG["vocab"])).to(dev)
-if os.environ.get("GGPM_FLAT_ADAM", "1") != "0":
+if _dev.HIP_ADAM:      # (False: torch.optim.Adam, for A/B runs)
     from ggpm_amd.optim import FlatAdam
     sync = FlatGradSync(model.parameters(), encoder=model.encoder, keep_flat=True)
     opt = FlatAdam(sync, lr=1e-3)
