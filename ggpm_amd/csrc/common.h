@@ -99,13 +99,13 @@ __device__ __forceinline__ float4 ggpm_sigmoid4(float4 a) {
 __device__ __forceinline__ float4 ggpm_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // The gather phases of the depth kernels evaluate one sigmoid per gathered neighbour element (rnn.py:31-32, 90) and are VALU
 // bound with libm expf + IEEE division (1.0 / 2.3 us per atom-level launch, round 4).  Two forms on the hardware units:
-// FAST (bf16 gate modes only): v_exp_f32(-x * log2e), v_rcp_f32.  The rounding of the product -x * log2e alone is worth
+// FAST (rounds 1-4; ablation builds only now): v_exp_f32(-x * log2e), v_rcp_f32.  The rounding of the product -x * log2e alone is worth
 // |x| * log2e * 2^-24 * ln2 relative error of the exponential (1.4 ulp at |x| = 5, 3 ulp at |x| = 10), then v_exp_f32 and
 // v_rcp_f32 add ~1 ulp each: measured mean 1.30 ulp, 25 % of the arguments above 1 ulp, 29.5 ulp at x = -29.8
 // (tools/probe/sigmoid_ulp.hip), and a sum-aggregating GRU over 30 depths amplifies it (twice the distance
 // to fp64 on the deciding configs[4] tensors).
 __device__ __forceinline__ float ggpm_fsigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-// ACCURATE (fp32 gate modes): measured mean 0.42 ulp, 6.9 % above 1 ulp, worst 3.4 ulp -- at |x| ~ 16.7, where 1 + e itself
+// ACCURATE (shipped, every gate mode): measured mean 0.42 ulp, 6.9 % above 1 ulp, worst 3.4 ulp -- at |x| ~ 16.7, where 1 + e itself
 // rounds -- against 0.40 / 5.3 % / 2.5 for libm expf + IEEE division, in 11 instructions instead of ~35 (and FEWER issue
 // slots than the fast form, whose __expf carries denormal-range handling: 2.57 against 3.82 ms for 2^33 evaluations):
 //   t = -x * log2e as a two-term product t_hi + t_lo (log2e = L_hi + L_lo, the rounding of the leading product recovered by
@@ -124,17 +124,20 @@ __device__ __forceinline__ float ggpm_fsigmoid_acc(float x) {
     const float r = __builtin_amdgcn_rcpf(d);
     return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 }
+// Round 5: the accurate form in EVERY gate mode -- under bf16 gate products, too, it is the faster one (configs[4] bf16 leg, same
+// box, alternating: 19.98 -> 19.47 ms per step, gru_fwd_a 129.8 -> 124.4 us, gru_bwd_a 115.8 -> 108.7 us: those gathers are VALU
+// bound) and the bf16 oracle tests see fewer flipped roundings with it.  The template argument stays for the ablation builds.
 #ifdef GGPM_ABL_EXACT_GATHER_SIGMOID      // ablation build (python -m ggpm_amd.build --variant exactsig -DGGPM_ABL_EXACT_GATHER_SIGMOID):
-template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_sigmoid(x); }      // libm expf + IEEE division in the gathers too
+template <bool BF16> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_sigmoid(x); }      // libm expf + IEEE division in the gathers too
 #elif defined(GGPM_ABL_FAST_GATHER_SIGMOID)      // ablation build: the round-4 form in every gate mode (timing A/B)
-template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_fast(x); }
-#elif defined(GGPM_ABL_ACC_SIGMOID_BF16)        // ablation build: the accurate form in the bf16 gate modes as well (timing / flip-count A/B)
-template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_acc(x); }
+template <bool BF16> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_fast(x); }
+#elif defined(GGPM_ABL_FAST_SIGMOID_BF16)        // ablation build: the round-4 form under bf16 gate products only
+template <bool BF16> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return BF16 ? ggpm_fsigmoid_fast(x) : ggpm_fsigmoid_acc(x); }
 #else
-template <bool FAST> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return FAST ? ggpm_fsigmoid_fast(x) : ggpm_fsigmoid_acc(x); }
+template <bool BF16> __device__ __forceinline__ float ggpm_fsigmoid(float x) { return ggpm_fsigmoid_acc(x); }
 #endif
-template <bool FAST> __device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {
-    return make_float4(ggpm_fsigmoid<FAST>(a.x), ggpm_fsigmoid<FAST>(a.y), ggpm_fsigmoid<FAST>(a.z), ggpm_fsigmoid<FAST>(a.w));
+template <bool BF16> __device__ __forceinline__ float4 ggpm_fsigmoid4(float4 a) {
+    return make_float4(ggpm_fsigmoid<BF16>(a.x), ggpm_fsigmoid<BF16>(a.y), ggpm_fsigmoid<BF16>(a.z), ggpm_fsigmoid<BF16>(a.w));
 }
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global stores / loads

@@ -607,7 +607,7 @@ def test_configs4_full_batch_is_invariant_under_batch_composition(dtype):
 
     The bound is CALIBRATED like the configs[4] GRU parity case, and for the same reason (a sum-aggregating GRU over 30 depths
     amplifies rounding, by how much depends on the molecule): the sub-batches are evaluated a second time in an equivalent
-    form that differs in rounding only -- fp32: gate products on fp32 MFMA instead of split operands (gate dtype "f32_mfma");
+    form that differs in rounding only -- fp32: gate products on split bf16 operands instead of fp32 MFMA (gate dtype "f32_split");
     bf16: the two-row-tile kernels forced on the halves (``fused.NARROW``) -- and per tensor the full batch may be at most
     4 x as far from the sub-batches as those two evaluations of the sub-batches are from each other (never asked to be below
     2e-4 / BF16_TOL).  A wrong row-tile mapping, stash slot or storage offset at the 950-tile geometry moves results by O(1).
@@ -673,7 +673,10 @@ def test_configs4_full_batch_is_invariant_under_batch_composition(dtype):
 
     big = run(specs, 1.0, dtype)
     small = pieces(dtype)
-    other = pieces("f32_mfma") if dtype == "f32" else pieces("bf16", narrow=True)      # the same pieces, rounding differs
+    # the same pieces once more, rounding differs: fp32 -- gate products on split bf16 operands wherever they fit (the default
+    # form of a B = 4 piece at H = 600 is fp32 MFMA with two column groups, like the full batch's two-row-tile launches);
+    # bf16 -- the two-row-tile kernels forced on the halves
+    other = pieces("f32_split") if dtype == "f32" else pieces("bf16", narrow=True)
     lib = _lib.load(build_if_missing=False)
     assert big["E1"] - 1 >= 512 * 16, "the B = 32 batch must reach the two-row-tile geometry (>= 512 row tiles)"
     assert bool(lib.ggpm_level_bf16_storage(big["E1"], H))
