@@ -181,6 +181,18 @@ int ggpm_gru_bias_u_grad(int E1, int H, int depth, int lo, float* work, float* d
 // ggpm_backward_defer_stash (include/ggpm_hip.h): caller-owned gate-gradient stashes for the next sparse backward of this
 // thread.  -> true (and the pointers) once.
 bool ggpm_take_defer_stash(float* (&out)[4]);
+// The next SPARSE backward of this thread (GRU or LSTM) leaves the hidden-half weight gradients to a later call of
+// ggpm_gru_sparse_weight_grads / ggpm_lstm_sparse_weight_grads with the same arguments -- the same launches, on whatever stream
+// that call names (tree_level.hip: beside the rest of the level's backward instead of in front of it).  Consumed by one call.
+void ggpm_sparse_backward_skip_wgrads(int yes);
+bool ggpm_take_sparse_skip_wgrads();
+int ggpm_gru_sparse_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs, float* work,
+                                 size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
+                                 int ld_dwh, ggpm_stream_t stream);
+int ggpm_lstm_sparse_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work, size_t work_bytes,
+                                  float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu, float* dWf_h,
+                                  int ld_dwf, ggpm_stream_t stream);
+hipEvent_t ggpm_wgrad_event(int i);          // small pool of re-recordable events, per thread (mpn_gru.hip)
 // ggpm_backward_skip_x_sums (include/ggpm_hip.h): consumed by the next dense level backward of this thread.
 bool ggpm_take_skip_x_sums();
 // ggpm_level_prefer_narrow (include/ggpm_hip.h): state of this thread's switch (mpn_gru.hip).

@@ -1017,6 +1017,9 @@ extern "C" void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float
     g_defer[0] = s0; g_defer[1] = s1; g_defer[2] = s2; g_defer[3] = s3;
     g_defer_set = s0 != nullptr;
 }
+namespace { thread_local bool g_sparse_skip_wgrads = false; }
+void ggpm_sparse_backward_skip_wgrads(int yes) { g_sparse_skip_wgrads = yes != 0; }
+bool ggpm_take_sparse_skip_wgrads() { const bool v = g_sparse_skip_wgrads; g_sparse_skip_wgrads = false; return v; }
 namespace { thread_local bool g_skip_xsum = false; }
 extern "C" void ggpm_backward_skip_x_sums(int yes) { g_skip_xsum = yes != 0; }
 bool ggpm_take_skip_x_sums() { const bool v = g_skip_xsum; g_skip_xsum = false; return v; }
@@ -1293,6 +1296,7 @@ static int gru_backward_impl(int E1, int H, int depth, const float* Xr, const fl
                                  const unsigned char* frozen, float* dHin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
+    if (ggpm_take_sparse_skip_wgrads() && frozen) weight_grads = 0;      // (ggpm_gru_sparse_weight_grads follows, on the caller's choice of stream)
     const bool skip_xsum = ggpm_take_skip_x_sums() && !frozen;
     float *ss_h = nullptr, *ss_c = nullptr;
     const int32_t* ss_idx = nullptr;
@@ -1560,6 +1564,13 @@ extern "C" int ggpm_gru_weight_grads_stacked(int rows, int rows_q, int H, const 
     if (rc) return rc;
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+int ggpm_gru_sparse_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs, float* work,
+                                 size_t work_bytes, float* dWz_h, int ld_dwz, float* dUr, int ld_dur, float* dbu, float* dWh_h,
+                                 int ld_dwh, ggpm_stream_t stream) {
+    return gru_weight_grads_impl(E1, H, depth, Hs, Ss, Gs, work, work_bytes, dWz_h, ld_dwz, dUr, ld_dur, dbu, dWh_h, ld_dwh,
+                                 true, 1, stream);
 }
 
 extern "C" int ggpm_gru_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, const float* Gs,

@@ -910,6 +910,7 @@ static int lstm_backward_impl(int E1, int H, int depth, const float* Xf, const f
                                   size_t work_bytes, int weight_grads, const unsigned char* frozen,
                                   const float* dCD, float* dHin, float* dCin, ggpm_stream_t stream) {
     GGPM_CLEAR_STALE_ERROR();
+    if (ggpm_take_sparse_skip_wgrads() && frozen) weight_grads = 0;      // (ggpm_lstm_sparse_weight_grads follows)
     const bool weights_packed = ggpm_take_weights_packed();      // (consumed on every path)
     float *ss_h = nullptr, *ss_c = nullptr;
     const int32_t* ss_idx = nullptr;
@@ -1123,6 +1124,13 @@ extern "C" int ggpm_lstm_weight_grads_stacked(int rows, int rows_q, int H, const
     if (rc) return rc;
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
+}
+
+int ggpm_lstm_sparse_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work, size_t work_bytes,
+                                  float* dWi_h, int ld_dwi, float* dWo_h, int ld_dwo, float* dWu_h, int ld_dwu, float* dWf_h,
+                                  int ld_dwf, ggpm_stream_t stream) {
+    return lstm_weight_grads_impl(E1, H, depth, Hs, Ss, work, work_bytes, dWi_h, ld_dwi, dWo_h, ld_dwo, dWu_h, ld_dwu, dWf_h,
+                                  ld_dwf, true, 1, stream);
 }
 
 extern "C" int ggpm_lstm_weight_grads(int E1, int H, int depth, const float* Hs, const float* Ss, float* work,

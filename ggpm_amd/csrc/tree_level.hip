@@ -125,9 +125,13 @@ extern "C" int ggpm_tree_level_forward(const ggpm_tree_level* L, float* saved, s
     CK(ggpm_onehot(L->mess_pos, d.ms, MAX_POS, v.hmess, d.ldm, H, d.ldm, stream));
     // 4. hoisted gate inputs, straight into the rows 1 .. E1-1 they belong to (row 0 / the extra rows: zero)
     if (hipMemsetAsync(v.X, 0, (size_t)d.G * d.slot * sizeof(float), s) != hipSuccess) return GGPM_ERR_LAUNCH;
-    for (int k = 0; k < d.G; ++k)
-        CK(ggpm_gemm(0, 1, d.ms, H, I, v.hmess, d.ldm, L->gate_w[k], L->ld_gate[k], v.X + (size_t)k * d.slot + Hp, Hp, Hp,
-                     L->gate_b[k], 0, GGPM_ACT_NONE, 0, nullptr, 0, stream));
+    {       // (one grouped launch, as the encoder's levels have it: three launches of 17-18 us -> one of ~12)
+        ggpm_gemm_problem gp[4];
+        for (int k = 0; k < d.G; ++k)
+            gp[k] = {v.hmess, d.ldm, L->gate_w[k], L->ld_gate[k], v.X + (size_t)k * d.slot + Hp, Hp, Hp, L->gate_b[k], 0,
+                     GGPM_ACT_NONE, 0};
+        CK(ggpm_gemm_grouped(0, 1, d.ms, H, I, d.G, gp, stream));
+    }
     // 5. start state: zero, the extra (frozen) rows carry `extra`
     if (hipMemsetAsync(v.hp, 0, d.slot * sizeof(float), s) != hipSuccess) return GGPM_ERR_LAUNCH;
     if (L->extra && L->n_extra > 0 &&
@@ -163,9 +167,15 @@ extern "C" int ggpm_tree_level_forward(const ggpm_tree_level* L, float* saved, s
     return GGPM_OK;
 }
 
+// `side_stream` (nullable): the level's PARAMETER gradients -- the hidden-half contractions over the stashes, the input
+// halves of the gate weights, the gate biases: ~145 us of a ~470 us level at configs[1] -- are issued there, behind an event
+// that the main stream records after the depth loop, so that the gradient the caller waits for (d_lower: what flows on to the
+// level below and, on the attachment level, to the atom level's 2.8 ms backward chain) is not queued behind them.  The same
+// launches in the same order either way: results do not depend on it.  The caller joins the second stream before it reads
+// those gradients and keeps `work` and the forward's `saved` alive until then.
 extern "C" int ggpm_tree_level_backward(const ggpm_tree_level* L, const ggpm_tree_level_views* vin, const float* d_node,
                                         const float* d_hid, const ggpm_tree_level_grads* g, float* work, size_t work_bytes,
-                                        ggpm_stream_t stream) {
+                                        ggpm_stream_t stream, ggpm_stream_t side_stream) {
     GGPM_CLEAR_STALE_ERROR();
     Dims d;
     if (!dims_of(L, d) || !vin || !g || !work || !L->succ_rowptr || !L->succ_col || !L->inT_rowptr || !L->inT_col ||
@@ -212,6 +222,8 @@ extern "C" int ggpm_tree_level_backward(const ggpm_tree_level* L, const ggpm_tre
     CK(ggpm_segment_sum(d_nei, Hp, L->inT_rowptr, L->inT_col, d.Etot, H, dHD, Hp, acc, acc ? 0 : Hp, stream));
     // ---- the level
     const size_t ds = (size_t)d.depth * d.slot;
+    hipStream_t ws = side_stream ? (hipStream_t)side_stream : s;       // where the parameter gradients are formed
+    if (side_stream) ggpm_sparse_backward_skip_wgrads(1);
     if (d.lstm) {
         if (hipMemsetAsync(dCD, 0, d.slot * sizeof(float), s) != hipSuccess) return GGPM_ERR_LAUNCH;
         CK(ggpm_lstm_sparse_backward(d.Etot, H, d.depth, L->frozen, v.X + 3 * d.slot, L->gate_w[0] + I, L->ld_gate[0],
@@ -228,13 +240,25 @@ extern "C" int ggpm_tree_level_backward(const ggpm_tree_level* L, const ggpm_tre
                                     g->dHin, dX, dX + d.slot, dX + 2 * d.slot, g->dgate_w[0] + I, g->ld_dgate[0], g->dUr, H,
                                     g->dbu, g->dgate_w[2] + I, g->ld_dgate[2], lwork, lwb, stream));
     }
+    if (side_stream) {      // the stashes and dX are complete: hidden halves on the second stream, in the order the level call had them
+        hipEvent_t ev = ggpm_wgrad_event(41);
+        if (!ev || hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(ws, ev, 0) != hipSuccess) return GGPM_ERR_LAUNCH;
+        if (d.lstm)
+            CK(ggpm_lstm_sparse_weight_grads(d.Etot, H, d.depth, v.Hs, v.St, lwork, lwb, g->dgate_w[0] + I, g->ld_dgate[0],
+                                             g->dgate_w[1] + I, g->ld_dgate[1], g->dgate_w[2] + I, g->ld_dgate[2],
+                                             g->dgate_w[3] + I, g->ld_dgate[3], (ggpm_stream_t)ws));
+        else
+            CK(ggpm_gru_sparse_weight_grads(d.Etot, H, d.depth, v.Hs, v.St, v.St + ds, lwork, lwb, g->dgate_w[0] + I,
+                                            g->ld_dgate[0], g->dUr, H, g->dbu, g->dgate_w[2] + I, g->ld_dgate[2],
+                                            (ggpm_stream_t)ws));
+    }
     // input halves of the gate weights, gate biases (the rows of the real messages, 1 .. E1-1, are contiguous)
     const float* dXs[4];
     for (int k = 0; k < G; ++k) dXs[k] = dX + (size_t)k * d.slot + Hp;
     for (int k = 0; k < G; ++k) {
         CK(ggpm_gemm(1, 0, H, I, d.ms, dXs[k], Hp, v.hmess, d.ldm, g->dgate_w[k], g->ld_dgate[k], I, nullptr, 0, GGPM_ACT_NONE, 0,
-                     skws, skb, stream));
-        if (g->dgate_b[k]) CK(ggpm_colsum(dXs[k], Hp, d.ms, H, g->dgate_b[k], csws, stream));
+                     skws, skb, (ggpm_stream_t)ws));
+        if (g->dgate_b[k]) CK(ggpm_colsum(dXs[k], Hp, d.ms, H, g->dgate_b[k], csws, (ggpm_stream_t)ws));
     }
     // ---- message inputs -> visit vectors
     {

@@ -20,14 +20,13 @@ class FlatAdam:
     def __init__(self, sync, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         self.sync = sync
         params = sync.params
-        flat = torch.empty(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
-        off = 0
+        # the gradient buffer's layout: every parameter on a 256-byte boundary (parallel.FlatGradSync says why), zeros between
+        flat = torch.zeros(sync.flat.numel(), dtype=params[0].dtype, device=params[0].device)
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, sync.offsets):
                 n = p.numel()
                 flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = flat[off:off + n].view_as(p)          # the module's parameters are views of the flat buffer now
-                off += n
         self.flat = torch.nn.Parameter(flat)
         self.opt = torch.optim.Adam([self.flat], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=flat.is_cuda)
         # on the GPU the step is ONE launch of ggpm_adam_step over the flat buffer (torch's fused Adam issues three

@@ -41,6 +41,8 @@ class FlatGradSync:
     collectives were slower than one (6.38 vs 5.98 ms/step) and the multi-GPU balance could not be measured here.
     """
 
+    ALIGN = 64      # floats
+
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, encoder=None, keep_flat: bool = False):
         import os
         import weakref
@@ -66,14 +68,22 @@ class FlatGradSync:
                 self.early_numel = sum(p.numel() for p in enc[:first_graph])
                 encoder._grad_sink = weakref.ref(self)
         self.params = uniq
-        total = sum(p.numel() for p in self.params)
+        # Every parameter starts on a 256-byte boundary of the flat buffer (zero padding in between: Adam leaves zeros at
+        # zero, an all-reduce of zeros is zeros).  Packed tightly, the first parameter with an element count that is not a
+        # multiple of four -- the decoder's topoNN ends in a Linear(H, 1): a bias of ONE float -- leaves everything behind it
+        # 4-byte aligned, and ggpm_amd.optim.FlatAdam makes the module's parameters views of a buffer with this layout: every
+        # GEMM that reads such a weight then fails the 16-byte test of the vector-load kernels and runs on the scalar-load
+        # fallback (round 5: the whole decoder side of the bench's VAE row did, 17-21 us per product instead of 9-12).
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = off
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        self.views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        if self.encoder_params:
+            self.early_numel = self.offsets[first_graph]
         self.encoder_views = self.views[:len(self.encoder_params)]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1

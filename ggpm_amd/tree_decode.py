@@ -367,14 +367,26 @@ class _TreeLevelNative(torch.autograd.Function):
             d_hid = d_hid.contiguous()
         wb = int(lib.ggpm_tree_level_work_bytes(ctypes.byref(L)))
         work = torch.empty((wb + 3) // 4, **f32)
+        # the level's parameter gradients on the second stream (csrc/tree_level.hip): what flows on -- d_lower, on the
+        # attachment level the input of the atom level's 2.8 ms backward chain -- is then not queued behind ~145 us of
+        # contractions per level.  The deferred-gradient queue (functional._DEFER) sums them: on that same stream when it is
+        # flushed early, on the main stream once it has waited for this one ("early") at the end of the pass.
+        side = F_._side_stream(dev) if (F_.side_stream_enabled() and _dev.TREE_WGRADS_ASIDE) else None
         _lib.check(lib.ggpm_tree_level_backward(ctypes.byref(L), ctypes.byref(V), F_._p(d_node), F_._p(d_hid), ctypes.byref(g),
-                                                F_._p(work), work.numel() * 4, F_._stream()), "tree_level_backward")
+                                                F_._p(work), work.numel() * 4, F_._stream(),
+                                                ctypes.c_void_p(side.cuda_stream) if side is not None else None),
+                   "tree_level_backward")
+        if side is not None:
+            for t in (work, saved):        # read there after this node has returned
+                t.record_stream(side)
         if lstm:
             pg = (dgw[0], dgb[0], dgw[1], dgb[1], dgw[2], dgb[2], dgw[3], dgb[3])
         else:
             pg = (dgw[0], dgb[0], dgw[1], dUr, dbu, dgw[2], dgb[2])
         for q, gr in zip(rp, pg):
             F_._defer_sum(q, gr)
+        if side is not None:
+            F_._DEFER["early"] = side      # the end-of-pass flush waits for the second stream before it reads what was queued
         F_._defer_linear(W, b, dpre_w, [finput, lower], (He, H))
         F_._defer_linear(Wo, bo, dpre_o, [hnode, nei], (H, H))
         F_._defer_gather(emb, He, d_finput, S.ids)

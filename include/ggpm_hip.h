@@ -447,9 +447,13 @@ size_t ggpm_tree_level_saved_floats(const ggpm_tree_level* level);
 size_t ggpm_tree_level_work_bytes(const ggpm_tree_level* level);
 int ggpm_tree_level_forward(const ggpm_tree_level* level, float* saved, size_t saved_floats, ggpm_tree_level_views* views,
                             ggpm_stream_t stream);
+/* side_stream (nullable): where the level's PARAMETER gradients (grads->dgate_w / dgate_b / dUr / dbu) are formed, behind an
+ * event the main stream records after the depth loop -- the gradients that flow on (d_lower, dHin, dpre_*, d_finput) are
+ * then not queued behind ~145 us of contractions.  Same launches, same results.  The caller joins that stream before it
+ * reads those four outputs and keeps `work` and the forward's `saved` alive until then. */
 int ggpm_tree_level_backward(const ggpm_tree_level* level, const ggpm_tree_level_views* views, const float* d_node,
                              const float* d_hid, const ggpm_tree_level_grads* grads, float* work, size_t work_bytes,
-                             ggpm_stream_t stream);
+                             ggpm_stream_t stream, ggpm_stream_t side_stream);
 
 /* ------------------------------------------------------------------ decoder score-head losses
  * Softmax cross entropy with reduction = sum and the additive vocabulary mask of ggpm/vocab.py:34-41,56-58 fused in

@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
         for b in mine[step::2]:
             model(_data(b)).pow(2).mean().backward()
         sync.all_reduce()
-        out.append(sync.flat.clone())
+        out.append(torch.cat([v.reshape(-1) for v in sync.views]).clone())       # (the buffer pads every parameter to 256 bytes)
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     q.put((rank, [o.numpy() for o in out], [p.detach().numpy() for p in model.parameters()]))
     dist.barrier()
@@ -119,3 +119,37 @@ def test_step_metrics_reads_on_first_access_and_behaves_like_the_reference_dict(
     assert m._ready and arr.tolist() == [98.875, 32.5, 0.25, 0.125, 0.5, 1.0]
     assert dict(m.items()) == {'Loss': 98.875, 'KL:': 32.5, 'Word': 0.25, 'I-Word': 0.125, 'Topo': 0.5, 'Assm': 1.0}
     assert all(isinstance(v, float) for v in m.values()) and m.get('nope', 7) == 7
+
+
+def test_flat_buffers_keep_every_parameter_on_a_256_byte_boundary():
+    """FlatGradSync / FlatAdam: a parameter with an odd element count (the decoder's topoNN ends in Linear(H, 1): a bias of one
+    float) must not leave the parameters behind it 4-byte aligned -- the vector-load GEMM kernels need 16-byte aligned
+    weights and fall back to scalar loads otherwise.  Same numbers as torch.optim.Adam on separately allocated tensors."""
+    import copy
+    from ggpm_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 1), torch.nn.Linear(1, 7), torch.nn.Linear(7, 3))
+    ref = copy.deepcopy(model)
+    sync = FlatGradSync(model.parameters(), keep_flat=True)
+    assert sync.offsets == sorted(sync.offsets) and all(o % 64 == 0 for o in sync.offsets)
+    assert sync.flat.numel() % 64 == 0 and sync.flat.numel() >= sum(p.numel() for p in model.parameters())
+    opt = FlatAdam(sync, lr=1e-2)
+    base = opt.flat.data_ptr()
+    assert all((p.data_ptr() - base) % 256 == 0 for p in model.parameters())
+    assert all((v.data_ptr() - sync.flat.data_ptr()) % 256 == 0 for v in sync.views)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    x = torch.randn(11, 5)
+    for _ in range(3):
+        sync.zero_grad()
+        model(x).pow(2).sum().backward()
+        sync.all_reduce()
+        opt.step()
+        ropt.zero_grad()
+        ref(x).pow(2).sum().backward()
+        ropt.step()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
+    pad = torch.ones(sync.flat.numel(), dtype=torch.bool)
+    for o, p in zip(sync.offsets, sync.params):
+        pad[o:o + p.numel()] = False
+    assert float(opt.flat.data[pad].abs().max()) == 0.0 and float(sync.flat[pad].abs().max()) == 0.0      # the padding stays zero
