@@ -19,6 +19,7 @@ ATOM_ASYNC = True          # ... issued by a worker thread of the library (ggpm_
 PACK_ONCE = True           # the decode steps share one packed weight set (False: every step packs again)
 TREE_COMPOSITE = True      # each tree-side decoder level as one autograd node (False: op by op)
 TREE_DRIVER = True         # ... whose two directions are one C call each (csrc/tree_level.hip; False: ~30 ctypes calls)
+HEADS_COMPOSITE = True     # the four score heads + losses + accuracies as ONE autograd node (heads_fused.py; False: ~30 nodes)
 TREE_WGRADS_ASIDE = True   # ... and whose parameter gradients are formed on the second stream, beside the rest of the backward
 ENC_NARROW = True          # the encoder's levels take two row tiles per workgroup while they run beside the atom-level chain
                            # ("fwd" / "bwd": in that direction only)

@@ -514,12 +514,44 @@ class HierMPNDecoder(ScoreHeads):
             init_vecs = src_root_vecs
         else:
             init_vecs = F_.linear([src_root_vecs.contiguous()], [L], self.W_root.weight, self.W_root.bias)[:, :H]
+        self._heads_in = None
         if _dev.DECODER_BATCHED and schedule.plan["all_live"] and schedule.plan["E1"] > 1:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_batched(schedule, D, tree_tensors, graph_tensors,
                                                                             init_vecs)
         else:
             topo_vecs, cls_vecs, assm_vecs, assm_dest = self._states_stepwise(D, tree_tensors, graph_tensors, init_vecs)
+        heads_in, self._heads_in = self._heads_in, None
+        if heads_in is not None and src_tree_vecs is src_graph_vecs:
+            return self._losses_composite(schedule, D, src_tree_vecs, topo_vecs, cls_vecs, heads_in, B, dev)
+        if heads_in is not None:                     # (distinct tree / graph context vectors: the op-by-op heads)
+            cand, blocks = heads_in
+            for b in blocks:
+                assm_vecs.append(self.enum_attach_rows(cand[b.base:b.base + b.n], b.k, b.icls32, b.nth))
+                assm_dest.append(b.dest)
         return self._losses(schedule, D, src_tree_vecs, src_graph_vecs, topo_vecs, cls_vecs, assm_vecs, assm_dest, B, dev)
+
+    def _losses_composite(self, schedule, D, z, topo_vecs, cls_vecs, heads_in, B, dev):
+        """The four heads, their losses and accuracies as ONE autograd node (ggpm_amd/heads_fused.py): the same launches as
+        ``_losses`` issues through ~30 nodes (ggpm/decoder.py:136-164, 261-301)."""
+        from . import heads_fused
+        cand, blocks = heads_in
+        spec = D.get("heads_spec")
+        if spec is None:
+            i32 = lambda t: t if (t.dtype == torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous()
+            spec = D["heads_spec"] = dict(
+                topo_idx=i32(D["topo_batch32"]), topo_y=_memo(D, "topo_label_f32", lambda: D["topo_label"].to(torch.float32)),
+                cls_idx=i32(D["cls_batch32"]),
+                cls_lab=_memo(D, "cls_clab32", lambda: D["cls_clab"].to(torch.int32).contiguous()),
+                icls_lab=_memo(D, "cls_ilab32", lambda: D["cls_ilab"].to(torch.int32).contiguous()),
+                cls_lab_raw=D["cls_clab"], icls_lab_raw=D["cls_ilab"], topo_lab_raw=D["topo_label"],
+                n_assm=D["n_assm"], max_cls_size=schedule.max_cls_size,
+                assm_idx=i32(D["assm_batch32"]) if D["n_assm"] > 0 else None,
+                assm_lab=_memo(D, "assm_labels32", lambda: torch.zeros(max(D["n_assm"], 1), dtype=torch.int32, device=dev)))
+        spec = dict(spec, assm_blocks=blocks)
+        tv = topo_vecs if (topo_vecs.dim() == 2 and topo_vecs.stride(1) == 1 and topo_vecs.stride(0) % 4 == 0) else topo_vecs.contiguous()
+        cv = cls_vecs if (cls_vecs.dim() == 2 and cls_vecs.stride(1) == 1 and cls_vecs.stride(0) % 4 == 0) else cls_vecs.contiguous()
+        loss_sum, acc = heads_fused.heads_losses(self, spec, z, tv, cv, cand)
+        return loss_sum / B, acc[0], acc[1], acc[2], acc[3]
 
     def _states_stepwise(self, D, tree_tensors, graph_tensors, init_vecs):
         """The reference's loop, step by step (ggpm/decoder.py:175-259): three incremental encoder calls per step."""
@@ -667,7 +699,13 @@ class HierMPNDecoder(ScoreHeads):
                     assm_vecs.append(self.enum_attach_rows(cand[base:base + n], k, meta[k]["icls"], meta[k]["nth"]))
                     assm_dest.append(meta[k]["dest"])
 
-            attach_rows()
+            from . import heads_fused
+            self._heads_in = None
+            if heads_fused.usable(self):       # enum_attach moves into the heads' one autograd node (heads_fused.py)
+                self._heads_in = (cand, [heads_fused.AssmBlock(k, base, n, meta[k]["icls"], meta[k]["nth"], meta[k]["dest"])
+                                         for k, base, n in ap.cand_blocks])
+            else:
+                attach_rows()
             steps = []
         else:
             # the masked sub-tensors of every step come from the schedule (host-built, one upload); the constant one-hot

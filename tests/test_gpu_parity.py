@@ -1332,7 +1332,7 @@ def _vae_mode_cases():
     GRU and the first LSTM fixture."""
     names = _vae_names()
     picked = [next((n for n in names if cell in n), None) for cell in ("gru", "lstm")]
-    others = ["batched_inline", "batched_pyloop", "batched_full", "levels", "stepwise"]
+    others = ["batched_inline", "batched_pyloop", "batched_full", "batched_opheads", "levels", "stepwise"]
     return [(n, "batched") for n in names] + [(n, m) for n in picked if n for m in others]
 
 
@@ -1355,6 +1355,8 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     monkeypatch.setattr(dev_settings, "ATOM_AHEAD", mode == "batched")
     if mode == "batched_pyloop":        # the decode step loops issued from Python instead of csrc/decode.hip
         monkeypatch.setattr(dev_settings, "DECODE_DRIVER", False)
+    if mode == "batched_opheads":       # the score heads op by op (~30 autograd nodes) instead of heads_fused's one node
+        monkeypatch.setattr(dev_settings, "HEADS_COMPOSITE", False)
     from golden_utils import VaeGolden
     from ggpm_amd import synth
     from ggpm_amd.decoder import DecodeSchedule
@@ -1377,6 +1379,44 @@ def test_vae_step_matches_reference_golden(name, mode, monkeypatch):
     for k, v in model.named_parameters():
         grad = v.grad.cpu().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
         g.check_grad(k, grad, rel=TOL)
+
+
+@pytest.mark.parametrize("name", ["vae_gru_s40", "vae_gru_s42", "vae_lstm_s43"])
+def test_heads_composite_equals_the_op_by_op_heads(name, monkeypatch):
+    """ggpm_amd/heads_fused.py issues the launches of the four score heads, their losses and accuracies
+    (decoder_heads.ScoreHeads + HierMPNDecoder._losses: ~30 autograd nodes) from ONE autograd node -- the same library calls on
+    the same operands: the loss, the four accuracies and the gradient of every parameter OF THE HEADS must be bit-identical
+    to the op-by-op path; everything upstream receives the same gradient up to the order in which the three context scatters
+    are added into d(latent vector) (autograd adds them as its nodes finish): 1e-6 norm-wise.  Fixtures with tied embeddings
+    and latent != hidden included."""
+    from golden_utils import VaeGolden
+    from ggpm_amd import _dev as dev_settings, synth
+    from ggpm_amd.decoder import DecodeSchedule
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    g = VaeGolden(name)
+    specs = g.specs()
+    tensors = synth.tensorize(specs)
+    res = []
+    for composite in (True, False):
+        monkeypatch.setattr(dev_settings, "HEADS_COMPOSITE", composite)
+        model = HierPropertyVAE(g.args(IndexPairVocab(g.n_motif, g.n_attach))).to(_dev())
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()}, strict=False)
+        sch = DecodeSchedule.from_specs(specs, tensors)
+        loss, metrics = model(None, None, tensors, [None] * g.B, None, None, beta=g.beta, perturb_z=False, schedule=sch)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), [metrics[k] for k in ("Word", "I-Word", "Topo", "Assm")],
+                    {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert set(res[0][2]) == set(res[1][2])
+    own = ("decoder.topoNN.", "decoder.clsNN.", "decoder.iclsNN.", "decoder.matchNN.", "decoder.W_assm.")
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        if k.startswith(own):
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30), k
 
 
 @pytest.mark.parametrize("name", ["vae_gru_s42", "vae_lstm_s43"])
