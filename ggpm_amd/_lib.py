@@ -57,8 +57,6 @@ SIGNATURES = {
                                      P, I, P, I, P, P, I, P, c_size_t, P]),
     "ggpm_backward_defer_stash": (None, [P, P, P, P]),
     "ggpm_level_prefer_narrow": (None, [I]),
-    "ggpm_level_dataflow": (I, [I]),
-    "ggpm_dataflow_stamps": (I, [P, I, I]),
     "ggpm_forward_gather_state": (None, [P, P, P]),
     "ggpm_backward_scatter_state": (None, [P, P, P]),
     "ggpm_weights_packed": (None, [I]),

@@ -137,12 +137,6 @@ struct GruFwdArgs {
     float* Hout;                   // bf16 storage only: where the LAST depth also writes h' in fp32 (the level's result)
     const float* src_h;            // kernel B of a sparse forward's q^0 launch (ggpm_forward_gather_state): row r of the
     const int32_t* src_idx;        // start state is src_h[src_idx[r]] (zero when < 0); the launch writes it to Hnew itself
-    // dataflow form (gru_fwd_a<..., DF = true>; tile_mma.h "tile-level hand-off"): per-row-tile epoch words, the range of
-    unsigned* df_flags;            // tiles each tile gathers from ([2 * tile] = lo, [2 * tile + 1] = hi; lo > hi: none),
-    const int* df_dep;             // the epoch this launch waits for (0: nothing to wait for) and the one it publishes
-    unsigned df_need, df_pub;
-    unsigned* df_tmo;              // set to tile + 1 by a wait that gave up
-    unsigned long long* df_dbg;    // optional stamps of every workgroup (100 MHz wall clock): [tile][4] = start, wait over, gather over, end
 };
 
 __global__ void pad_bias(const float* __restrict__ b, int H, int Hp, float* __restrict__ out) {
@@ -156,12 +150,11 @@ __device__ __forceinline__ float4 one_minus(float4 r) { return make_float4(1.f -
 // Kernel A (16 waves): every wave gathers one message row at a time (full Hp width: two 256-column sweeps
 // and 4 predecessor rows in flight -> 16 independent 16-byte loads per lane), then the first `tg` waves run
 // the gate GEMMs of their output tile and the gate math.
-template <bool STASH, int GM, int RTT, bool ST16 = false, bool DF = false>
+template <bool STASH, int GM, int RTT, bool ST16 = false>
 __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
     constexpr int ROWS = RTT * 16;
     constexpr bool BF16 = GM == 1, SPLIT = GM == 2;
     static_assert(!SPLIT || RTT == 1, "split operands: one row tile per workgroup");
-    static_assert(!DF || (STASH && RTT == 1 && !ST16), "dataflow form: dense training levels, one row tile, fp32 storage");
     static_assert(!ST16 || GM == 1, "bf16 storage goes with bf16 gate products");      // Hs, Qs, S, G, Z, M in bf16 (tile_mma.h)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Hp = a.Hp, LD = Hp + 4, KC = Hp / 16, NT = Hp / 16;
@@ -183,21 +176,6 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
     if (dbg_on) a.dbg[0] = wall_clock64();
     const bool dbg15 = a.dbg && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 15 * 64;
     if (dbg15) a.dbg[5] = wall_clock64();
-
-    // dataflow form: the rows this workgroup gathers were written by the launch of the previous depth, which may still be
-    // running on the other queue -- wait for the owners of exactly those tiles, then read their rows past the L1 (sc1)
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsH = ggpm_rsrc(a.Hprev, DF && a.Hprev ? (unsigned)a.E1 * Hp * 4u : 0u);
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsQ = ggpm_rsrc(a.Qprev, DF && a.Qprev ? (unsigned)a.E1 * Hp * 4u : 0u);
-    if constexpr (DF) {
-        if (a.df_dbg && threadIdx.x == 0) a.df_dbg[4 * blockIdx.x] = wall_clock64();
-        if (a.df_need) {
-            if (wave == 0)
-                ggpm_df_wait(a.df_flags, a.df_dep[2 * blockIdx.x], a.df_dep[2 * blockIdx.x + 1], a.df_need, lane, a.df_tmo,
-                             blockIdx.x, 2000000ull /* 20 ms */);
-            __syncthreads();
-        }
-        if (a.df_dbg && threadIdx.x == 0) a.df_dbg[4 * blockIdx.x + 1] = wall_clock64();
-    }
 
     // ---- P1: gather
     for (int lr = wave; lr < ROWS; lr += GGPM_NWA) {
@@ -228,13 +206,8 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
                         const size_t p = (size_t)ggpm_list_at(chunk, j + u, m) * Hp;
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            if constexpr (DF) {
-                                h[u][k] = ggpm_ld4_sc1(rsH, (unsigned)(p + cs[k]) * 4u);
-                                q[u][k] = ggpm_ld4_sc1(rsQ, (unsigned)(p + cs[k]) * 4u);
-                            } else {
-                                h[u][k] = ggpm_ldx<ST16>(a.Hprev, p + cs[k]);
-                                q[u][k] = ggpm_ldx<ST16>(a.Qprev, p + cs[k]);
-                            }
+                            h[u][k] = ggpm_ldx<ST16>(a.Hprev, p + cs[k]);
+                            q[u][k] = ggpm_ldx<ST16>(a.Qprev, p + cs[k]);
                         }
                     }
 #pragma unroll
@@ -284,12 +257,9 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
         if (p2_gemm && t < t_end) ggpm_split_ring_prefetch<2>(wps2, KC32, t, lane, sring2);
     ggpm_lds_barrier();      // LDS tiles only: the stash stores above finish under the GEMM
     if (dbg_on) a.dbg[2] = wall_clock64();
-    if constexpr (DF) if (a.df_dbg && threadIdx.x == 0) a.df_dbg[4 * blockIdx.x + 2] = wall_clock64();
 
     // ---- P2: gate GEMMs + gate math for this wave's tiles (wave, wave+16, ... inside the column group)
     const int lr = lane & 15;
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsHn = ggpm_rsrc(a.Hnew, DF ? (unsigned)a.E1 * Hp * 4u : 0u);
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsQn = ggpm_rsrc(a.Qnew, DF && a.Qnew ? (unsigned)a.E1 * Hp * 4u : 0u);
     for (int tt = t; tt < t_end; tt += GGPM_NWA) {
         const int c = 16 * tt + 4 * (lane >> 4);
         float4 xz[RTT], xh[RTT];
@@ -341,8 +311,7 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
                                 (1.f - z.z) * s.z + z.z * m.z, (1.f - z.w) * s.w + z.w * m.w);
                 if constexpr (ST16) h = ggpm_rne4(h);
             }
-            if constexpr (DF) ggpm_st4_sc1(rsHn, (unsigned)o * 4u, h);    // (write-through: the next depth's launch reads it now)
-            else ggpm_stx<ST16>(a.Hnew, o, h);
+            ggpm_stx<ST16>(a.Hnew, o, h);
             if constexpr (ST16) if (a.Hout) ggpm_st4(a.Hout + o, h);      // the level's result (last depth) also in fp32
             if (a.fuse_b) keep_h(h);
             if (STASH) {
@@ -352,17 +321,7 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
         }
     }
     if (dbg_on) a.dbg[4] = wall_clock64();
-    auto publish = [&]() {      // dataflow form: every storing wave drains, the workgroup meets, ONE lane stores the tile's epoch word
-        if constexpr (DF) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(a.df_flags + blockIdx.x, a.df_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.df_dbg) a.df_dbg[4 * blockIdx.x + 3] = wall_clock64();
-            }
-        }
-    };
-    if (!a.fuse_b) { publish(); return; }
+    if (!a.fuse_b) return;
 
     // ---- P3 (single column group, RTT = 1 only): the workgroup holds the complete h' rows -> q' = U_r h' + b_u
     if constexpr (RTT == 1) {
@@ -388,32 +347,9 @@ __global__ void GGPM_A_BOUNDS gru_fwd_a(GruFwdArgs a) {
                 ggpm_wave_gemm_split<1>(imgs, PLANE, LDH, wps3, KC32, tt, tn, lane, acc, sring3);
             } else if constexpr (BF16) ggpm_wave_gemm_bf16<1, 1>(tiles, LD, wps3, Hp, tt, lane, acc);
             else ggpm_wave_gemm_ring<1, 1>(tiles, LD, wps3, KC, tt, tn, lane, acc, ring3);
-            if (row < a.E1) {
-                if constexpr (DF) ggpm_st4_sc1(rsQn, (unsigned)((size_t)row * Hp + c) * 4u, ggpm_f4(acc[0][0]) + b);
-                else ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
-            }
+            if (row < a.E1) ggpm_stx<ST16>(a.Qnew, (size_t)row * Hp + c, ggpm_f4(acc[0][0]) + b);
         }
     }
-    publish();
-}
-
-// per row tile: the range of tiles its rows gather from (one wave per tile; the CSR is depth invariant)
-__global__ void df_dep_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int E1, int* __restrict__ dep) {
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    const int r_lo = tile * 16, r_hi = min(E1, r_lo + 16);
-    int lo = 0x7fffffff, hi = -1;
-    if (r_lo < E1) {
-        const int b = rowptr[r_lo], e = rowptr[r_hi];
-        for (int i = b + lane; i < e; i += 64) {
-            const int p = col[i];
-            if (p > 0) { lo = min(lo, p >> 4); hi = max(hi, p >> 4); }
-        }
-    }
-    for (int off = 32; off; off >>= 1) {
-        lo = min(lo, __shfl_xor(lo, off));
-        hi = max(hi, __shfl_xor(hi, off));
-    }
-    if (lane == 0) { dep[2 * tile] = hi < 0 ? 1 : lo; dep[2 * tile + 1] = hi < 0 ? 0 : hi; }
 }
 
 // Kernel B (same geometry as A): q' = U_r h' + b_u (h' rows come back from L2).
@@ -865,13 +801,6 @@ inline int gate_mode(int dtype, int Hp, bool rt2, bool single_group, bool sparse
 }
 inline bool single_group(int E1, int Hp) { return pick_tg(E1, Hp / 16) >= Hp / 16; }
 
-// would launch_fwd take the fused single-column-group split-operand form for this level (the only form with a dataflow variant)?
-inline bool fwd_dataflow_form(int E1, int Hp, int tg, int gm) {
-    const int NT = Hp / 16;
-    const size_t tile_b = (size_t)16 * (Hp + 4) * sizeof(float), img_b = ggpm_split_image_bytes(16, Hp);
-    return gm == 2 && !use_rt2(E1, Hp, false) && ggpm_ceil_div(NT, tg) == 1 && tile_b + 3 * img_b <= 160 * 1024 && !env_no_fuse_b();
-}
-
 void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_t s) {
     const int Hp = a.Hp, NT = Hp / 16;
     const bool rt2 = use_rt2(a.E1, Hp, a.frozen != nullptr);
@@ -896,13 +825,6 @@ void launch_fwd(GruFwdArgs a, bool stash, bool with_b, double flops1, hipStream_
         set_lds(kernel, lds_a);
         kernel<<<grid_a, GGPM_NWA * 64, lds_a, s>>>(a);
     };
-    if (a.df_flags) {      // dataflow form (gru_forward_impl decides; the fused split-operand training form only)
-        if (!(a.bf16 == 2 && stash && !rt2 && (a.fuse_b || !a.Qnew))) { (void)hipGetLastError(); return; }
-        a.fuse_b = a.Qnew ? 1 : 0;
-        go(gru_fwd_a<true, 2, 1, false, true>);
-        ggpm_timing_end(0, s);
-        return;
-    }
     if (a.st16) {      // (training levels only: always with stashes)
         if (rt2) go(gru_fwd_a<true, 1, 2, true>); else go(gru_fwd_a<true, 1, 1, true>);
     } else if (rt2) {
@@ -1057,81 +979,6 @@ bool ggpm_take_defer_stash(float* (&out)[4]) {
     return v;
 }
 
-// ---- dataflow form: per-thread state (a second queue, two events, the epoch words, the dependency table, the timeout word).
-// EXPERIMENT: the one place where the library owns device memory and a stream (the C ABI passes one stream and has no slot for
-// these); a product form would take them from the caller's workspace.  Epochs only grow (one counter per thread), so the
-// words are zeroed once, when they are allocated, and a stale word of an earlier call can never satisfy a wait.
-namespace {
-struct DfState {
-    hipStream_t aux = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    unsigned* flags = nullptr;
-    int* dep = nullptr;
-    unsigned* tmo = nullptr;
-    unsigned long long* dbg = nullptr;      // [DF_DBG_DEPTHS][tiles][4] stamps (ggpm_level_dataflow(2))
-    int tiles = 0, device = -1;
-    unsigned epoch = 1;
-};
-constexpr int DF_DBG_DEPTHS = 32;
-thread_local int g_dataflow = -1;      // ggpm_level_dataflow: -1 = the dev build's GGPM_DATAFLOW, 0 off, 1 on
-inline bool dataflow_enabled() {
-    if (g_dataflow >= 0) return g_dataflow != 0;
-    static const bool v = ggpm_dev_env("GGPM_DATAFLOW") && atoi(ggpm_dev_env("GGPM_DATAFLOW")) != 0;
-    return v;
-}
-DfState* df_state(int tiles) {
-    static thread_local DfState st;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (st.device != dev || st.tiles < tiles) {
-        if (st.flags) { (void)hipFree(st.flags); st.flags = nullptr; }
-        if (st.dbg) { (void)hipFree(st.dbg); st.dbg = nullptr; }
-        const int cap = tiles < 4096 ? 4096 : 2 * tiles;
-        if (hipMalloc(&st.dbg, (size_t)DF_DBG_DEPTHS * cap * 4 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); st.dbg = nullptr; }
-        else (void)hipMemset(st.dbg, 0, (size_t)DF_DBG_DEPTHS * cap * 4 * sizeof(unsigned long long));
-        if (hipMalloc(&st.flags, (size_t)cap * 12 + 64) != hipSuccess) { (void)hipGetLastError(); st.tiles = 0; return nullptr; }
-        (void)hipMemset(st.flags, 0, (size_t)cap * 12 + 64);
-        st.dep = reinterpret_cast<int*>(st.flags + cap);
-        st.tmo = st.flags + 3 * (size_t)cap;
-        st.tiles = cap;
-        if (st.device != dev) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (hipStreamCreateWithFlags(&st.aux, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            for (int i = 0; i < 2; ++i)
-                if (hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        }
-        st.device = dev;
-    }
-    return st.aux ? &st : nullptr;
-}
-}  // namespace
-// 1 / 0: the dense training level calls of this thread use / do not use the dataflow form where it applies; -1: default.  -> the
-// timeout word of this thread's state (tile + 1 of a wait that gave up since the last call; 0: none), read with a device sync.
-namespace { thread_local bool g_df_stamps = false; }
-// dev: copies the stamps of the last dataflow level forward of this thread -- [depths][tiles][4] ticks of the 100 MHz wall clock
-// (workgroup start, wait over, gather over, tile published) -- into `out` (depths * tiles * 4 entries; depths <= 32)
-extern "C" int ggpm_dataflow_stamps(unsigned long long* out, int depths, int tiles) {
-    DfState* st = df_state(1);
-    if (!st || !st->dbg || !out || depths > DF_DBG_DEPTHS || tiles > st->tiles) return GGPM_ERR_ARG;
-    (void)hipDeviceSynchronize();
-    for (int d = 0; d < depths; ++d)
-        if (hipMemcpy(out + (size_t)d * tiles * 4, st->dbg + (size_t)d * st->tiles * 4, (size_t)tiles * 4 * sizeof(unsigned long long),
-                      hipMemcpyDeviceToHost) != hipSuccess) return GGPM_ERR_LAUNCH;
-    return GGPM_OK;
-}
-extern "C" int ggpm_level_dataflow(int on) {
-    g_dataflow = on < 0 ? -1 : (on ? 1 : 0);
-    g_df_stamps = on == 2;
-    DfState* st = df_state(1);
-    if (!st) return -1;
-    unsigned v = 0;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&v, st->tmo, 4, hipMemcpyDeviceToHost);
-    (void)hipMemset(st->tmo, 0, 4);
-    return (int)v;
-}
-
 static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const float* Xr, const float* Xh,
                             const float* Wz_h, int ld_wz, const float* Ur, int ld_ur, const float* bu,
                             const float* Wh_h, int ld_wh, const int32_t* pred_rowptr, const int32_t* pred_col,
@@ -1185,21 +1032,6 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
     const bool st16 = bf16 == 1 && !frozen && save_for_backward && ggpm_bf16_storage_applies(E1, H);
     int run_depth = ggpm_take_run_depth();
     if (run_depth <= 0 || run_depth > depth || frozen || !save_for_backward) run_depth = depth;
-    // ---- dataflow form (experiment): consecutive depth launches on two queues, tile-level hand-off instead of the
-    // kernel boundary.  Dense training levels in the fused split-operand form (the atom level) only.
-    DfState* df = nullptr;
-    if (dataflow_enabled() && !frozen && save_for_backward && !st16 && run_depth >= 3 && fwd_dataflow_form(E1, Hp, tg, bf16))
-        df = df_state(ggpm_ceil_div(E1, 16));
-    hipStream_t s2 = s;
-    unsigned df_base = 0;
-    if (df) {
-        s2 = df->aux;
-        df_base = df->epoch;
-        df->epoch += (unsigned)depth + 2u;
-        df_dep_kernel<<<ggpm_ceil_div(E1, 16), 64, 0, s>>>(pred_rowptr, pred_col, E1, df->dep);
-        (void)hipEventRecord(df->ev[0], s);                    // packed weights, dep table, gate inputs: ready from here on
-        (void)hipStreamWaitEvent(s2, df->ev[0], 0);
-    }
     for (int t = 1; t <= run_depth; ++t) {
         GruFwdArgs a = {};
         a.E1 = E1; a.Hp = Hp; a.tg = tg; a.Xz = Xz; a.Xr = Xr; a.Xh = Xh;
@@ -1222,17 +1054,7 @@ static int gru_forward_impl(int E1, int H, int depth, const float* Xz, const flo
             a.Qprev = Qs + (size_t)((t - 1) & 1) * slot; a.Qnew = Qs + (size_t)(t & 1) * slot;
             a.S = a.G = a.Z = a.M = a.R = nullptr;
         }
-        if (df) {
-            a.df_flags = df->flags; a.df_dep = df->dep; a.df_tmo = df->tmo;
-            a.df_need = t > 1 ? df_base + (unsigned)(t - 1) : 0u;      // (the first depth starts from h^0 = 0: nothing to wait for)
-            a.df_pub = df_base + (unsigned)t;
-            a.df_dbg = (g_df_stamps && df->dbg && t <= DF_DBG_DEPTHS) ? df->dbg + (size_t)(t - 1) * df->tiles * 4 : nullptr;
-        }
-        launch_fwd(a, save_for_backward != 0, t < depth, flops1, (df && (t & 1) == 0) ? s2 : s);
-    }
-    if (df) {      // whatever follows on the caller's stream follows BOTH queues
-        (void)hipEventRecord(df->ev[1], s2);
-        (void)hipStreamWaitEvent(s, df->ev[1], 0);
+        launch_fwd(a, save_for_backward != 0, t < depth, flops1, s);
     }
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;

@@ -398,7 +398,11 @@ __device__ __forceinline__ void ggpm_wave_gemm_split(const __bf16* const (&imgs)
                                                      int lane, f32x4 (&acc)[NOPS][1], GgpmSplitRing<NOPS>& ring) {
     constexpr int PF = GgpmSplitPf<NOPS>::value;
     constexpr int NACC = SUM ? 1 : NOPS;
+#ifdef GGPM_ABL_LDS_BROADCAST      // timing ablation (wrong results): every lane reads row 0 of the image -- one address per 16-lane
+    const int boff = 8 * (lane >> 4);      // group, no bank conflict possible: what the measured 46 % conflict ratio costs
+#else
     const int boff = (lane & 15) * LDH + 8 * (lane >> 4);
+#endif
     const bool chain = t_next >= 0 && (KC32 % PF) == 0;
     const __bf16* wp[NOPS];
     const __bf16* wn[NOPS];
@@ -437,12 +441,16 @@ __device__ __forceinline__ void ggpm_wave_gemm_split(const __bf16* const (&imgs)
                     lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][0], b[1], lo_, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot
+#ifndef GGPM_ABL_NOLOAD            // (timing / traffic ablation: no weight-plane refills -- the ring keeps its first chunks)
 #pragma unroll
                 for (int o = 0; o < NOPS; ++o)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
                         ring.r[d][o][p] = *reinterpret_cast<const bf16x8*>((over && chain ? wn[o] : wp[o]) +
                                                                            ((size_t)kn * 3 + p) * 512);
+#else
+                (void)kn; (void)over;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -505,54 +513,6 @@ static inline float* ggpm_slot_ptr(float* base, size_t t, size_t slot, bool b16)
 }
 static inline const float* ggpm_slot_ptr(const float* base, size_t t, size_t slot, bool b16) {
     return b16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(base) + t * slot) : base + t * slot;
-}
-
-// ---- tile-level hand-off between CONSECUTIVE LAUNCHES of a depth loop ("dataflow" form; mpn_gru.hip: gru_fwd_a<..., DF>) ----------
-// Depth t + 1 is launched on a second queue WITHOUT a kernel boundary behind depth t: a workgroup of t + 1 waits, per row
-// tile, for the epoch word that the depth-t owner of every tile it gathers from publishes behind its h' / q' rows.
-// MI355X_MICROARCH.md "inter-workgroup visibility", the sc1 row of the table: every handed-off byte is stored write-through
-// (buffer_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's barrier, ONE lane then stores
-// the tile's word (sc1); the consumer polls with sc1 loads from ONE wave, joins a workgroup barrier, and EVERY load of the
-// handed-off rows is a buffer_load ... sc1 to registers.  Row tiles of 16 rows are whole 128-byte lines only when the slot
-// base is 128-byte aligned; the launch code checks that (it is for every slot of an even depth index, see gru_forward_impl).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ggpm_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-typedef float ggpm_gf32x4 __attribute__((__vector_size__(16)));
-typedef unsigned ggpm_gu32x4 __attribute__((__vector_size__(16)));
-__device__ __forceinline__ float4 ggpm_ld4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    // (the builtin returns a GCC-style vector of unsigned: cast the WHOLE vector -- picking elements out of it with
-    // __builtin_bit_cast(float, v[i]) compiled to a ONE-dword load used for all four components, hipcc of ROCm 7.2)
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);      // aux 16 = sc1
-    const ggpm_gf32x4 f = __builtin_bit_cast(ggpm_gf32x4, v);
-    return make_float4(f[0], f[1], f[2], f[3]);
-}
-__device__ __forceinline__ void ggpm_st4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 x) {
-    const ggpm_gf32x4 f = {x.x, x.y, x.z, x.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ggpm_gu32x4, f), r, (int)byte_off, 0, 16);
-}
-// ONE wave waits until flags[0] (the tile of the all-zero row every null slot reads) and flags[lo..hi] have reached `need`
-// (epochs only grow: a thread's calls draw them from one counter).  BOUNDED: after `limit` ticks of the 100 MHz wall clock the
-// wave stores its tile number + 1 into *tmo and goes on (the launch then finishes with wrong rows instead of hanging; the
-// host reads the word back: GGPM_ERR_LAUNCH).  -> true when every word was seen.
-__device__ __forceinline__ bool ggpm_df_wait(const unsigned* flags, int lo, int hi, unsigned need, int lane, unsigned* tmo,
-                                             unsigned tile, unsigned long long limit) {
-    const unsigned long long t0 = wall_clock64();
-    for (int base = lo - 1; base <= hi; base += 64) {          // index lo - 1 stands for tile 0
-        const int i = base + lane;
-        const bool active = i <= hi;
-        const unsigned* w = flags + (i < lo ? 0 : i);
-        for (;;) {
-            const unsigned v = active ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-            if (__all((int)(v - need) >= 0)) break;
-            if (wall_clock64() - t0 > limit) {
-                if (lane == 0) __hip_atomic_store(tmo, tile + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    return true;
 }
 
 // ---- CSR row walk helpers for the gather phases -------------------------------------------------------

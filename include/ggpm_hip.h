@@ -331,19 +331,6 @@ void ggpm_backward_defer_stash(float* s0, float* s1, float* s2, float* s3);
  * level that runs BESIDE a latency-bound chain on another stream -- the encoder next to the decoder's atom level in the
  * full VAE step (ggpm/property_vae.py:47-58 runs them one after the other) -- this leaves the chain's launches free CUs. */
 void ggpm_level_prefer_narrow(int yes);
-/* EXPERIMENT (off by default): ggpm_level_dataflow(1) -- until switched off again (0; -1: the build's default), the
- * dense TRAINING GRU level forwards of this thread that run the fused single-column-group split-operand form (the atom level)
- * issue consecutive depth steps of GRU.forward's loop (ggpm/rnn.py:41-50) alternately on the caller's stream and on a second
- * queue of the library, with a per-row-tile epoch word in place of the kernel boundary: depth t + 1 gathers a tile's
- * predecessor rows as soon as THEIR owners of depth t have published them (write-through stores, bounded waits).  Results
- * are bit-identical to the default form.  Returns the timeout word of the calling thread's state (0: no wait has given up
- * since the previous call; otherwise tile + 1), read back with a device synchronisation, and clears it; -1: no state. */
-int ggpm_level_dataflow(int on);
-/* dev instrumentation of the experiment: after ggpm_level_dataflow(2) every workgroup of a dataflow level forward stamps the
- * 100 MHz wall clock at its start, after its wait, after its gather and when it has published its tile; this copies the stamps
- * of the calling thread's last such forward, [depths][tiles][4], to host memory (tools/probe/dataflow_ab.py prints the
- * per-tile wait histogram from them). */
-int ggpm_dataflow_stamps(unsigned long long* out, int depths, int tiles);
 void ggpm_forward_gather_state(const float* src_h, const float* src_c, const int32_t* idx);
 void ggpm_backward_scatter_state(float* dst_h, float* dst_c, const int32_t* idx);
 size_t ggpm_weight_grads_stacked_workspace_bytes(int H, int rows);
