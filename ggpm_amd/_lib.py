@@ -93,6 +93,7 @@ SIGNATURES = {
     "ggpm_tree_level_work_bytes": (c_size_t, [P]),
     "ggpm_tree_level_forward": (I, [P, P, c_size_t, P, P]),
     "ggpm_tree_level_backward": (I, [P, P, P, P, P, P, c_size_t, P, P]),
+    "ggpm_linear_wgrads_batch": (I, [I, P, P, c_size_t, P, P]),
     "ggpm_timing_enable": (I, [I]),
     "ggpm_timing_collect": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     # host-only decode schedule (csrc/schedule.hip): in: ggpm_sched_in*

@@ -1555,3 +1555,31 @@ extern "C" int ggpm_act_backward(const float* dy, const float* y, int rows, int 
     GGPM_CHECK_LAUNCH();
     return GGPM_OK;
 }
+
+// ---- a batch of Linear weight gradients in ONE call ----------------------------------------------------------------------------
+// Item i:  dW_i[N x K] = dpre_i[M x N]^T x_i[M x K]  (ggpm_gemm(1, 0, N, K, M, ...) with split-K over the M rows where it pays)
+// and, when `db` is given, db_i[N] = column sums of dpre_i -- what autograd's mm / sum backward of a Linear computes
+// (ggpm/decoder.py:35-58's heads, ggpm/encoder.py:15-19,62-72's read-outs) and what ggpm_amd/functional.py::_defer_flush used to
+// issue as ~60 separate ctypes calls per backward pass (10-15 us of host time each).  Same launches, same order, same results;
+// `ws` (ws_bytes >= the largest ggpm_gemm_workspace_bytes(N, K, M) of the batch, may be 0 / NULL: no split-K) and `csws`
+// (256 * max N floats) are shared by the items, which run one after the other on `stream`.
+extern "C" int ggpm_linear_wgrads_batch(int count, const ggpm_wgrad_item* items, float* ws, size_t ws_bytes, float* csws,
+                                        ggpm_stream_t stream) {
+    if (count < 0 || (count > 0 && !items)) return GGPM_ERR_ARG;
+    for (int i = 0; i < count; ++i) {
+        const ggpm_wgrad_item& it = items[i];
+        if (!it.dpre || !it.x || !it.dW || it.M <= 0 || it.N <= 0 || it.K <= 0) return GGPM_ERR_ARG;
+        const size_t need = ggpm_gemm_workspace_bytes(it.N, it.K, it.M);
+        const bool split = ws && need && need <= ws_bytes;
+        int rc = ggpm_gemm(1, 0, it.N, it.K, it.M, it.dpre, it.ld_dpre, it.x, it.ld_x, it.dW, it.ld_dw, it.K, nullptr, 0, GGPM_ACT_NONE, 0,
+                           split ? ws : nullptr, split ? ws_bytes : 0, stream);
+        if (rc) return rc;
+        if (it.db) {
+            if (!csws) return GGPM_ERR_ARG;
+            rc = ggpm_colsum(it.dpre, it.ld_dpre, it.M, it.N, it.db, csws, stream);
+            if (rc) return rc;
+        }
+    }
+    return GGPM_OK;
+}
+

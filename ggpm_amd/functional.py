@@ -228,6 +228,13 @@ def gemm(ta: int, tb: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B:
                              int(accumulate), act, int(zero_row0), _p(ws), wsb, _stream()), "gemm")
 
 
+class WgradItem(ctypes.Structure):
+    """include/ggpm_hip.h: ggpm_wgrad_item"""
+    _fields_ = [("dpre", ctypes.c_void_p), ("ld_dpre", ctypes.c_int), ("x", ctypes.c_void_p), ("ld_x", ctypes.c_int),
+                ("dW", ctypes.c_void_p), ("ld_dw", ctypes.c_int), ("db", ctypes.c_void_p), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("K", ctypes.c_int)]
+
+
 class GemmProblem(ctypes.Structure):
     """include/ggpm_hip.h: ggpm_gemm_problem"""
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int),
@@ -707,7 +714,23 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
         else:
             _add_to_grad(param, g)
 
+    def target(param):
+        """Where a parameter's gradient is formed: its slice of the flat gradient buffer (parallel.FlatGradSync) when it has one
+        and nothing has been written there in this pass -- the optimizer / all-reduce side then finds it in place (no pack copy:
+        one multi-tensor launch right in front of the optimizer, and ~35 `.grad` re-pointings, less per step) -- else a fresh
+        tensor.  The first contribution of a pass writes, later ones are added (`_add_to_grad`)."""
+        v = getattr(param, "_ggpm_grad_view", None)
+        if v is not None and param.grad is None and id(param) not in taken:
+            taken.add(id(param))
+            return v
+        return torch.empty_like(param)
+
+    taken = set(id(q) for q, _ in _DEFER["pending"])
     with torch.cuda.stream(stream):
+        # every Linear's weight gradient (one contraction per K segment) and bias gradient in ONE library call
+        # (ggpm_linear_wgrads_batch: the same launches in the same order as ~60 separate gemm / colsum calls)
+        items, keep, n_max, ws_max = [], [], 0, 0
+        lib = _lib.load()
         for weight, bias, Ks, visits in lin.values():
             N = weight.shape[0]
             if len(visits) == 1:
@@ -716,21 +739,33 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
                 dpre = torch.cat([use(v[0]) for v in visits], dim=0)
                 xs = [torch.cat([use(v[1][i])[:, :K] for v in visits], dim=0) for i, K in enumerate(Ks)]
             M = dpre.shape[0]
-            dW = torch.empty_like(weight)
+            dW = target(weight)
+            db = target(bias) if bias is not None else None
             o = 0
-            for x, K in zip(xs, Ks):
-                gemm(1, 0, N, K, M, dpre, _ld(dpre), x, _ld(x), dW[:, o:], dW.stride(0), K, splitk=True)
+            for i, (x, K) in enumerate(zip(xs, Ks)):
+                items.append((dpre.data_ptr(), _ld(dpre), x.data_ptr(), _ld(x), dW.data_ptr() + 4 * o, dW.stride(0),
+                              db.data_ptr() if (db is not None and i == 0) else 0, M, N, K))
+                ws_max = max(ws_max, int(lib.ggpm_gemm_workspace_bytes(N, K, M)))
                 o += K
+            n_max = max(n_max, N)
+            keep.append((dpre, xs, dW, db))
             publish(weight, dW)
-            if bias is not None:
-                publish(bias, colsum(dpre, M, N))
+            if db is not None:
+                publish(bias, db)
+        if items:
+            arr = (WgradItem * len(items))(*[WgradItem(*it) for it in items])
+            dev = keep[0][0].device
+            ws = torch.empty(ws_max // 4, dtype=torch.float32, device=dev) if ws_max else None
+            csws = torch.empty(256 * n_max, dtype=torch.float32, device=dev)
+            _lib.check(lib.ggpm_linear_wgrads_batch(len(items), ctypes.cast(arr, ctypes.c_void_p), _p(ws), ws_max, _p(csws),
+                                                    _stream()), "linear_wgrads_batch")
         for param, grads in sums.values():
             publish(param, use(grads[0]) if len(grads) == 1 else torch.stack([use(g) for g in grads], dim=0).sum(dim=0))
         for table, width, visits in gath.values():       # embedding tables: d(table)[id] = sum of the rows that used id
             dout = use(visits[0][0]) if len(visits) == 1 else torch.cat([use(v[0]) for v in visits], dim=0)
             idx = use(visits[0][1]) if len(visits) == 1 else torch.cat([use(v[1]).reshape(-1) for v in visits], dim=0)
             csrT = csr_from_index(idx.reshape(-1), ncols=table.shape[0]).T
-            dtable = torch.empty(table.shape, dtype=torch.float32, device=dout.device)
+            dtable = target(table)
             _segment_sum_raw(dout, csrT, width, dtable)
             publish(table, dtable)
 

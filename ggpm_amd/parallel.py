@@ -93,6 +93,15 @@ class FlatGradSync:
         # there and ggpm_amd.optim.FlatAdam reads it as the gradient of its single flat parameter
         self.keep_flat = keep_flat
         self._early_work = None
+        if self.active():
+            # gradients this package forms itself (functional._defer_flush) are written straight into their slice of the
+            # buffer: pack() then has nothing to copy for them
+            # (not the encoder's: the C++ backward driver OVERWRITES its slices -- a tied embedding's decoder-side contribution
+            # must be ADDED behind it, which the fresh-tensor path does)
+            enc = set(id(p) for p in self.encoder_params)
+            for p, v in zip(self.params, self.views):
+                if id(p) not in enc:
+                    p._ggpm_grad_view = v
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"             # RCCL averages in the collective; gloo sums, then one division
 

@@ -119,6 +119,21 @@ int ggpm_gemm_tn_bf16(int M, int N, int K, const float* A, int lda, const float*
                       size_t ws_bytes, ggpm_stream_t stream);
 /* 1 when a contraction of this shape runs on bf16 operands (host-only query; 16-byte aligned operands assumed). */
 int ggpm_gemm_tn_bf16_applies(int M, int N, int K);
+/* A batch of Linear weight gradients in one call: item i forms dW_i[N x K] = dpre_i[M x N]^T x_i[M x K] (ggpm_gemm(1, 0, N, K, M,
+ * ...), split-K over the M rows through `ws` where that pays) and, when `db` is not NULL, db_i[N] = column sums of dpre_i -- autograd's
+ * mm / sum backward of a Linear (the score heads of ggpm/decoder.py:35-58, the read-outs of ggpm/encoder.py:15-19,62-72), which the
+ * deferred-gradient queue of ggpm_amd/functional.py forms once per parameter and pass.  The items run one after the other on
+ * `stream` and share `ws` (>= the largest ggpm_gemm_workspace_bytes(N, K, M); NULL / 0: no split-K) and `csws` (256 * max N
+ * floats).  Same launches and results as the separate calls. */
+typedef struct ggpm_wgrad_item {
+    const float* dpre; int ld_dpre;
+    const float* x; int ld_x;
+    float* dW; int ld_dw;
+    float* db;
+    int M, N, K;
+} ggpm_wgrad_item;
+int ggpm_linear_wgrads_batch(int count, const ggpm_wgrad_item* items, float* ws, size_t ws_bytes, float* csws,
+                             ggpm_stream_t stream);
 /* out[n] = sum_m A[m*lda+n] (bias gradients), deterministic two-stage; ws >= 256*N floats. */
 int ggpm_colsum(const float* A, int lda, int M, int N, float* out, float* ws, ggpm_stream_t stream);
 /* dpre = dy * act'(y) given the activation OUTPUT y; optional row-0 zeroing. In-place allowed. */
