@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ on a GPU box (run from the repo root through gpurun; writes gpurun_out/<tag>/).
-#   bash tools/make_profiles.sh r04p
+#   bash tools/make_profiles.sh r05p
 # rocprofv3 runs the program itself (python3 bench.py ...), never through env / bash -c; PMC passes are separate runs.
 set -u
-TAG=${1:-r04p}
+TAG=${1:-r05p}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
