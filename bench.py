@@ -489,8 +489,12 @@ class Workload:
         try:      # HBM bytes per ATOM-LEVEL launch from the committed rocprofv3 --pmc passes of this same command
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 tj = json.load(f)
-            if self.cfg is CONFIGS.get(1) or all(self.cfg[k] == CONFIGS[1][k] for k in ("hidden", "depth", "batch", "gen")):
+            same = lambda n: all(self.cfg[k] == CONFIGS[n][k] for k in ("hidden", "depth", "batch", "gen"))
+            if same(1) and self.gate_dtype != "bf16":
                 traffic = tj.get(self.rnn + "_atom_level", {}).get(kname, {}).get("bytes_per_launch")
+            elif same(4) and self.rnn == "GRU":
+                key = "configs4_%s_atom_level" % ("bf16" if self.gate_dtype == "bf16" else "f32")
+                traffic = tj.get(key, {}).get(kname, {}).get("bytes_per_launch")
         except Exception:
             pass
         tree = {lv: per[lv][kname] for lv in ("attachment", "motif") if kname in per.get(lv, {})}
@@ -792,7 +796,7 @@ class VaeWorkload:
                                           "step k; make_cuda and the two table uploads stay in the step"},
                "steps": steps, "warmup": warm, "rnn_type": self.rnn, "n_gpus": self.world,
                "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                            "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": self._counter_traffic(),
                             "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
                             "algorithmic_gflop_per_step_per_gpu": round(fl_alg / 1e9, 2),
                             "note": "whole-step figure: executed flops (every row the kernels process; fwd + bwd = 3 x fwd) over "
@@ -814,6 +818,16 @@ class VaeWorkload:
         except Exception:
             pass
         return out
+
+    def _counter_traffic(self):
+        """Bytes per STEP at the L2 <-> fabric boundary from the committed FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-vae`
+        (profiles/pmc_traffic.json, tools/pmc_step_total.py; Infinity-Cache hits included).  Roughly half of it is the packed gate
+        weights: each of the step's ~700 small depth launches pulls them into eight L2s again (8 x 1.1 MB)."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                return json.load(f).get("vae_step_" + self.rnn, {}).get("bytes_per_step")
+        except Exception:
+            return None
 
     def cpu_baseline(self, budget_s=14.0):
         """The oracle's full VAE step (oracle/ref_decoder.py, reference op order) on the same batches."""
@@ -871,8 +885,9 @@ def configs4_leg(a, lib, dev, budget_s=90.0):
                                      "warmup_steps_run", "timed_regions_repeated", "timed_region") if k in m}
             r = m.get("roofline")
             if r:
-                leg["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
-                                                     "algorithmic_bytes_per_launch", "mfma") if k in r}
+                leg["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                     "algorithmic_bytes_per_launch", "stored_element_bytes", "depth_step_pairs",
+                                                     "regime", "mfma") if k in r}
                 leg["roofline"]["all_depth_kernels"] = {"atom": r.get("all_depth_kernels", {}).get("atom")}
             out[key] = leg
             del wl
