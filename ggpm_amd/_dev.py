@@ -13,7 +13,6 @@ DECODER_BATCHED = True     # tree-side levels as ONE level call each over the de
 ATOM_DECODE = True         # atom level as one autograd node on host-built index tables (False: through IncMPNEncoder per step)
 ATOM_COMPACT = True        # ... on the compact row set of every decode step (False: all rows of the level, frozen mask)
 ATOM_AHEAD = True          # ... issued on its own stream BEFORE the encoder, joined where the attachment level needs it
-SCHEDULE_BESIDE_ENCODER = True   # model(*batch): the decode schedule is built on a helper thread while the encoder is issued
 ATOM_PRIORITY = True       # ... on a high-priority stream
 DECODE_DRIVER = True       # the two step loops as one C call each (csrc/decode.hip; False: launches issued from Python)
 ATOM_ASYNC = True          # ... issued by a worker thread of the library (ggpm_decode_steps_*_async)

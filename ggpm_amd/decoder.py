@@ -614,11 +614,7 @@ class HierMPNDecoder(ScoreHeads):
     # overlaps the encoder's backward the same way.  _dev.ATOM_AHEAD = False switches it off.
     _ATOM_STREAMS = {}
 
-    def start_atom_level(self, schedule, tensors, ready=None) -> bool:
-        """``ready`` (an event recorded on the current stream once the batch's index tensors are on the device): the level's
-        stream waits for THAT instead of for everything the current stream has been given, and the schedule's tables are
-        uploaded on the level's stream -- for a caller that has already issued other work (the encoder) on the current stream
-        while the schedule was being built (HierPropertyVAE.forward, the vae_train.py call shape)."""
+    def start_atom_level(self, schedule, tensors) -> bool:
         self._atom_ahead = None
         if schedule is None or not (_dev.ATOM_AHEAD and _dev.ATOM_DECODE and _dev.DECODER_BATCHED):
             return False
@@ -629,6 +625,7 @@ class HierMPNDecoder(ScoreHeads):
         ap = schedule.atom_plan(graph_tensors[0].size(0), graph_tensors[1].size(0))
         if not ap.ok:
             return False
+        D = schedule.to_device(dev)._dev
         main = torch.cuda.current_stream(dev)
         side = self._ATOM_STREAMS.get(dev.index)
         if side is None:
@@ -636,18 +633,7 @@ class HierMPNDecoder(ScoreHeads):
             # has slack -- where both have a kernel waiting for CUs, this one goes first (_dev.ATOM_PRIORITY = False: default priority)
             prio = -1 if _dev.ATOM_PRIORITY else 0
             side = self._ATOM_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=prio)
-        if ready is None:
-            D = schedule.to_device(dev)._dev
-            side.wait_stream(main)
-        else:
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                fresh = schedule._dev is None
-                D = schedule.to_device(dev)._dev
-                if fresh:      # allocated on this stream, read on the main one later: the allocator must know
-                    for t in D.get("native") or D.get("packs") or ():
-                        if isinstance(t, torch.Tensor) and t.is_cuda:
-                            t.record_stream(main)
+        side.wait_stream(main)
         from .atom_decode import compact_enabled
         with torch.cuda.stream(side):
             if compact_enabled():       # issued now; its autograd node is created at the join, behind the encoder's

@@ -214,17 +214,6 @@ class StepMetrics(dict):
         return dict.__repr__(self)
 
 
-_SCHEDULE_POOL = []
-
-
-def _schedule_pool():
-    """One idle helper thread per process for the decode schedule of the batch in flight (HierPropertyVAE.forward)."""
-    if not _SCHEDULE_POOL:
-        from concurrent.futures import ThreadPoolExecutor
-        _SCHEDULE_POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="ggpm-schedule"))
-    return _SCHEDULE_POOL[0]
-
-
 class HierPropertyVAE(nn.Module):
     """reference ggpm/property_vae.py:11-62 -- encoder, latent heads, teacher-forced decoder; the class
     ``OPVNet.get_model('hier-prop')`` returns (ggpm/opvnet.py:4-9) and ``vae_train.py:78`` calls as
@@ -254,32 +243,20 @@ class HierPropertyVAE(nn.Module):
     def forward(self, mols, graphs, tensors, orders, homos=None, lumos=None, beta=0.0, perturb_z=True, schedule=None):
         if schedule is None:
             schedule = getattr(graphs, "ggpm_schedule", None)       # dataloader.ScheduleAhead: built one batch ahead
-        pending = None
         if schedule is None and graphs is not None:
             # the reference's call shape, ``model(*batch, beta=beta)`` (vae_train.py:78): derive the decoder's integer
             # bookkeeping HERE, from the batch as it arrives (host arrays: no read-back), so that the atom level can be
-            # issued beside the encoder exactly as with a prepared schedule.  The build is 1.7 ms of host time per batch of 32
-            # (C++, the GIL released): a helper thread does it while this thread uploads the batch and issues the encoder,
-            # which needs nothing of it (_dev.SCHEDULE_BESIDE_ENCODER = False: built first, on this thread).
+            # issued beside the encoder exactly as with a prepared schedule
             from .decoder import DecodeSchedule
-            hints = self.decoder.schedule_hints()
-            if _dev.SCHEDULE_BESIDE_ENCODER and _dev.ATOM_AHEAD:
-                pending = _schedule_pool().submit(DecodeSchedule.from_graphs, graphs, tensors, orders, self.decoder.vocab, **hints)
-            else:
-                schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab, **hints)
+            schedule = DecodeSchedule.from_graphs(graphs, tensors, orders, self.decoder.vocab, **self.decoder.schedule_hints())
         tree_tensors, graph_tensors = tensors = make_cuda(tensors)
         F_.mark("fwd: inputs on the device")
-        ready = None
-        if pending is None:
-            self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
-            F_.mark("fwd: atom level posted")
-        elif tree_tensors[0].is_cuda:
-            ready = torch.cuda.Event()
-            ready.record()
+        self.decoder.start_atom_level(schedule, tensors)       # independent of the latent vector: issued beside the encoder
+        F_.mark("fwd: atom level posted")
         # beside the atom level's chain of small launches the encoder's levels take half as many (twice as large)
         # workgroups: the chain's launches then find free compute units instead of waiting for the encoder's to drain
         from . import fused
-        beside = (pending is not None or getattr(self.decoder, "_atom_ahead", None) is not None) and _dev.ENC_NARROW
+        beside = getattr(self.decoder, "_atom_ahead", None) is not None and _dev.ENC_NARROW
         fused.NARROW[0] = beside
         try:
             root_vecs = self.encoder.forward_padded(tree_tensors, graph_tensors)[0]
@@ -287,10 +264,6 @@ class HierPropertyVAE(nn.Module):
             fused.NARROW[0] = False
         root_vecs, kl_div = rsample(root_vecs, self.R_mean, self.R_var, perturb_z)
         F_.mark("fwd: encoder + rsample issued")
-        if pending is not None:
-            schedule = pending.result()
-            self.decoder.start_atom_level(schedule, tensors, ready=ready)
-            F_.mark("fwd: atom level posted")
         loss, wacc, iacc, tacc, sacc = self.decoder(mols, (root_vecs, root_vecs, root_vecs), graphs, tensors, orders,
                                                     schedule=schedule)
         loss = loss + beta * kl_div

@@ -125,20 +125,11 @@ def test_forward_with_graphs_equals_forward_with_a_prebuilt_schedule():
         loss.backward()
         return float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}
 
-    la, ga = run()                       # (default: the schedule is built on a helper thread while the encoder is issued)
+    la, ga = run()
     lb, gb = run(schedule=DecodeSchedule.from_specs(specs, batch[2]))
     assert la == lb
     for k in ga:
         assert torch.equal(ga[k], gb[k]), k
-    from ggpm_amd import _dev
-    was, _dev.SCHEDULE_BESIDE_ENCODER = _dev.SCHEDULE_BESIDE_ENCODER, False      # built first, on the calling thread
-    try:
-        lc, gc_ = run()
-    finally:
-        _dev.SCHEDULE_BESIDE_ENCODER = was
-    assert la == lc
-    for k in ga:
-        assert torch.equal(ga[k], gc_[k]), k
 
 
 def test_schedule_ahead_loop_equals_the_plain_loop():
