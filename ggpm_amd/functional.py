@@ -114,7 +114,7 @@ class _StagingRing:
     fresh tensor is a cudaHostAlloc of several milliseconds per call -- more than the copy -- so the bytes go through a
     small ring of pinned buffers that are allocated once and grow on demand."""
 
-    def __init__(self, slots: int = 4):
+    def __init__(self, slots: int = 8):      # (three uploads per batch in the vae_train.py call shape: a slot is reused 2-3 batches later)
         self.slots, self.bufs, self.events, self.i = slots, [None] * slots, [None] * slots, 0
 
     def upload(self, a, device) -> torch.Tensor:
