@@ -441,7 +441,7 @@ __device__ __forceinline__ void ggpm_wave_gemm_split(const __bf16* const (&imgs)
                     lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring.r[d][o][0], b[1], lo_, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot
-#ifndef GGPM_ABL_NOLOAD            // (timing / traffic ablation: no weight-plane refills -- the ring keeps its first chunks)
+#ifndef GGPM_ABL_NOLOAD_SPLIT      // (timing / traffic ablation: no weight-plane refills -- the ring keeps its first chunks)
 #pragma unroll
                 for (int o = 0; o < NOPS; ++o)
 #pragma unroll
