@@ -661,6 +661,21 @@ class VaeWorkload:
             _settle_gc()
             self._fence()
             allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            self._gc_events = []
+            if os.environ.get("GGPM_BENCH_NO_GC"):
+                import gc
+                gc.disable()
+            if os.environ.get("GGPM_BENCH_TRACE_STEPS"):
+                import gc
+                gc.callbacks[:] = []
+                st = {}
+
+                def _cb(phase, info, st=st, ev=self._gc_events):
+                    if phase == "start":
+                        st["t"] = time.perf_counter()
+                    else:
+                        ev.append((info["generation"], round(1e3 * (time.perf_counter() - st["t"]), 2), info["collected"], st["t"]))
+                gc.callbacks.append(_cb)
             t0 = time.perf_counter()
             marks, issue = [t0], []
             for i in range(steps):
@@ -685,6 +700,7 @@ class VaeWorkload:
             self.region_log = {}
         self.region_log[what] = {"attempts": len(readings), "ms_per_step_of_each_attempt": readings,
                                  "device_allocs_in_reported_attempt": int(grew)}
+        self._step_trace = [(1e3 * (b - a), [e for e in self._gc_events if a <= e[3] < b]) for a, b in zip(marks, marks[1:])]
         return 1e3 * dt / steps, [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
 
     def work(self):
@@ -738,6 +754,16 @@ class VaeWorkload:
                m["Loss"]))
         if getattr(self.a, "vae_profile", None) == "resident":      # (rocprofv3 runs: the trace ends with the resident steps)
             return {"ms_per_step": round(ms, 3), "steps": steps, "rnn_type": self.rnn}
+        if getattr(self.a, "vae_profile", None) == "gc":          # what cyclic garbage does one step leave?
+            from tools.gc_cycles import cycles_of
+            for label, fn in (("resident", self.step), ("in_loop", self.step_in_loop)):
+                k = [0]
+
+                def one(fn=fn, k=k):
+                    fn(k[0])
+                    k[0] += 1
+                log("cyclic garbage of 4 %s steps: " % label + "\n".join(cycles_of(one, repeat=4)))
+            return {"ms_per_step": round(ms, 3), "steps": steps, "rnn_type": self.rnn}
         if getattr(self.a, "vae_profile", None) == "in_loop":
             for i in range(len(self.items)):
                 self.step_in_loop(i)
@@ -760,6 +786,7 @@ class VaeWorkload:
             self.step_in_loop(i)
         loop_ms, loop_raw = self._timed(self.step_in_loop, min(steps, 20), 0, "in_loop")
         loop_issue = self.host_issue_ms
+        loop_trace = self._step_trace
         # ... and with the loop's iterator wrapped (dataloader.ScheduleAhead): the schedule of batch k+1 built during step k
         self._ahead = None
         for i in range(len(self.items)):
@@ -774,8 +801,13 @@ class VaeWorkload:
             b6 = self.items[k % len(self.items)][3]
             DecodeSchedule.from_graphs(b6[1], b6[2], b6[3], self.vocab, **hints)
         build_ms = 1e3 * (time.perf_counter() - t0) / 16
-        log("  ... %.2f ms/step as vae_train.py calls it (host batch + networkx graphs in; schedule build %.2f ms of host time); "
-            "%.2f ms/step with the loop's iterator wrapped in ScheduleAhead" % (loop_ms, build_ms, ahead_ms))
+        lr = sorted(loop_raw)
+        if os.environ.get("GGPM_BENCH_TRACE_STEPS"):
+            log("  in-loop per step (ms; of which gc ms @ highest generation): " + " ".join(
+                "%.2f(%.2f@%s)" % (x, sum(e[1] for e in evs), max([e[0] for e in evs], default="-")) for x, evs in loop_trace))
+        log("  ... %.2f ms/step as vae_train.py calls it (host batch + networkx graphs in; schedule build %.2f ms of host time; per "
+            "step: min %.2f, median %.2f, max %.2f); %.2f ms/step with the loop's iterator wrapped in ScheduleAhead"
+            % (loop_ms, build_ms, lr[0], lr[len(lr) // 2], lr[-1], ahead_ms))
         fl_exec, fl_alg = self.work()
         tf = fl_exec * self.world / (ms * 1e-3) / 1e12
         out = {"ms_per_step": round(ms, 3), "value": round(B * self.world / (ms * 1e-3), 2), "unit": "molecules/s",
@@ -953,7 +985,7 @@ def parse_args(argv=None):
                     help="skip the run of the other message function (configs[1] reports GRU and, under \"lstm\", LSTM)")
     ap.add_argument("--no-vae", action="store_true", help="skip the full-VAE-step row (\"vae_step\", configs[1], N = 1)")
     ap.add_argument("--only-vae", action="store_true", help="profiling: run ONLY the full-VAE-step row and print it")
-    ap.add_argument("--vae-profile", default=None, choices=["resident", "in_loop"],
+    ap.add_argument("--vae-profile", default=None, choices=["resident", "in_loop", "gc"],
                     help="with --only-vae under rocprofv3: stop after the resident steps / after the vae_train.py-shaped steps, so "
                          "that the trace ends with the steps to be cut out (tools/prof_summary.py --steps)")
     ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] leg of the default line (\"configs4\": fp32 + bf16)")

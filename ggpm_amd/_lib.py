@@ -140,3 +140,16 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().ggpm_error_string(code).decode()
         raise RuntimeError("ggpm_amd: %s failed: %s (code %d)" % (what, msg, code))
+
+
+_ARRAY_TYPES: dict = {}
+
+
+def array_type(base, n: int):
+    """``base * n``, remembered.  ctypes only keeps array types weakly: once the last instance is gone the type (a class, i.e.
+    a reference cycle) waits for Python's collector and the next ``base * n`` builds it again -- tens of microseconds on the
+    thread that issues the launches, several times per training step."""
+    t = _ARRAY_TYPES.get((base, n))
+    if t is None:
+        t = _ARRAY_TYPES[(base, n)] = base * n
+    return t

@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -179,6 +180,7 @@ class AtomPlan:
         """Host tables only: device copies and the descriptors that name them stay with the process that made them."""
         st = dict(self.__dict__)
         st["_dev"] = {}
+        st["_schedule"] = self._schedule() if self._schedule is not None else None       # (the weak reference back: __setstate__)
         st["_ct"] = {k: dict(v, dev={}) for k, v in self._ct.items()}
         if self._native is not None:
             from .decoder import _FrozenTables
@@ -188,6 +190,11 @@ class AtomPlan:
             st["_raw_cache"] = None
         return st
 
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        if self._schedule is not None:
+            self._schedule = weakref.ref(self._schedule)
+
     # ------------------------------------------------------------------ tables built by csrc/schedule.hip
     @classmethod
     def from_native(cls, schedule, nt, n_gnodes: int, n_gmess: int) -> "AtomPlan":
@@ -196,7 +203,9 @@ class AtomPlan:
         (depth, gates) the build was given are already there."""
         self = cls.__new__(cls)
         sc, g = nt.scalars(), nt.get
-        self._native, self._schedule = nt, schedule
+        # (weak: the schedule owns this plan -- a strong reference back would make the pair, and with it every device table of
+        # the batch, a reference cycle that only Python's collector frees)
+        self._native, self._schedule = nt, weakref.ref(schedule)
         self.T, self.N1, self.E1, self.full, self.ok = sc["T"], n_gnodes, n_gmess, False, bool(sc["ok"])
         self.nloc, self.floc_off = g("nloc").tolist(), g("floc_off").tolist()
         self.aoff, self.ioff = schedule.plan["atom_off"], schedule.plan["inst_off"]
@@ -238,11 +247,17 @@ class AtomPlan:
                                                         native=True)
         return self
 
+    def _owner(self):
+        sch = self._schedule() if self._schedule is not None else None
+        if sch is None:
+            raise RuntimeError("AtomPlan: the DecodeSchedule these tables belong to is gone")
+        return sch
+
     @property
     def _raw(self):
         """per step (rows, local frozen mask, incoming-message table, pool table) -- what compact_tables reads"""
         if self._raw_cache is None:
-            nt, P = self._native, self._schedule.plan
+            nt, P = self._native, self._owner().plan
             rows_all, rows_off = nt.get("rows").astype(np.int64), nt.get("rows_off").tolist()
             loc = nt.get("loc").reshape(-1, P["pool"].shape[1])
             self._raw_cache = []
@@ -348,7 +363,7 @@ class AtomPlan:
         device = torch.device(device)
         D = self._dev.get(device)
         if D is None and self._native is not None:
-            sd = self._schedule.to_device(device)._dev
+            sd = self._owner().to_device(device)._dev
             d64, d32 = sd["native"]
             nd = self._native.dir
 
@@ -403,16 +418,16 @@ def _decode_steps(plan: "AtomPlan", D, ct, cp, H: int, depth: int, lstm: bool):
         return hit
     T, ptr = plan.T, D["ptr"]
     roff, qoff = plan.row_offsets(depth)
-    arr32 = (ctypes.c_int32 * T)(*plan.nloc)
-    a64 = lambda v: (ctypes.c_int64 * (T + 1))(*[int(x) for x in v])
-    pa = lambda vals: (ctypes.c_void_p * T)(*[int(v) for v in vals])
+    arr32 = _lib.array_type(ctypes.c_int32, T)(*plan.nloc)
+    a64 = lambda v: _lib.array_type(ctypes.c_int64, T + 1)(*[int(x) for x in v])
+    pa = lambda vals: _lib.array_type(ctypes.c_void_p, T)(*[int(v) for v in vals])
     frz = D["frozen_loc"].data_ptr()
     keep = dict(n=arr32, foff=a64(ct["foff"]), roff=a64(roff), qoff=a64(qoff),
                 srcH=pa(cp[("srcH", t)] for t in range(T)), srcF=pa(cp[("srcF", t)] for t in range(T)),
                 frozen=pa(frz + plan.floc_off[t] for t in range(T)),
                 pred_rowptr=pa(ptr[("lpred_rp", t)] for t in range(T)), pred_col=pa(ptr[("lpred_col", t)] for t in range(T)),
                 succ_rowptr=pa(ptr[("lsucc_rp", t)] for t in range(T)), succ_col=pa(ptr[("lsucc_col", t)] for t in range(T)))
-    d = DecodeSteps(T, H, depth, int(lstm), *[ctypes.cast(keep[k], ctypes.c_void_p) for k in
+    d = DecodeSteps(T, H, depth, int(lstm), *[ctypes.addressof(keep[k]) for k in
                                                ("n", "foff", "roff", "qoff", "srcH", "srcF", "frozen", "pred_rowptr",
                                                 "pred_col", "succ_rowptr", "succ_col")])
     D["desc"][key] = (d, keep)      # beside the tensors whose addresses it holds
@@ -645,8 +660,8 @@ class _AtomDecodeCompact(torch.autograd.Function):
             hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
         else:
             hw = ((Wz, I), (Ur, 0), (Wh, I))
-        W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
-        ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
+        W_arr = _lib.array_type(ctypes.c_void_p, 4)(*[w[:, c:].data_ptr() for w, c in hw])
+        ld_arr = _lib.array_type(ctypes.c_int, 4)(*[w.stride(0) for w, _ in hw])
         deferred = False
         if _dev.DECODE_DRIVER:         # the whole step loop as one C call (csrc/decode.hip)
             desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
@@ -802,11 +817,11 @@ class _AtomDecodeCompact(torch.autograd.Function):
                 hw = ((Wi, I), (Wo_g, I), (Wu, I), (Wf, I))
             else:
                 hw = ((Wz, I), (Ur, 0), (Wh, I))
-            W_arr = (ctypes.c_void_p * 4)(*[w[:, c:].data_ptr() for w, c in hw])
-            ld_arr = (ctypes.c_int * 4)(*[w.stride(0) for w, _ in hw])
+            W_arr = _lib.array_type(ctypes.c_void_p, 4)(*[w[:, c:].data_ptr() for w, c in hw])
+            ld_arr = _lib.array_type(ctypes.c_int, 4)(*[w.stride(0) for w, _ in hw])
             desc, _keep = _decode_steps(plan, D, ct, cp, H, depth, lstm)
             tmp = torch.empty(2 * nmax, Hp, **f32)
-            dW_arr = (ctypes.c_void_p * 4)(*([a.data_ptr() for a in acc] + ([] if len(acc) == 4 else [0])))
+            dW_arr = _lib.array_type(ctypes.c_void_p, 4)(*([a.data_ptr() for a in acc] + ([] if len(acc) == 4 else [0])))
             fn = lib.ggpm_decode_steps_backward_async if go_async else lib.ggpm_decode_steps_backward
             _lib.check(fn(
                 ctypes.byref(desc), W_arr, ld_arr, P(X_all), P(Hs_all), P(Cs_all) if lstm else None, P(Qs_all), P(St_all),

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -60,7 +61,8 @@ class CSR:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, rows: int, ncols: int):
         self.rowptr, self.col, self.rows, self.ncols = rowptr, col, rows, ncols
         self._T: Optional["CSR"] = None
-        self._T_event = None
+        self._back = None           # on a transpose: weak reference to the CSR it was built from (a strong one would make the
+        self._T_event = None        # pair a reference cycle, and its device tensors would wait for Python's collector)
         self._keep = None
 
     def _build_T(self) -> "CSR":
@@ -72,13 +74,16 @@ class CSR:
         _lib.check(lib.ggpm_csr_transpose(_p(self.rowptr), _p(self.col), self.rows, self.ncols, _p(rowptrT),
                                           _p(colT), _p(cursor), _stream()), "csr_transpose")
         t = CSR(rowptrT, colT, self.ncols, self.rows)
-        t._T = self
+        t._back = weakref.ref(self)
         t._keep = cursor
         return t
 
     @property
     def T(self) -> "CSR":
         if self._T is None:
+            back = self._back() if self._back is not None else None
+            if back is not None:
+                return back
             self._T = self._build_T()
         ev = self._T_event
         if ev is not None:          # built ahead of time on the second stream: order this stream behind it once
@@ -90,7 +95,7 @@ class CSR:
 def prefetch_transposes(csrs: Sequence["CSR"]) -> None:
     """Build the transposes the BACKWARD will need on the second stream while the forward runs (each is a
     single-workgroup integer kernel of ~10 us that would otherwise sit on the backward's critical path)."""
-    todo = [c for c in csrs if c is not None and c._T is None]
+    todo = [c for c in csrs if c is not None and c._T is None and (c._back is None or c._back() is None)]
     if not todo or not side_stream_enabled():
         return
     main = torch.cuda.current_stream()
@@ -199,7 +204,8 @@ def csr_from_index(idx: torch.Tensor, ncols: int) -> CSR:
         return hit
     rows = idx.numel()
     rowptr = torch.arange(rows + 1, dtype=torch.int32, device=idx.device)
-    return _memo_put(idx, "_ggpm_csr_index", ncols, CSR(rowptr, idx, rows, ncols))
+    # (the remembered CSR holds an alias of `idx`, not the object the memo hangs on: no reference cycle)
+    return _memo_put(idx, "_ggpm_csr_index", ncols, CSR(rowptr, idx.detach(), rows, ncols))
 
 
 def extract_column(mat: torch.Tensor, column: int) -> torch.Tensor:
@@ -247,7 +253,7 @@ def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems, splitk: boo
     up to four independent products of one shape in one launch.  ``splitk``: the K range in chunks where the group has few
     output tiles and a long K (ggpm_gemm_grouped_splitk: weight gradients over all rows of a level)."""
     lib = _lib.load()
-    arr = (GemmProblem * len(problems))()
+    arr = _lib.array_type(GemmProblem, len(problems))()
     for i, q in enumerate(problems):
         arr[i] = GemmProblem(_p(q["A"]), q["lda"], _p(q["B"]), q["ldb"], _p(q["C"]), q["ldc"], q["n_pad"],
                              _p(q.get("bias")), int(q.get("accumulate", False)), q.get("act", ACT_NONE),
@@ -255,10 +261,10 @@ def gemm_grouped(ta: int, tb: int, M: int, N: int, K: int, problems, splitk: boo
     wsb = int(lib.ggpm_gemm_grouped_splitk_workspace_bytes(M, N, K, len(problems))) if splitk else 0
     if wsb:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=problems[0]["C"].device)
-        _lib.check(lib.ggpm_gemm_grouped_splitk(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p), _p(ws), wsb,
+        _lib.check(lib.ggpm_gemm_grouped_splitk(ta, tb, M, N, K, len(problems), ctypes.addressof(arr), _p(ws), wsb,
                                                 _stream()), "gemm_grouped_splitk")
         return
-    _lib.check(lib.ggpm_gemm_grouped(ta, tb, M, N, K, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()),
+    _lib.check(lib.ggpm_gemm_grouped(ta, tb, M, N, K, len(problems), ctypes.addressof(arr), _stream()),
                "gemm_grouped")
 
 
@@ -284,10 +290,10 @@ def gemm_ksegments(tb: int, M: int, N: int, As, ldas, Bs, ldbs, Ks, C: torch.Ten
                    zero_row0: bool = False) -> None:
     """C = act(sum_s A_s B_s' + bias (+ C)) in one launch (up to four K segments)."""
     n = len(As)
-    pa = (ctypes.c_void_p * n)(*[_p(a) for a in As])
-    pb = (ctypes.c_void_p * n)(*[_p(b) for b in Bs])
-    la, lb, kk = (ctypes.c_int * n)(*ldas), (ctypes.c_int * n)(*ldbs), (ctypes.c_int * n)(*Ks)
-    cast = lambda x: ctypes.cast(x, ctypes.c_void_p)
+    vp, ci = _lib.array_type(ctypes.c_void_p, n), _lib.array_type(ctypes.c_int, n)
+    pa, pb = vp(*[_p(a) for a in As]), vp(*[_p(b) for b in Bs])
+    la, lb, kk = ci(*ldas), ci(*ldbs), ci(*Ks)
+    cast = ctypes.addressof          # (ctypes.cast would leave each array in a reference cycle with itself)
     _lib.check(_lib.load().ggpm_gemm_ksegments(tb, M, N, n, cast(pa), cast(la), cast(pb), cast(lb), cast(kk), _p(C), ldc,
                                                n_pad, _p(bias), int(accumulate), act, int(zero_row0), _stream()),
                "gemm_ksegments")
@@ -753,11 +759,11 @@ def _defer_flush(side: Optional[torch.cuda.Stream] = None) -> None:
             if db is not None:
                 publish(bias, db)
         if items:
-            arr = (WgradItem * len(items))(*[WgradItem(*it) for it in items])
+            arr = _lib.array_type(WgradItem, len(items))(*[WgradItem(*it) for it in items])
             dev = keep[0][0].device
             ws = torch.empty(ws_max // 4, dtype=torch.float32, device=dev) if ws_max else None
             csws = torch.empty(256 * n_max, dtype=torch.float32, device=dev)
-            _lib.check(lib.ggpm_linear_wgrads_batch(len(items), ctypes.cast(arr, ctypes.c_void_p), _p(ws), ws_max, _p(csws),
+            _lib.check(lib.ggpm_linear_wgrads_batch(len(items), ctypes.addressof(arr), _p(ws), ws_max, _p(csws),
                                                     _stream()), "linear_wgrads_batch")
         for param, grads in sums.values():
             publish(param, use(grads[0]) if len(grads) == 1 else torch.stack([use(g) for g in grads], dim=0).sum(dim=0))

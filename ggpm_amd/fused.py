@@ -63,7 +63,7 @@ def _arena_size(nbytes: int) -> int:
 
 
 def _ptr_array(tensors) -> ctypes.Array:
-    arr = (ctypes.c_void_p * len(tensors))()
+    arr = _lib.array_type(ctypes.c_void_p, len(tensors))()
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr()
     return arr
