@@ -662,9 +662,6 @@ class VaeWorkload:
             self._fence()
             allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
             self._gc_events = []
-            if os.environ.get("GGPM_BENCH_NO_GC"):
-                import gc
-                gc.disable()
             if os.environ.get("GGPM_BENCH_TRACE_STEPS"):
                 import gc
                 gc.callbacks[:] = []

@@ -16,6 +16,8 @@ import numpy as np
 from . import _lib
 
 _P64 = ctypes.POINTER(ctypes.c_int64)
+_view = ctypes.pythonapi.PyMemoryView_FromMemory          # (address, bytes, PyBUF_WRITE = 0x200) -> memoryview, no copy
+_view.restype, _view.argtypes = ctypes.py_object, (ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int)
 
 
 class SchedIn(ctypes.Structure):
@@ -59,7 +61,9 @@ class NativeTables:
         for which in (0, 1, 2):
             _lib.check(lib.ggpm_schedule_pack(handle, which, ctypes.byref(ptr), ctypes.byref(nb)), "schedule_pack")
             if nb.value and ptr.value:
-                self._bytes[which] = np.frombuffer((ctypes.c_uint8 * nb.value).from_address(ptr.value), dtype=np.uint8)
+                # (a memoryview over the library's buffer; ``(c_uint8 * n).from_address`` would create a new ctypes array TYPE
+                # per distinct size -- three classes per batch, each a reference cycle left to Python's collector)
+                self._bytes[which] = np.frombuffer(_view(ptr.value, nb.value, 0x200), dtype=np.uint8)
             else:
                 self._bytes[which] = np.zeros(0, dtype=np.uint8)
         self.packs = {1: self._bytes[1].view(np.int64), 2: self._bytes[2].view(np.int32)}
