@@ -46,7 +46,7 @@ class NativeTables:
     def __init__(self, handle, lib):
         self._h, self._lib = handle, lib
         cap = 1 << 13
-        buf = ctypes.create_string_buffer(cap)
+        buf = _lib.array_type(ctypes.c_char, cap)()       # (create_string_buffer builds the array type anew per call)
         _lib.check(lib.ggpm_schedule_names(handle, buf, cap), "schedule_names")
         self.names = buf.value.decode().split("\n")[:-1]
         table = np.empty(4 * len(self.names), dtype=np.int64)

@@ -263,3 +263,41 @@ def test_a_parameter_with_a_hook_gets_its_gradient_through_autograd():
     assert len(seen) == 1 and seen[0] > 0
     want = torch.ones(5, 16, device=dev).t() @ x
     assert float((lin.weight.grad - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("rnn", ["GRU", "LSTM"])
+def test_a_training_step_leaves_nothing_for_the_cyclic_collector(rnn):
+    """vae_train.py's loop body, repeated: every object a step creates is freed by reference counting when the step is over.
+    Reference cycles (a CSR and its transpose naming each other, an index memo that leads back to its own tensor, the atom
+    plan and its schedule, a ``ctypes.cast`` result, a ctypes array type built per call) would hold a finished batch's device
+    tables until Python's collector comes round and cost its passes on the thread that issues the launches."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from tools.gc_cycles import cycles_of
+    from ggpm_amd import synth
+    from ggpm_amd.property_vae import HierPropertyVAE
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(40, 120)
+    configs = _Configs(vocab, rnn_type=rnn, hidden_size=64, embed_size=64, latent_size=16, depthT=6, depthG=6, dropout=0.1)
+    torch.manual_seed(5)
+    model = HierPropertyVAE(configs).to(_dev())
+    _init_like_vae_train(model)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    dataset = [synth.train_batch(synth.random_batch(200 + i, 6, motifs=(2, 7), n_motif_vocab=40, n_attach_vocab=120))
+               for i in range(2)]
+    k = [0]
+
+    def step():
+        batch = dataset[k[0] % 2]
+        k[0] += 1
+        model.zero_grad()
+        loss, metrics = model(*batch, beta=0.1)
+        loss.backward()
+        optimizer.step()
+        assert math.isfinite(metrics["Loss"])
+
+    step()
+    step()
+    report = cycles_of(step, repeat=4)
+    assert report[0].startswith("0 objects"), "\n".join(report)

@@ -207,3 +207,33 @@ def test_published_gradients_are_not_stream_marked_by_default():
     finally:
         _dev.RECORD_GRADS = was
 
+
+
+def test_index_structures_and_ctypes_marshalling_create_no_reference_cycles():
+    """The host objects the step builds per call are freed by reference counting: the CSR remembered on an index
+    tensor does not lead back to that tensor object, a transpose names its source weakly, array types are remembered."""
+    import ctypes
+    import gc
+    import weakref
+    import torch
+    from ggpm_amd import _lib
+    from ggpm_amd import functional as F_
+    assert _lib.array_type(ctypes.c_void_p, 3) is _lib.array_type(ctypes.c_void_p, 3)
+    assert _lib.array_type(ctypes.c_int, 3) is not _lib.array_type(ctypes.c_int, 4)
+    gc.collect()
+    gc.disable()
+    try:
+        idx = torch.tensor([2, 0, 1, 2], dtype=torch.int32)
+        csr = F_.csr_from_index(idx, 3)
+        assert F_.csr_from_index(idx, 3) is csr                      # remembered on the tensor ...
+        assert csr.col is not idx and csr.col.data_ptr() == idx.data_ptr()      # ... through an alias, not the object itself
+        t = F_.CSR(torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int32), 3, 4)
+        t._back = weakref.ref(csr)                                   # (what _build_T sets on a transpose)
+        assert t.T is csr
+        probe = weakref.ref(csr)
+        del csr, idx, t
+        assert probe() is None, "the CSR of an index tensor is kept alive by a reference cycle"
+        arr = _lib.array_type(ctypes.c_void_p, 2)(1, 2)
+        assert ctypes.addressof(arr) and arr._objects is None        # (ctypes.cast(arr, c_void_p) would store arr in arr._objects)
+    finally:
+        gc.enable()

@@ -18,6 +18,8 @@ def _name(o):
         n += "{" + ",".join(sorted(map(str, list(o.keys())[:5]))) + "}"
     elif t is tuple or t is list:
         n += "[%d]" % len(o)
+    elif isinstance(o, type):
+        n += "<%s>" % o.__name__
     return n
 
 
