@@ -154,12 +154,33 @@ __global__ void __launch_bounds__(SCAN_THREADS) padded_to_csr_small(const int64_
     }
 }
 
+// Ascending order inside every transposed row makes the backward sums deterministic.  Rows of up to SORT_SERIAL entries are
+// sorted by the thread that owns the column; longer ones (an index with few distinct ids: the molecule of every prediction
+// row, 90 rows per molecule -- 320 us of serial insertion sort through global memory before) by RANK through LDS: one wave
+// per row of up to SORT_WAVE_CAP entries, the whole workgroup per row beyond that (up to 16 384 entries).
+constexpr int SORT_SERIAL = 24, SORT_WAVE_CAP = 512, SORT_WAVES = SCAN_THREADS / 64, SORT_LIST = 512;
+constexpr int SORT_BLOCK_CAP = SORT_WAVES * SORT_WAVE_CAP;      // entries of one LDS chunk of the workgroup path
+constexpr int SORT_PER_THREAD = 16;                             // workgroup path: rows of up to 16 x 1024 entries
+
+__device__ __forceinline__ void insertion_sort_global(int32_t* colT, int lo, int hi) {
+    for (int i = lo + 1; i < hi; ++i) {
+        const int32_t v = colT[i];
+        int j = i - 1;
+        while (j >= lo && colT[j] > v) { colT[j + 1] = colT[j]; --j; }
+        colT[j + 1] = v;
+    }
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS) csr_transpose_small(const int32_t* __restrict__ rowptr,
                                                                      const int32_t* __restrict__ col, int rows,
                                                                      int ncols, int32_t* __restrict__ rowptrT,
                                                                      int32_t* __restrict__ colT,
                                                                      int32_t* __restrict__ cursor) {
     __shared__ int32_t partial[SCAN_THREADS];
+    __shared__ int32_t stage[SORT_BLOCK_CAP];
+    __shared__ int32_t wave_list[SORT_LIST], block_list[SORT_LIST];
+    __shared__ int32_t n_wave, n_block;
+    if (threadIdx.x == 0) { n_wave = 0; n_block = 0; }
     for (int c = threadIdx.x; c <= ncols; c += SCAN_THREADS) rowptrT[c] = 0;
     for (int c = threadIdx.x; c < ncols; c += SCAN_THREADS) cursor[c] = 0;
     __syncthreads();
@@ -176,14 +197,60 @@ __global__ void __launch_bounds__(SCAN_THREADS) csr_transpose_small(const int32_
             if (c >= 0 && c < ncols) colT[rowptrT[c] + atomicAdd(&cursor[c], 1)] = r;
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < ncols; c += SCAN_THREADS) {     // ascending order => deterministic sums
-        const int lo = rowptrT[c], hi = rowptrT[c + 1];
-        for (int i = lo + 1; i < hi; ++i) {
-            const int32_t v = colT[i];
-            int j = i - 1;
-            while (j >= lo && colT[j] > v) { colT[j + 1] = colT[j]; --j; }
-            colT[j + 1] = v;
+    for (int c = threadIdx.x; c < ncols; c += SCAN_THREADS) {
+        const int lo = rowptrT[c], hi = rowptrT[c + 1], n = hi - lo;
+        if (n <= SORT_SERIAL) { insertion_sort_global(colT, lo, hi); continue; }
+        int slot = -1;
+        if (n <= SORT_WAVE_CAP) { slot = atomicAdd(&n_wave, 1); if (slot < SORT_LIST) wave_list[slot] = c; }
+        else if (n <= SORT_PER_THREAD * SCAN_THREADS) { slot = atomicAdd(&n_block, 1); if (slot < SORT_LIST) block_list[slot] = c; }
+        if (slot < 0 || slot >= SORT_LIST) insertion_sort_global(colT, lo, hi);      // (no room in the lists / longer than the LDS)
+    }
+    __syncthreads();
+    const int nw = min((int)n_wave, SORT_LIST), nb = min((int)n_block, SORT_LIST);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int base = 0; base < nw; base += SORT_WAVES) {         // (uniform trip count: the barriers below are reached by every wave)
+        const int k = base + wave;
+        int lo = 0, n = 0;
+        if (k < nw) { const int c = wave_list[k]; lo = rowptrT[c]; n = rowptrT[c + 1] - lo; }
+        int32_t* mine = stage + wave * SORT_WAVE_CAP;
+        for (int i = lane; i < n; i += 64) mine[i] = colT[lo + i];
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) {
+            const int32_t v = mine[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) { const int32_t x = mine[j]; rank += (x < v) || (x == v && j < i); }
+            colT[lo + rank] = v;
         }
+        __syncthreads();
+    }
+    for (int k = 0; k < nb; ++k) {
+        // up to SORT_PER_THREAD entries per thread stay in registers while the row passes through the LDS in chunks
+        const int c = block_list[k], lo = rowptrT[c], n = rowptrT[c + 1] - lo;
+        int32_t v[SORT_PER_THREAD];
+        int rank[SORT_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < SORT_PER_THREAD; ++q) {
+            const int i = threadIdx.x + q * SCAN_THREADS;
+            v[q] = i < n ? colT[lo + i] : 0;
+            rank[q] = 0;
+        }
+        for (int c0 = 0; c0 < n; c0 += SORT_BLOCK_CAP) {
+            const int cn = min(SORT_BLOCK_CAP, n - c0);
+            for (int j = threadIdx.x; j < cn; j += SCAN_THREADS) stage[j] = colT[lo + c0 + j];
+            __syncthreads();
+            for (int j = 0; j < cn; ++j) {
+                const int32_t x = stage[j];
+                const int gj = c0 + j;
+#pragma unroll
+                for (int q = 0; q < SORT_PER_THREAD; ++q)
+                    rank[q] += (x < v[q]) || (x == v[q] && gj < threadIdx.x + q * SCAN_THREADS);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < SORT_PER_THREAD; ++q)
+            if (threadIdx.x + q * SCAN_THREADS < n) colT[lo + rank[q]] = v[q];
+        __syncthreads();
     }
 }
 

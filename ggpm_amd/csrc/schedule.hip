@@ -336,6 +336,61 @@ extern "C" void* ggpm_schedule_build(const ggpm_sched_in* in) {
         for (int64_t e = 1; e < E1; ++e) { mi.push_back(mess_inst[(size_t)e]); mp.push_back(tfmess[e * 4 + 2]); }
     }
 
+    // ---------------------------------------------------------------- index structures of the batched tree-side levels and of
+    // the heads, exactly as the device kernels derive them from the tables above (ggpm_padded_to_csr keeps the in-row order of
+    // the non-zero entries, ggpm_csr_transpose lists the rows of every column ascending): a batch that arrives with its schedule
+    // brings them in the same upload instead of ~30 single-workgroup launches in front of the levels and the backward
+    {
+        auto csr_pair = [&](const V& table, int64_t nrows_tab, int64_t width, int64_t first_row, int64_t total_rows, int64_t ncols,
+                            const std::string& name, const std::string& nameT) {
+            V &rp = S->put(name + "_rp", 2), &col = S->put(name + "_col", 2);
+            V er, ec;
+            rp.assign((size_t)total_rows + 1, 0);
+            for (int64_t r = 0; r < nrows_tab; ++r) {
+                int64_t cnt = 0;
+                for (int64_t j = 0; j < width; ++j) {
+                    const int64_t p = table[(size_t)(r * width + j)];
+                    if (p != 0) { col.push_back(p); er.push_back(first_row + r); ec.push_back(p); ++cnt; }
+                }
+                rp[(size_t)(first_row + r) + 1] = cnt;
+            }
+            for (int64_t i = 0; i < total_rows; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
+            col.push_back(0);                              // (never an empty table: its address is handed to kernels)
+            V &rpT = S->put(nameT + "_rp", 2), &colT = S->put(nameT + "_col", 2);
+            transpose(er, ec, ncols, rpT, colT);
+            colT.push_back(0);
+        };
+        auto index_T = [&](const V& idx, int64_t ncols, const std::string& nameT) {
+            V rows(idx.size());
+            for (size_t i = 0; i < rows.size(); ++i) rows[i] = (int64_t)i;
+            V &rpT = S->put(nameT + "_rp", 2), &colT = S->put(nameT + "_col", 2);
+            transpose(rows, idx, ncols, rpT, colT);
+            colT.push_back(0);
+        };
+        const int64_t n_extra[2] = {0, B};
+        const V* dags[2] = {&dag_inter, &dag_tree};
+        const V* ins[2] = {&in_inter, &in_tree};
+        const char* tag[2] = {"inter", "tree"};
+        for (int l = 0; l < 2; ++l) {
+            const int64_t Etot = E1 + n_extra[l];
+            const std::string t = tag[l];
+            csr_pair(*dags[l], E1 - 1, Kt, 1, Etot, Etot, "pred_" + t, "succ_" + t);
+            csr_pair(*ins[l], n_inst, At, 0, n_inst, Etot, "in_" + t, "inT_" + t);
+            V& fz = S->put("frozen_" + t, 3);              // rows the level never recomputes: the pad row and the pseudo rows
+            fz.assign((size_t)Etot, 0);
+            fz[0] = 1;
+            for (int64_t e = E1; e < Etot; ++e) fz[(size_t)e] = 1;
+        }
+        V mi(mess_inst.begin() + 1, mess_inst.end());
+        index_T(mi, std::max<int64_t>(n_inst, 1), "srcT");
+        index_T(topo_batch, B, "topoT");
+        index_T(S->a["cls_batch"], B, "clsT");
+        index_T(S->a["assm_batch"], B, "assmT");
+        V& iota = S->put("iota", 2);                        // rowptr of every one-entry-per-row CSR: a prefix of 0, 1, 2, ...
+        const size_t longest = std::max({mi.size(), topo_batch.size(), S->a["cls_batch"].size(), S->a["assm_batch"].size()});
+        iota.resize(longest + 1);
+        for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int64_t)i;
+    }
     lap("level plan");
     // ---------------------------------------------------------------- AtomPlan (compact row sets)
     V &nloc = S->put("nloc", 0), &floc_off = S->put("floc_off", 0), &frozen_loc = S->put("frozen_loc", 3);

@@ -17,6 +17,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -335,6 +336,36 @@ class DecodeSchedule:
         self._dev = dict(device=device, steps=None, n_assm=nt.scalars()["n_assm"], host=None, plan=plan, native=(d64, d32),
                          **{k: view(k) for k in ("topo_label", "cls_clab", "cls_ilab", "topo_batch32", "cls_batch32",
                                                  "assm_batch32")})
+        if nt.has("pred_tree_rp"):
+            # the CSRs, transposes and frozen masks of the two tree-side levels and the transposes the heads' backward sums
+            # over came with the upload (csrc/schedule.hip): nothing is derived on the device for a batch seen for the first time
+            sc = nt.scalars()
+            E1, n_inst, B = sc["E1"], sc["n_inst"], sc["B"]
+            iota = view("iota")
+
+            def pair(rp, col, rows, ncols, rpT, colT):
+                c, t = F_.CSR(rp, col, rows, ncols), F_.CSR(rpT, colT, ncols, rows)
+                c._T, t._back = t, weakref.ref(c)
+                return c
+
+            def index_csr(idx, ncols, nameT):
+                return pair(iota[:idx.numel() + 1], idx, idx.numel(), ncols, view(nameT + "_rp"), view(nameT + "_col"))
+
+            def bytes_of(name):
+                _, off, cnt, _ = nt.dir[name]
+                return d32.view(torch.uint8)[off:off + cnt]
+
+            src = index_csr(plan["mess_inst"], n_inst, "srcT")
+            structs = {}
+            for tag, n_extra in (("inter", 0), ("tree", B)):
+                Etot = E1 + n_extra
+                structs[tag] = (bytes_of("frozen_" + tag),
+                                pair(view("pred_%s_rp" % tag), view("pred_%s_col" % tag), Etot, Etot,
+                                     view("succ_%s_rp" % tag), view("succ_%s_col" % tag)),
+                                pair(view("in_%s_rp" % tag), view("in_%s_col" % tag), n_inst, Etot,
+                                     view("inT_%s_rp" % tag), view("inT_%s_col" % tag)), src)
+            self._dev["level_structs"] = structs
+            self._dev["head_csr"] = {k: index_csr(self._dev[k + "_batch32"], B, k + "T") for k in ("topo", "cls", "assm")}
         return self
 
     # ------------------------------------------------------------------ device copy (one upload)
@@ -546,7 +577,8 @@ class HierMPNDecoder(ScoreHeads):
                 cls_lab_raw=D["cls_clab"], icls_lab_raw=D["cls_ilab"], topo_lab_raw=D["topo_label"],
                 n_assm=D["n_assm"], max_cls_size=schedule.max_cls_size,
                 assm_idx=i32(D["assm_batch32"]) if D["n_assm"] > 0 else None,
-                assm_lab=_memo(D, "assm_labels32", lambda: torch.zeros(max(D["n_assm"], 1), dtype=torch.int32, device=dev)))
+                assm_lab=_memo(D, "assm_labels32", lambda: torch.zeros(max(D["n_assm"], 1), dtype=torch.int32, device=dev)),
+                idx_csr=D.get("head_csr") or {})          # molecule -> its prediction rows, when the schedule's builder made them
         spec = dict(spec, assm_blocks=blocks)
         tv = topo_vecs if (topo_vecs.dim() == 2 and topo_vecs.stride(1) == 1 and topo_vecs.stride(0) % 4 == 0) else topo_vecs.contiguous()
         cv = cls_vecs if (cls_vecs.dim() == 2 and cls_vecs.stride(1) == 1 and cls_vecs.stride(0) % 4 == 0) else cls_vecs.contiguous()
@@ -747,9 +779,12 @@ class HierMPNDecoder(ScoreHeads):
             specs = D.get("level_specs")
             if specs is None:
                 B_ = init_vecs.shape[0]
+                pre = D.get("level_structs") or {}
                 specs = D["level_specs"] = (
-                    TD.LevelSpec(T["inst_attach"], T["mess_inst"], T["mess_pos"], T["dag_inter"], T["in_inter"], E1, 0, depth),
-                    TD.LevelSpec(T["inst_motif"], T["mess_inst"], T["mess_pos"], T["dag_tree"], T["in_tree"], E1, B_, depth))
+                    TD.LevelSpec(T["inst_attach"], T["mess_inst"], T["mess_pos"], T["dag_inter"], T["in_inter"], E1, 0, depth,
+                                 prebuilt=pre.get("inter")),
+                    TD.LevelSpec(T["inst_motif"], T["mess_inst"], T["mess_pos"], T["dag_tree"], T["in_tree"], E1, B_, depth,
+                                 prebuilt=pre.get("tree") if pre.get("tree") is not None and pre["tree"][1].rows == E1 + B_ else None))
             hinter_node, _ = TD.tree_level(specs[0], ie.rnn, hmpn.E_i, hmpn.W_i, ie.W_o, pooled, None)
             htree_node, hid_t = TD.tree_level(specs[1], te.rnn, hmpn.E_c, hmpn.W_c, te.W_o, hinter_node,
                                               init_vecs.contiguous())

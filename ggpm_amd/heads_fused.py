@@ -79,10 +79,13 @@ def _mlp_backward(seq, x, cxt, h, ds, H: int, L: int, dx: Optional[torch.Tensor]
     return dx, dcxt
 
 
-def _scatter_context(dcxt: torch.Tensor, idx32: torch.Tensor, B: int, L: int) -> torch.Tensor:
-    """backward of z.index_select(0, idx): the rows of one molecule summed in a fixed order (transposed CSR)"""
+def _scatter_context(dcxt: torch.Tensor, idx32: torch.Tensor, B: int, L: int, csr=None) -> torch.Tensor:
+    """backward of z.index_select(0, idx): the rows of one molecule summed in a fixed order (transposed CSR; ``csr``: the one
+    that came with the schedule's upload)"""
     dz = torch.empty(B, L, dtype=torch.float32, device=dcxt.device)
-    F_._segment_sum_raw(dcxt, F_.csr_from_index(idx32, ncols=B).T, L, dz)
+    if csr is None or csr.rows != idx32.numel() or csr.ncols != B:
+        csr = F_.csr_from_index(idx32, ncols=B)
+    F_._segment_sum_raw(dcxt, csr.T, L, dz)
     return dz
 
 
@@ -197,13 +200,13 @@ class _Heads(torch.autograd.Function):
         ds_t = torch.zeros(n_t, S["ld_st"], **f32)
         ds_t[:, 0] = S["dx_t"] * g
         dtopo_x, dcxt_t = _mlp_backward(heads.topoNN, S["topo_x"], S["cxt_t"], S["h_t"], ds_t, H, L, None, False)
-        dz = _scatter_context(dcxt_t, spec["topo_idx"], B, L)
+        dz = _scatter_context(dcxt_t, spec["topo_idx"], B, L, spec.get("idx_csr", {}).get("topo"))
         # ---- class heads (both read the same rows: one input gradient, two scatters into the same context rows)
         dcls_x, dcxt_c = _mlp_backward(heads.clsNN, S["cls_x"], S["cxt_c"], S["h_c"],
                                        scale(S["d_c"], heads.clsNN[3].weight.shape[0]), H, L, None, False)
         dcls_x, dcxt_i = _mlp_backward(heads.iclsNN, S["cls_x"], S["cxt_c"], S["h_i"],
                                        scale(S["d_i"], heads.iclsNN[3].weight.shape[0]), H, L, dcls_x, True)
-        dz = dz + _scatter_context(dcxt_c.add_(dcxt_i), spec["cls_idx"], B, L)
+        dz = dz + _scatter_context(dcxt_c.add_(dcxt_i), spec["cls_idx"], B, L, spec.get("idx_csr", {}).get("cls"))
         # ---- attachment head
         dcand = None
         if P > 0:
@@ -214,7 +217,7 @@ class _Heads(torch.autograd.Function):
             dproj[:, :L] = d_a * cxt_a[:, :L]
             dcxt_a = torch.zeros_like(cxt_a)
             dcxt_a[:, :L] = d_a * proj[:, :L]
-            dz = dz + _scatter_context(dcxt_a, spec["assm_idx"], B, L)
+            dz = dz + _scatter_context(dcxt_a, spec["assm_idx"], B, L, spec.get("idx_csr", {}).get("assm"))
             wa = heads.W_assm
             dbuf = torch.empty(P * C, Hp, **f32)
             F_.gemm(0, 0, P * C, H, L, dproj, F_._ld(dproj), wa.weight, wa.weight.stride(0), dbuf, Hp, Hp)

@@ -40,13 +40,17 @@ def enabled() -> bool:
 class LevelSpec:
     """The index tables of one level of one schedule on one device (built once per schedule, see decoder.py)."""
 
-    def __init__(self, ids, mess_inst, mess_pos, dag, in_table, E1: int, n_extra: int, depth: int):
+    def __init__(self, ids, mess_inst, mess_pos, dag, in_table, E1: int, n_extra: int, depth: int, prebuilt=None):
         self.ids, self.mess_inst, self.mess_pos, self.dag, self.in_table = ids, mess_inst, mess_pos, dag, in_table
         self.E1, self.n_extra, self.depth = E1, n_extra, depth
-        self.rows = torch.arange(1, E1, dtype=torch.long, device=dag.device)
+        self.prebuilt = prebuilt          # the four structures below, when the schedule's builder made them (csrc/schedule.hip)
+        self.rows = None if prebuilt is not None else torch.arange(1, E1, dtype=torch.long, device=dag.device)
 
     def structures(self):
-        """(frozen mask, predecessor CSR, incoming CSR, message -> visit CSR, visit id CSR): memoised on the index tensors"""
+        """(frozen mask, predecessor CSR, incoming CSR, message -> visit CSR): part of the schedule's upload, or derived on
+        the device and memoised on the index tensors"""
+        if self.prebuilt is not None:
+            return self.prebuilt
         Etot = self.E1 + self.n_extra
         frozen, pred, _ = F_._sparse_structure(Etot, self.rows, self.dag)
         return (frozen, pred, F_.csr_from_padded(self.in_table, ncols=Etot),

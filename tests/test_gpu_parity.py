@@ -48,6 +48,38 @@ def test_padded_to_csr_and_transpose(rows, width):
         assert list(cl[rp[c]:rp[c + 1]]) == sorted(exp_T[c])
 
 
+@pytest.mark.parametrize("rows,ncols", [(2832, 32), (3000, 7), (9000, 1), (16000, 3), (16300, 1), (700, 6214), (5000, 40)])
+def test_transpose_of_an_index_with_few_ids(rows, ncols):
+    """csr_from_index(idx).T when many rows share an id (the molecule of every prediction row; 9000 rows of ONE id): the
+    transposed rows are sorted by rank through LDS -- by one wave up to 512 entries, by the workgroup up to 16 384, serially
+    beyond -- and must list the rows ascending whichever path took them."""
+    from ggpm_amd import functional as F_
+    rs = np.random.RandomState(rows + ncols)
+    idx = rs.randint(0, ncols, size=rows).astype(np.int32)
+    if ncols == 40:
+        idx[: rows // 2] = 5           # one long row among short ones
+    T = F_.csr_from_index(torch.from_numpy(idx).to(_dev()), ncols=ncols).T
+    rp, cl = T.rowptr.cpu().numpy(), T.col.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == rows
+    order = np.argsort(idx, kind="stable")
+    assert np.array_equal(cl[:rows], order.astype(np.int32))
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=ncols))]))
+
+
+def test_transpose_keeps_repeated_entries():
+    """a padded table whose rows name the same column twice: both entries appear in the transposed row"""
+    from ggpm_amd import functional as F_
+    rows, width, ncols = 400, 6, 3
+    rs = np.random.RandomState(4)
+    padded = rs.randint(1, ncols, size=(rows, width)).astype(np.int64)
+    padded[0] = 0
+    T = F_.csr_from_padded(torch.from_numpy(padded).to(_dev()), ncols=ncols).T
+    rp, cl = T.rowptr.cpu().numpy(), T.col.cpu().numpy()
+    for c in range(ncols):
+        exp = sorted(r for r in range(rows) for v in padded[r] if v == c and v != 0)
+        assert list(cl[rp[c]:rp[c + 1]]) == exp
+
+
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 33, 70, 62), (0, 1, 513, 300, 320), (0, 0, 257, 62, 300),
                                          (1, 0, 300, 320, 5000), (1, 0, 16, 16, 40), (0, 1, 1, 1, 1),
                                          (1, 1, 65, 66, 67), (0, 1, 2751, 300, 62),

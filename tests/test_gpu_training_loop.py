@@ -301,3 +301,38 @@ def test_a_training_step_leaves_nothing_for_the_cyclic_collector(rnn):
     step()
     report = cycles_of(step, repeat=4)
     assert report[0].startswith("0 objects"), "\n".join(report)
+
+
+def test_index_structures_that_come_with_the_schedule_equal_the_device_built_ones():
+    """csrc/schedule.hip puts the CSRs, transposes and frozen masks of the two tree-side levels and the transposes of the
+    heads' molecule indices into the schedule's upload; the device kernels (ggpm_padded_to_csr, ggpm_csr_transpose) derive
+    the same structures from the same tables: entry for entry."""
+    from ggpm_amd import functional as F_, synth, tree_decode as TD
+    from ggpm_amd.decoder import DecodeSchedule
+    specs = synth.random_batch(31, 9, motifs=(3, 9), n_motif_vocab=40, n_attach_vocab=120)
+    tensors = synth.tensorize(specs)
+    sch = DecodeSchedule.from_specs(specs, tensors, depth=5, gates=3)
+    assert sch._native is not None
+    D = sch.to_device(_dev())._dev
+    T, E1, B = D["plan"], sch.plan["E1"], sch.batch_size
+    pre = D["level_structs"]
+
+    def same_csr(a, b, what):
+        assert (a.rows, a.ncols) == (b.rows, b.ncols), what
+        nnz = int(b.rowptr[-1])
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col[:nnz], b.col[:nnz]), what
+        at, bt = a.T, b.T
+        assert torch.equal(at.rowptr, bt.rowptr) and torch.equal(at.col[:nnz], bt.col[:nnz]), what + " (transposed)"
+
+    for tag, ids, n_extra in (("inter", "inst_attach", 0), ("tree", "inst_motif", B)):
+        plain = TD.LevelSpec(T[ids], T["mess_inst"], T["mess_pos"], T["dag_" + tag], T["in_" + tag], E1, n_extra, 5)
+        frozen, pred, inc, src = plain.structures()
+        f2, p2, i2, s2 = pre[tag]
+        assert torch.equal(frozen, f2), tag
+        same_csr(p2, pred, tag + " pred")
+        same_csr(i2, inc, tag + " incoming")
+        same_csr(s2, src, tag + " source")
+    for k in ("topo", "cls", "assm"):
+        idx = D[k + "_batch32"]
+        if idx.numel():
+            same_csr(D["head_csr"][k], F_.csr_from_index(idx.clone(), ncols=B), k)

@@ -105,6 +105,72 @@ def test_native_schedule_equals_the_numpy_builders(case, depth, gates):
     assert pa.row_offsets(depth) == pb.row_offsets(depth)
 
 
+def _csr_of_padded(table, first_row, total_rows):
+    """what ggpm_padded_to_csr makes of ``table`` placed at rows first_row.. of a [total_rows, width] zero table"""
+    rp, col = np.zeros(total_rows + 1, dtype=np.int64), []
+    for r, row in enumerate(np.asarray(table)):
+        nz = [int(v) for v in row if v != 0]
+        col.extend(nz)
+        rp[first_row + r + 1] = len(nz)
+    return np.cumsum(rp), np.asarray(col, dtype=np.int64)
+
+
+def _transpose(rp, col, ncols):
+    """ggpm_csr_transpose: per column the rows that name it, ascending"""
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    order = np.lexsort((rows, col))
+    return np.concatenate([[0], np.cumsum(np.bincount(col, minlength=ncols))]), rows[order]
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_native_level_and_head_index_structures(case):
+    """The CSRs, transposes and frozen masks of the two tree-side levels and the transposes of the heads' molecule indices
+    that csrc/schedule.hip puts into the upload, against the statement of what the device kernels derive from the NUMPY
+    builder's tables (padded -> CSR keeps the in-row order of the non-zero entries; a transpose lists rows ascending)."""
+    specs, tensors = _batch(CASES[case])
+    nat = DecodeSchedule.from_specs(specs, tensors, depth=5, gates=3, native=True)
+    ref = DecodeSchedule.from_specs(specs, tensors, native=False)
+    if nat._native is None:
+        return
+    g, P = nat._native.get, ref.plan
+    E1, n_inst, B = P["E1"], P["n_inst"], ref.batch_size
+
+    def same(name, exp, pad=False):
+        got = np.asarray(g(name), dtype=np.int64)
+        if pad:                                            # (col tables carry one trailing 0 so that none is empty)
+            assert got[-1] == 0
+            got = got[:-1]
+        assert got.shape == np.asarray(exp).shape and np.array_equal(got, exp), (case, name)
+
+    for tag, n_extra in (("inter", 0), ("tree", B)):
+        Etot = E1 + n_extra
+        rp, col = _csr_of_padded(P["dag_" + tag], 1, Etot)
+        same("pred_%s_rp" % tag, rp)
+        same("pred_%s_col" % tag, col, pad=True)
+        rpT, colT = _transpose(rp, col, Etot)
+        same("succ_%s_rp" % tag, rpT)
+        same("succ_%s_col" % tag, colT, pad=True)
+        rp, col = _csr_of_padded(P["in_" + tag], 0, n_inst)
+        same("in_%s_rp" % tag, rp)
+        same("in_%s_col" % tag, col, pad=True)
+        rpT, colT = _transpose(rp, col, Etot)
+        same("inT_%s_rp" % tag, rpT)
+        same("inT_%s_col" % tag, colT, pad=True)
+        frozen = np.ones(Etot, dtype=np.int64)
+        frozen[1:E1] = 0
+        same("frozen_" + tag, frozen)
+    heads = {"srcT": (np.asarray(P["mess_inst"], dtype=np.int64), n_inst), "topoT": (np.asarray(ref.topo()[0], dtype=np.int64), B),
+             "clsT": (np.asarray(ref.cls()[0], dtype=np.int64), B),
+             "assmT": (np.repeat(np.asarray(ref.assm_batch(), dtype=np.int64), ref.max_cls_size), B)}
+    longest = 0
+    for name, (idx, ncols) in heads.items():
+        rpT, colT = _transpose(np.arange(len(idx) + 1), idx, ncols)
+        same(name + "_rp", rpT)
+        same(name + "_col", colT, pad=True)
+        longest = max(longest, len(idx))
+    same("iota", np.arange(longest + 1))
+
+
 def test_native_schedule_survives_pickling():
     """Loader workers build schedules and ship them: a natively built one converts its tables to plain arrays."""
     specs, tensors = _batch(CASES["small"])
