@@ -563,6 +563,11 @@ int ggpm_timing_collect(int which, int* launches, double* total_ms, double* flop
  *   per tree node v: the attachment ids of its inter_label, icls[icls_off[v] .. icls_off[v+1]) (k_v = their number), and
  *   its assm_cands as cand_off[v+1] - cand_off[v] candidates of k_v atoms each, flat from cands[cand_atom_off[v]].
  * depth / gates: also build the tables that depend on the decoder's diterG and cell (3 GRU / 4 LSTM); 0 = leave out.
+ * The int32 pack also carries the index structures the device would otherwise derive per batch from those tables
+ * (ggpm_padded_to_csr / ggpm_csr_transpose semantics: in-row order kept, transposed rows ascending): for the two
+ * tree-side levels L in {inter, tree} pred_L / succ_L / in_L / inT_L (_rp, _col) and frozen_L (bytes), the message ->
+ * visit transpose srcT, the transposes topoT / clsT / assmT of the heads' molecule indices, and iota (the rowptr of any
+ * one-entry-per-row CSR); every _col table ends with one pad entry so that none is empty.
  * Returns an opaque handle (NULL: malformed input); tables are read with ggpm_schedule_get by name (pack 0 = host
  * only; 1 / 2 = inside the int64 / int32 device pack; ggpm_schedule_pack returns a pack's base, `offset` is in bytes from it).  The
  * call keeps no global state and may run on any thread. */
