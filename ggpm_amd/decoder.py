@@ -101,12 +101,39 @@ class DecodeSchedule:
         """From the reference's batch tuple: ``graphs = (tree_batchG, graph_batchG)`` (networkx, as produced by
         ``MolGraph.tensorize``).  Only the two labels that are not in the tensors are read from the node attributes."""
         tree_batch = graphs[0]
+        from . import schedule_native as SN
+        if kw.get("native") is not False and DecodeSchedule._native_wanted():
+            # one pass over the nodes straight into the flat arrays the C++ builder reads (no per-node tuples / dicts)
+            flat = SN.labels_from_graph(tree_batch, vocab, int(np.shape(tensors[0][0])[0]))
+            if flat is not None:
+                S = DecodeSchedule._build_native(tensors, orders, flat, kw.get("depth"), kw.get("gates"))
+                if S is not None:
+                    return S
         inter_icls, assm_cands = {}, {}
         for v, attr in tree_batch.nodes(data=True):
             cls = attr["smiles"]
             inter_icls[v] = tuple(vocab[(cls, icls)][1] for _, icls in attr["inter_label"])
             assm_cands[v] = list(attr["assm_cands"])
         return DecodeSchedule.from_tensors(tensors, orders, inter_icls, assm_cands, **kw)
+
+    @staticmethod
+    def _native_wanted() -> bool:
+        from . import schedule_native as SN
+        return bool(SN.enabled() and _dev.DECODER_BATCHED and _dev.ATOM_DECODE and _dev.ATOM_COMPACT)
+
+    @staticmethod
+    def _build_native(tensors, orders, labels, depth, gates) -> "Optional[DecodeSchedule]":
+        """The schedule over tables built by csrc/schedule.hip, or None (the library declined the batch, or the batch is one
+        of the degenerate ones that take the step-by-step forms: the numpy builder handles both)."""
+        from . import schedule_native as SN
+        nt = SN.build_tables(tensors, orders, labels, None, depth or 0, gates or 0)
+        if nt is None:
+            return None
+        sc = nt.scalars()
+        if not (sc["ok"] and sc["all_live"] and sc["E1"] > 1):
+            return None
+        inter_icls, assm_cands = labels.views() if isinstance(labels, SN.FlatLabels) else labels
+        return DecodeSchedule._from_native(nt, tensors, inter_icls, assm_cands)
 
     @staticmethod
     def from_specs(specs, tensors, orders=None, **kw) -> "DecodeSchedule":
@@ -130,13 +157,15 @@ class DecodeSchedule:
         prepare the tables that depend on them as well; ``native=False`` forces the numpy builder (the checker)."""
         from . import schedule_native as SN
         if native is None:
-            native = SN.enabled() and _dev.DECODER_BATCHED and _dev.ATOM_DECODE and _dev.ATOM_COMPACT
+            native = DecodeSchedule._native_wanted()
         if native:
-            nt = SN.build_tables(tensors, orders, inter_icls, assm_cands, depth or 0, gates or 0)
-            if nt is not None:
-                sc = nt.scalars()
-                if sc["ok"] and sc["all_live"] and sc["E1"] > 1:      # (anything else takes the step-by-step forms)
-                    return DecodeSchedule._from_native(nt, tensors, inter_icls, assm_cands)
+            flat = SN.labels_from_dicts(inter_icls, assm_cands, int(np.shape(tensors[0][0])[0]))
+            if flat is not None:
+                nt = SN.build_tables(tensors, orders, flat, None, depth or 0, gates or 0)
+                if nt is not None:
+                    sc = nt.scalars()
+                    if sc["ok"] and sc["all_live"] and sc["E1"] > 1:      # (anything else takes the step-by-step forms)
+                        return DecodeSchedule._from_native(nt, tensors, inter_icls, assm_cands)
         tree_tensors, graph_tensors = tensors
         host = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
         tfnode, tfmess, cgraph = host(tree_tensors[0]), host(tree_tensors[1]), host(tree_tensors[4])

@@ -95,22 +95,47 @@ class NativeTables:
         raise TypeError("NativeTables holds a library handle; pickle the DecodeSchedule (it converts itself)")
 
 
-def build_tables(tensors, orders, inter_icls: Dict[int, Tuple[int, ...]], assm_cands: Dict[int, list], depth: int = 0,
-                 gates: int = 0) -> "NativeTables | None":
-    """-> NativeTables, or None when the library declines the batch (malformed orders / labels: the numpy builder then
-    raises the informative error)."""
-    lib = _lib.load()
-    tree, graph = tensors
-    tfnode, tfmess, tagraph, tbgraph, cgraph = (_i64(x) for x in tree[:5])
-    gfmess, gagraph, gbgraph = _i64(graph[1]), _i64(graph[2]), _i64(graph[3])
-    if tfnode.ndim != 2 or tfnode.shape[1] != 2 or tfmess.ndim != 2 or tfmess.shape[1] != 4 or gfmess.shape[1] != 4:
-        return None
-    scope = np.ascontiguousarray(np.asarray(tree[-1], dtype=np.int64).reshape(-1, 2))
-    B, Nt1 = len(orders), tfnode.shape[0]
-    od = np.asarray([(x, -1 if y is None else y, z) for o in orders for (x, y, z) in o], dtype=np.int64).reshape(-1, 3)
-    ooff = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum([len(o) for o in orders], out=ooff[1:])
-    # per tree node: its attachment ids (k of them) and its candidates (tuples of k atoms, or bare atoms when k = 1), flat
+class _View:
+    """read-only ``mapping[v]`` over a function of the node id (what DecodeSchedule keeps as its labels)"""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __getitem__(self, v):
+        return self._fn(int(v))
+
+    def get(self, v, default=None):
+        try:
+            return self._fn(int(v))
+        except IndexError:
+            return default
+
+
+class FlatLabels:
+    """Per tree node v the two labels that are not in the tensors, flat, as ``ggpm_schedule_build`` reads them: the attachment
+    ids of its inter_label (``icls[icls_off[v]:icls_off[v+1]]``, k_v of them) and its assm_cands as ``cand_off[v+1] -
+    cand_off[v]`` candidates of k_v atoms each from ``cands[cand_atom_off[v]:]``."""
+
+    def __init__(self, icls_n, cand_n, atom_n, icls_flat, cand_flat):
+        self.icls_off, self.cand_off, self.cand_atom_off = (np.cumsum(np.asarray(x, dtype=np.int64)) for x in (icls_n, cand_n, atom_n))
+        self.icls, self.cands = np.asarray(icls_flat, dtype=np.int64), np.asarray(cand_flat, dtype=np.int64)
+        self.ok = self.cands.size == self.cand_atom_off[-1] and self.icls.size == self.icls_off[-1]
+
+    def icls_of(self, v: int) -> tuple:
+        return tuple(self.icls[self.icls_off[v]:self.icls_off[v + 1]].tolist())
+
+    def cands_of(self, v: int) -> np.ndarray:
+        n, k = int(self.cand_off[v + 1] - self.cand_off[v]), int(self.icls_off[v + 1] - self.icls_off[v])
+        a0 = int(self.cand_atom_off[v])
+        return self.cands[a0:a0 + n * k].reshape(n, max(k, 1)) if n else np.zeros((0, max(k, 1)), dtype=np.int64)
+
+    def views(self):
+        """(inter_icls, assm_cands) as mappings over the node id"""
+        return _View(self.icls_of), _View(self.cands_of)
+
+
+def labels_from_dicts(inter_icls: Dict[int, Tuple[int, ...]], assm_cands: Dict[int, list], Nt1: int) -> "FlatLabels | None":
+    """None: a node whose candidates do not have one atom per attachment id (the numpy builder raises the informative error)."""
     icls_n, cand_n, atom_n = [0] * (Nt1 + 1), [0] * (Nt1 + 1), [0] * (Nt1 + 1)
     icls_flat, cand_flat = [], []
     for v in range(Nt1):
@@ -134,10 +159,67 @@ def build_tables(tensors, orders, inter_icls: Dict[int, Tuple[int, ...]], assm_c
                 cand_flat.extend(c)
             cand_n[v + 1] = len(c)
             atom_n[v + 1] = len(c) * k
-    icls_off, cand_off, cand_atom_off = (np.cumsum(np.asarray(x, dtype=np.int64)) for x in (icls_n, cand_n, atom_n))
-    icls, cands = np.asarray(icls_flat, dtype=np.int64), np.asarray(cand_flat, dtype=np.int64)
-    if cands.size != cand_atom_off[-1] or icls.size != icls_off[-1]:
+    out = FlatLabels(icls_n, cand_n, atom_n, icls_flat, cand_flat)
+    return out if out.ok else None
+
+
+def labels_from_graph(tree_batch, vocab, Nt1: int) -> "FlatLabels | None":
+    """The same arrays read straight off the networkx nodes of a batch (``MolGraph.tensorize``'s ``tree_batchG``: attributes
+    ``smiles``, ``inter_label``, ``assm_cands``) in ONE pass -- no per-node tuples and dicts in between.  None when the nodes
+    do not come in ascending id order or a node is not of the expected shape: the caller then takes the dictionary path."""
+    from itertools import chain
+    icls_n, cand_n, atom_n = [0] * (Nt1 + 1), [0] * (Nt1 + 1), [0] * (Nt1 + 1)
+    icls_flat, cand_flat = [], []
+    add_icls, add_cand = icls_flat.extend, cand_flat.extend
+    prev = -1
+    for v, attr in tree_batch.nodes(data=True):
+        if not (prev < v < Nt1):
+            return None
+        prev = v
+        il = attr["inter_label"]
+        k = len(il)
+        if k:
+            cls = attr["smiles"]
+            add_icls([vocab[(cls, ic)][1] for _, ic in il])
+            icls_n[v + 1] = k
+        c = attr["assm_cands"]
+        n = len(c)
+        if n:
+            if isinstance(c, np.ndarray):
+                return None
+            if isinstance(c[0], (list, tuple)):
+                if len(c[0]) != k:
+                    return None
+                add_cand(chain.from_iterable(c))
+            else:
+                if k != 1:
+                    return None
+                add_cand(c)
+            cand_n[v + 1] = n
+            atom_n[v + 1] = n * k
+    out = FlatLabels(icls_n, cand_n, atom_n, icls_flat, cand_flat)
+    return out if out.ok else None
+
+
+def build_tables(tensors, orders, inter_icls, assm_cands=None, depth: int = 0, gates: int = 0) -> "NativeTables | None":
+    """-> NativeTables, or None when the library declines the batch (malformed orders / labels: the numpy builder then
+    raises the informative error).  ``inter_icls``: a :class:`FlatLabels`, or the two dictionaries of the numpy builder."""
+    lib = _lib.load()
+    tree, graph = tensors
+    tfnode, tfmess, tagraph, tbgraph, cgraph = (_i64(x) for x in tree[:5])
+    gfmess, gagraph, gbgraph = _i64(graph[1]), _i64(graph[2]), _i64(graph[3])
+    if tfnode.ndim != 2 or tfnode.shape[1] != 2 or tfmess.ndim != 2 or tfmess.shape[1] != 4 or gfmess.shape[1] != 4:
         return None
+    scope = np.ascontiguousarray(np.asarray(tree[-1], dtype=np.int64).reshape(-1, 2))
+    B, Nt1 = len(orders), tfnode.shape[0]
+    flat = [-1 if v is None else v for o in orders for step in o for v in step]
+    od = np.asarray(flat, dtype=np.int64).reshape(-1, 3)
+    ooff = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum([len(o) for o in orders], out=ooff[1:])
+    labels = inter_icls if isinstance(inter_icls, FlatLabels) else labels_from_dicts(inter_icls, assm_cands, Nt1)
+    if labels is None or labels.icls_off.shape[0] != Nt1 + 1:
+        return None
+    icls_off, cand_off, cand_atom_off, icls, cands = labels.icls_off, labels.cand_off, labels.cand_atom_off, labels.icls, labels.cands
     keep = (tfnode, tfmess, tagraph, tbgraph, cgraph, scope, gfmess, gagraph, gbgraph, od, ooff, icls_off, icls, cand_off,
             cand_atom_off, cands)
     p = lambda a: a.ctypes.data if a.size else 0

@@ -190,6 +190,58 @@ def test_native_schedule_survives_pickling():
     _same(back._native.packs[2], nat._native.packs[2], "pack32")
 
 
+@pytest.mark.parametrize("case", ["configs1", "small", "one_molecule", "mix", "sweep_03", "sweep_11"])
+def test_schedule_from_the_networkx_batch_equals_the_one_from_dictionaries(case):
+    """``from_graphs`` reads the labels off the networkx nodes in one pass straight into the flat arrays of the C++ builder
+    (schedule_native.labels_from_graph); ``from_specs`` goes through the per-node dictionaries.  Same packs, same labels (the
+    lazily rebuilt per-step lists read them), and the label views survive pickling."""
+    from ggpm_amd import schedule_native as SN
+    from ggpm_amd.vocab import IndexPairVocab
+    c = CASES[case]
+    specs, tensors = _batch(c)
+    nm, na = c["vocab"]
+    vocab = IndexPairVocab(nm, na, owner=None if na % nm == 0 else np.arange(na) % nm)
+    b6 = synth.train_batch(specs, tensors)
+    a = DecodeSchedule.from_graphs(b6[1], b6[2], b6[3], vocab, depth=5, gates=3)
+    b = DecodeSchedule.from_specs(specs, tensors, depth=5, gates=3)
+    assert (a._native is None) == (b._native is None)
+    if a._native is None:
+        return
+    flat = SN.labels_from_graph(b6[1][0], vocab, tensors[0][0].shape[0])
+    assert flat is not None                                 # (the fast path was the one taken)
+    assert a._native.names == b._native.names
+    _same(a._native.packs[1], b._native.packs[1], "pack64")
+    _same(a._native.packs[2], b._native.packs[2], "pack32")
+    for name in a._native.names:
+        _same(a._native.get(name), b._native.get(name), name)
+    _same_steps(a.steps, b.steps)
+    back = pickle.loads(pickle.dumps(DecodeSchedule.from_graphs(b6[1], b6[2], b6[3], vocab, depth=5, gates=3)))
+    _same_steps(back.steps, b.steps)
+
+
+def test_labels_from_graph_declines_what_it_does_not_understand():
+    """nodes out of order, or a node whose candidates do not have one atom per attachment id: None (the dictionary path and
+    the numpy builder then take the batch and raise the informative error)"""
+    import networkx as nx
+    from ggpm_amd import schedule_native as SN
+    from ggpm_amd.vocab import IndexPairVocab
+    vocab = IndexPairVocab(30, 90)
+    g = nx.DiGraph()
+    g.add_node(1, smiles=0, inter_label=[(0, 1)], assm_cands=[3, 4])
+    g.add_node(0, smiles=0, inter_label=[], assm_cands=[])
+    assert SN.labels_from_graph(g, vocab, 2) is None        # 1 before 0
+    g = nx.DiGraph()
+    g.add_node(0, smiles=0, inter_label=[], assm_cands=[])
+    g.add_node(1, smiles=0, inter_label=[(0, 1), (0, 2)], assm_cands=[(3,), (4,)])
+    assert SN.labels_from_graph(g, vocab, 2) is None        # two attachment ids, one atom per candidate
+    g = nx.DiGraph()
+    g.add_node(0, smiles=0, inter_label=[], assm_cands=[])
+    g.add_node(1, smiles=0, inter_label=[(0, 1), (0, 2)], assm_cands=[(3, 5), (4, 6)])
+    ok = SN.labels_from_graph(g, vocab, 2)
+    assert ok is not None and ok.cands.tolist() == [3, 5, 4, 6] and ok.cands_of(1).tolist() == [[3, 5], [4, 6]]
+    assert ok.icls_of(1) == tuple(vocab[(0, k)][1] for k in (1, 2)) and ok.icls_of(0) == ()
+
+
 def test_native_builder_refuses_tables_that_index_outside_themselves():
     from ggpm_amd import schedule_native as SN
     from ggpm_amd.decoder import synth_orders
