@@ -237,3 +237,36 @@ def test_index_structures_and_ctypes_marshalling_create_no_reference_cycles():
         assert ctypes.addressof(arr) and arr._objects is None        # (ctypes.cast(arr, c_void_p) would store arr in arr._objects)
     finally:
         gc.enable()
+
+
+def test_bench_harness_term_equals_the_plain_sum_of_the_outputs():
+    """bench.py drives a gradient into every encoder output with ``1e-3 * (hroot.sum() + hnode.sum() + hinter.sum() +
+    hatom.sum())``; over outputs that are row ranges of one buffer it forms that term as ONE reduction and its gradient as ONE
+    fill (bench._SumOutputs).  Same value, same gradients -- also when the outputs are not views of one buffer."""
+    import torch
+    import bench
+    torch.manual_seed(0)
+
+    class Four(torch.autograd.Function):         # four outputs that are row ranges of one buffer, like fused._HierEncoder
+        @staticmethod
+        def forward(ctx, x):
+            out = x * 2.0
+            return out.split([3, 5, 5, 11])
+
+        @staticmethod
+        def backward(ctx, *g):
+            assert all(t.is_contiguous() for t in g)
+            return torch.cat(g, dim=0) * 2.0
+
+    for views in (True, False):
+        x = torch.randn(24, 8, dtype=torch.float64, requires_grad=True)
+        outs = Four.apply(x) if views else tuple(t * 2.0 for t in x.split([3, 5, 5, 11]))
+        a = 1e-3 * bench._sum_outputs(*outs)
+        ga, = torch.autograd.grad(a, x)
+        x2 = x.detach().clone().requires_grad_(True)
+        outs2 = tuple(t * 2.0 for t in x2.split([3, 5, 5, 11]))
+        b = 1e-3 * (outs2[0].sum() + outs2[1].sum() + outs2[2].sum() + outs2[3].sum())
+        gb, = torch.autograd.grad(b, x2)
+        assert abs(float(a) - float(b)) <= 1e-12 * abs(float(b)) and torch.equal(ga, gb), views
+    ragged = (torch.ones(2, 3, requires_grad=True), torch.ones(2, 4, requires_grad=True))
+    assert float(bench._sum_outputs(*ragged)) == 14.0
