@@ -524,10 +524,25 @@ class Workload:
         except Exception:
             pass
         tree = {lv: per[lv][kname] for lv in ("attachment", "motif") if kname in per.get(lv, {})}
+        rocprof = None
+        try:      # the committed rocprofv3 --kernel-trace summary of the same command: its mean duration of this kernel class
+            import glob
+            same1 = all(self.cfg[q] == CONFIGS[1][q] for q in ("hidden", "depth", "batch", "gen"))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_kernel_stats.txt" % self.rnn.lower())))
+            if same1 and self.gate_dtype != "bf16" and files:
+                for line in open(files[-1]):
+                    if line.startswith(kname + "[atom level]"):
+                        us = float(line.split()[3])
+                        # (an event bracket reads ~2 us longer than the kernel itself: the trace's figure is the kernel's)
+                        rocprof = {"avg_launch_us": us, "frac": round(k["gflop_per_launch"] * 1e9 / (us * 1e-6) / 1e12 / peak_tf, 4),
+                                   "source": os.path.relpath(files[-1], ROOT)}
+                        break
+        except Exception:
+            pass
         out = {"kernel": kname, "level": "atom (one 16-wave workgroup per 16 messages, all gate columns)",
                "bound": "mfma", "achieved": k["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
                "frac": k["frac"], "traffic": traffic, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
-               "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "tree_levels": tree,
+               "flops_per_launch_avg": round(k["gflop_per_launch"] * 1e9, 1), "rocprof_trace": rocprof, "tree_levels": tree,
                "all_depth_kernels": per}
         if self.gate_dtype == "bf16":
             # The bf16 leg is priced against HBM (bf16 gate products leave the matrix pipe 16x faster than fp32).
